@@ -1,0 +1,9 @@
+"""MI355X-native reward-scoring forward path for LLaVA-Reward (Phi-3.5-V).
+
+Drop-in surface (mirrors eval/reward_adaptor_loader.py of the reference):
+    load_reward_adaptor, inference_process_phi3v, preference_compute, and a model object whose
+    ``custom_forward`` runs the hand-written HIP path through the C-ABI in ``include/llava_reward_hip.h``.
+"""
+from . import synth  # noqa: F401
+
+__all__ = ["synth"]

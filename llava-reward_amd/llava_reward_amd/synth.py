@@ -1,0 +1,352 @@
+"""Synthetic configs, deterministic weights and synthetic inputs for the reward-scoring path.
+
+No checkpoint and no network exist in the build container or on the GPU box, so parity and
+throughput are measured on seeded synthetic weights.  The generator is a
+counter-based integer hash (splitmix64) so that three implementations produce bit-identical
+tensors: this numpy one (tests, oracle, golden generation), the HIP kernel in
+``csrc/synth_weights.hip`` (full-size weights generated straight into HBM) and any future port.
+
+Element i of tensor `name` under base seed s:
+    t   = splitmix64(s ^ fnv1a64(name))
+    h   = splitmix64(t + i)
+    v   = float(int(h >> 40) - 2**23) * scale          # one exactly-rounded fp32 multiply
+    v   = offset + v ; optionally rounded to bf16 (RNE), as the reference loads bf16 checkpoints
+          (eval/reward_adaptor_loader.py:33-40, torch_dtype=torch.bfloat16)
+`scale = std * sqrt(12) / 2**24` gives a uniform distribution with the requested std.
+
+Weight names follow the reference's state_dict (llava_reward/models/base_mllm/phi3_v/
+modeling_phi3_v.py:1332-1374 Phi3VModel, :118-207 Phi3ImageEmbedding, transformers CLIPVisionModel;
+llava_reward/models/rw_model_general_preference.py:314-326 for the reward heads).
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import Dict, Iterator, List, Tuple
+
+import numpy as np
+
+MASK64 = (1 << 64) - 1
+
+
+# ----------------------------------------------------------------------------------------------
+# configuration
+# ----------------------------------------------------------------------------------------------
+@dataclasses.dataclass
+class ClipConfig:
+    """CLIP ViT geometry; the reference hard-wires ViT-L/14-336 (modeling_phi3_v.py:68-83) and
+    uses hidden_states[-2], i.e. 23 of the 24 layers (utils/utils.py:264-282)."""
+    hidden: int = 1024
+    heads: int = 16
+    mlp: int = 4096
+    layers_used: int = 23
+    image: int = 336
+    patch: int = 14
+    ln_eps: float = 1e-5
+
+    @property
+    def grid(self) -> int:
+        return self.image // self.patch          # 24
+
+    @property
+    def tokens(self) -> int:
+        return self.grid * self.grid + 1         # 577
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden // self.heads
+
+
+@dataclasses.dataclass
+class RewardConfig:
+    """Phi-3.5-V reward model geometry (configuration_phi3_v.py:119-145 + reward_config.yaml keys)."""
+    vocab_size: int = 32064
+    hidden: int = 3072
+    intermediate: int = 8192
+    layers: int = 32
+    heads: int = 32
+    rms_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    max_pos: int = 131072
+    orig_max_pos: int = 4096
+    short_factor: Tuple[float, ...] = ()
+    long_factor: Tuple[float, ...] = ()
+    clip: ClipConfig = dataclasses.field(default_factory=ClipConfig)
+    # reward head (eval/reward_adaptor_loader.py:25-30)
+    is_general_preference: bool = False
+    add_cross_attention: bool = True
+    value_head_dim: int = 1
+    general_preference_tau: float = 0.1
+    ca_eps: float = 1e-5          # RMSNorm_class_eps passed by load_reward_adaptor (:32)
+
+    def __post_init__(self):
+        if not self.short_factor:
+            self.short_factor = default_rope_factors(self.head_dim, 1.0, 0.004)
+        if not self.long_factor:
+            self.long_factor = default_rope_factors(self.head_dim, 1.0, 0.8)
+        if not self.is_general_preference:
+            self.value_head_dim = 1
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden // self.heads
+
+    @property
+    def proj_in(self) -> int:
+        return 4 * self.clip.hidden
+
+    def to_json(self) -> dict:
+        d = dataclasses.asdict(self)
+        d["short_factor"] = list(self.short_factor)
+        d["long_factor"] = list(self.long_factor)
+        return d
+
+    @staticmethod
+    def from_json(d: dict) -> "RewardConfig":
+        d = dict(d)
+        clip = ClipConfig(**d.pop("clip"))
+        d["short_factor"] = tuple(d["short_factor"])
+        d["long_factor"] = tuple(d["long_factor"])
+        return RewardConfig(clip=clip, **d)
+
+
+def default_rope_factors(head_dim: int, base: float, step: float) -> Tuple[float, ...]:
+    """Synthetic su-RoPE factors (the real ones live in the checkpoint's config.json)."""
+    return tuple(float(np.float32(base + step * i)) for i in range(head_dim // 2))
+
+
+def full_config(**kw) -> RewardConfig:
+    """Phi-3.5-vision-instruct shapes (BASELINE.json configs 1-3)."""
+    return RewardConfig(**kw)
+
+
+def ref_small_config(**kw) -> RewardConfig:
+    """Full CLIP ViT-L (the reference cannot build any other tower) + a 2-layer, 384-wide LLM."""
+    base = dict(vocab_size=1024, hidden=384, intermediate=512, layers=2, heads=4)
+    base.update(kw)
+    return RewardConfig(**base)
+
+
+def tiny_config(**kw) -> RewardConfig:
+    """Everything small (engine-vs-oracle tests; not buildable by the reference)."""
+    base = dict(vocab_size=1024, hidden=384, intermediate=512, layers=2, heads=4,
+                clip=ClipConfig(hidden=128, heads=2, mlp=512, layers_used=2))
+    base.update(kw)
+    return RewardConfig(**base)
+
+
+# ----------------------------------------------------------------------------------------------
+# counter-based RNG
+# ----------------------------------------------------------------------------------------------
+def fnv1a64(name: str) -> int:
+    h = 0xCBF29CE484222325
+    for b in name.encode("utf-8"):
+        h ^= b
+        h = (h * 0x100000001B3) & MASK64
+    return h
+
+
+def splitmix64_scalar(x: int) -> int:
+    x = (x + 0x9E3779B97F4A7C15) & MASK64
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+    return z ^ (z >> 31)
+
+
+def tensor_seed(base_seed: int, name: str) -> int:
+    return splitmix64_scalar((base_seed ^ fnv1a64(name)) & MASK64)
+
+
+def _splitmix64_np(x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        z = x
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def round_to_bf16_np(x: np.ndarray) -> np.ndarray:
+    """fp32 -> nearest-even bf16, returned as fp32 (finite inputs only)."""
+    u = x.view(np.uint32)
+    r = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)
+    return r.view(np.float32)
+
+
+def uniform_scale(std: float) -> np.float32:
+    return np.float32(std * math.sqrt(12.0) / 16777216.0)
+
+
+def _gen_chunk(t: np.uint64, s: int, e: int, scale: np.float32, offset: float, out: np.ndarray) -> None:
+    idx = np.arange(s, e, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        h = _splitmix64_np(t + idx)
+    c = (h >> np.uint64(40)).astype(np.int64) - (1 << 23)
+    v = c.astype(np.float32) * scale
+    if offset != 0.0:
+        v = v + np.float32(offset)
+    out[s:e] = v
+
+
+def gen_tensor(base_seed: int, name: str, shape: Tuple[int, ...], std: float, offset: float = 0.0,
+               bf16_valued: bool = True, chunk: int = 1 << 22) -> np.ndarray:
+    """Deterministic fp32 tensor; identical to csrc/synth_weights.hip for the same arguments."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    out = np.empty(n, dtype=np.float32)
+    t = np.uint64(tensor_seed(base_seed, name))
+    scale = uniform_scale(std)
+    spans = [(s, min(n, s + chunk)) for s in range(0, n, chunk)]
+    if len(spans) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        import os
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+            list(ex.map(lambda se: _gen_chunk(t, se[0], se[1], scale, offset, out), spans))
+    else:
+        for s, e in spans:
+            _gen_chunk(t, s, e, scale, offset, out)
+    if bf16_valued:
+        out = round_to_bf16_np(out)
+    return out.reshape(shape)
+
+
+# ----------------------------------------------------------------------------------------------
+# weight inventory
+# ----------------------------------------------------------------------------------------------
+CLIP_PREFIX = "model.vision_embed_tokens.img_processor.vision_model."
+EMB_PREFIX = "model.vision_embed_tokens."
+
+
+def weight_specs(cfg: RewardConfig) -> List[Tuple[str, Tuple[int, ...], float, float]]:
+    """(name, shape, std, offset) for every tensor the path reads.  Linear/embedding std 0.02
+    mirrors _init_weights (modeling_phi3_v.py:1241-1250); norm weights are 1 + small noise so
+    that a dropped or mis-ordered scale vector is visible to the parity tests."""
+    c = cfg.clip
+    D, I = cfg.hidden, cfg.intermediate
+    s: List[Tuple[str, Tuple[int, ...], float, float]] = []
+    s.append(("model.embed_tokens.weight", (cfg.vocab_size, D), 0.02, 0.0))
+    # CLIP tower
+    s.append((CLIP_PREFIX + "embeddings.class_embedding", (c.hidden,), 0.02, 0.0))
+    s.append((CLIP_PREFIX + "embeddings.patch_embedding.weight", (c.hidden, 3, c.patch, c.patch), 0.02, 0.0))
+    s.append((CLIP_PREFIX + "embeddings.position_embedding.weight", (c.tokens, c.hidden), 0.02, 0.0))
+    s.append((CLIP_PREFIX + "pre_layrnorm.weight", (c.hidden,), 0.05, 1.0))
+    s.append((CLIP_PREFIX + "pre_layrnorm.bias", (c.hidden,), 0.02, 0.0))
+    for l in range(c.layers_used):
+        p = f"{CLIP_PREFIX}encoder.layers.{l}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s.append((p + f"self_attn.{nm}.weight", (c.hidden, c.hidden), 0.02, 0.0))
+            s.append((p + f"self_attn.{nm}.bias", (c.hidden,), 0.02, 0.0))
+        s.append((p + "layer_norm1.weight", (c.hidden,), 0.05, 1.0))
+        s.append((p + "layer_norm1.bias", (c.hidden,), 0.02, 0.0))
+        s.append((p + "mlp.fc1.weight", (c.mlp, c.hidden), 0.02, 0.0))
+        s.append((p + "mlp.fc1.bias", (c.mlp,), 0.02, 0.0))
+        s.append((p + "mlp.fc2.weight", (c.hidden, c.mlp), 0.02, 0.0))
+        s.append((p + "mlp.fc2.bias", (c.hidden,), 0.02, 0.0))
+        s.append((p + "layer_norm2.weight", (c.hidden,), 0.05, 1.0))
+        s.append((p + "layer_norm2.bias", (c.hidden,), 0.02, 0.0))
+    # HD transform separators + projector (modeling_phi3_v.py:165-179)
+    s.append((EMB_PREFIX + "glb_GN", (1, 1, cfg.proj_in), 0.02, 0.0))
+    s.append((EMB_PREFIX + "sub_GN", (1, 1, 1, cfg.proj_in), 0.02, 0.0))
+    s.append((EMB_PREFIX + "img_projection.0.weight", (D, cfg.proj_in), 0.02, 0.0))
+    s.append((EMB_PREFIX + "img_projection.0.bias", (D,), 0.02, 0.0))
+    s.append((EMB_PREFIX + "img_projection.2.weight", (D, D), 0.02, 0.0))
+    s.append((EMB_PREFIX + "img_projection.2.bias", (D,), 0.02, 0.0))
+    # decoder
+    for l in range(cfg.layers):
+        p = f"model.layers.{l}."
+        s.append((p + "input_layernorm.weight", (D,), 0.05, 1.0))
+        s.append((p + "self_attn.qkv_proj.weight", (3 * D, D), 0.02, 0.0))
+        s.append((p + "self_attn.o_proj.weight", (D, D), 0.02, 0.0))
+        s.append((p + "post_attention_layernorm.weight", (D,), 0.05, 1.0))
+        s.append((p + "mlp.gate_up_proj.weight", (2 * I, D), 0.02, 0.0))
+        s.append((p + "mlp.down_proj.weight", (D, I), 0.02, 0.0))
+    s.append(("model.norm.weight", (D,), 0.05, 1.0))
+    # reward heads (rw_model_general_preference.py:314-326)
+    if cfg.add_cross_attention:
+        for nm in ("W_q", "W_k", "W_v"):
+            s.append((nm + ".weight", (D, D), 0.02, 0.0))
+        s.append(("ca_layernorm.weight", (D,), 0.05, 1.0))
+    s.append(("value_head.weight", (cfg.value_head_dim, D), 1.0 / math.sqrt(D), 0.0))
+    return s
+
+
+def iter_weights(cfg: RewardConfig, seed: int) -> Iterator[Tuple[str, np.ndarray]]:
+    for name, shape, std, offset in weight_specs(cfg):
+        yield name, gen_tensor(seed, name, shape, std, offset)
+
+
+def make_weights(cfg: RewardConfig, seed: int) -> Dict[str, np.ndarray]:
+    return dict(iter_weights(cfg, seed))
+
+
+# ----------------------------------------------------------------------------------------------
+# input geometry (restates processing_phi3_v.py:83-136,194,269-272 token/crop arithmetic)
+# ----------------------------------------------------------------------------------------------
+def hd_target_size(width: int, height: int, num_crops: int = 16) -> Tuple[int, int, bool]:
+    """Size the HD transform resizes+pads to, as (h, w, transposed).  processing_phi3_v.py:83-104."""
+    trans = False
+    if width < height:
+        width, height = height, width
+        trans = True
+    ratio = width / height
+    scale = 1
+    while scale * math.ceil(scale / ratio) <= num_crops:
+        scale += 1
+    scale -= 1
+    new_w = int(scale * 336)
+    new_h = int(new_w / ratio)
+    # padding_336 (processing_phi3_v.py:62-71): height padded up to a multiple of 336
+    tar = int(math.ceil(new_h / 336) * 336)
+    if trans:
+        return new_w, tar, True       # image is transposed back: (h, w) = (new_w, padded h)
+    return tar, new_w, False
+
+
+def num_img_tokens(h: int, w: int) -> int:
+    """processing_phi3_v.py:269: ((h/336)*(w/336)+1)*144 + 1 + (h/336+1)*12."""
+    return int((h // 336) * (w // 336) + 1) * 144 + 1 + int(h // 336 + 1) * 12
+
+
+def synth_pixels(seed: int, name: str, shape: Tuple[int, ...]) -> np.ndarray:
+    """CLIP-normalised-like pixel noise, std 1, fp32 (not bf16-valued)."""
+    return gen_tensor(seed, name, shape, 1.0, 0.0, bf16_valued=False)
+
+
+def synth_batch(cfg: RewardConfig, seed: int, caption_lens: List[int], grids, max_crops: int = None,
+                pad_token_id: int = None):
+    """Token/mask/pixel tensors shaped like collate_fn output (reward_dataset.py:137-202, Appendix B
+    of SURVEY.md): each row is [bos, <|user|>, \\n, -1 x V_b, \\n, caption..., eos]; rows are LEFT-padded
+    with pad_token_id / mask 0 to the longest row (datasets/utils.py:5-13).
+    `grids` is one (h_crop, w_crop) for all samples or a list with one per sample.
+    Returns numpy arrays: input_ids [B,S] i64, attention_mask [B,S] i64,
+    pixel_values [B,C,3,336,336] f32 (crop 0 = global, then local crops row-major, zero-padded to C,
+    processing_phi3_v.py:272-278), image_sizes [B,2] i64 (HD-transformed h, w)."""
+    batch = len(caption_lens)
+    if isinstance(grids[0], int):
+        grids = [tuple(grids)] * batch
+    assert len(grids) == batch
+    ncrops = [hc * wc + 1 for hc, wc in grids]
+    C = max_crops + 1 if max_crops is not None else max(ncrops)
+    assert C >= max(ncrops)
+    hi = min(32000, cfg.vocab_size - 1)
+    pad_id = pad_token_id if pad_token_id is not None else hi
+    lo = 3
+    rows = []
+    for b, n in enumerate(caption_lens):
+        V = num_img_tokens(336 * grids[b][0], 336 * grids[b][1])
+        t = tensor_seed(seed, f"caption.{b}")
+        cap = np.array([lo + splitmix64_scalar((t + i) & MASK64) % (hi - lo) for i in range(n)],
+                       dtype=np.int64)
+        rows.append(np.concatenate([np.array([1, 2, 13], dtype=np.int64), np.full(V, -1, dtype=np.int64),
+                                    np.array([13], dtype=np.int64), cap, np.array([pad_id], dtype=np.int64)]))
+    S = max(len(r) for r in rows)
+    ids = np.full((batch, S), pad_id, dtype=np.int64)
+    mask = np.zeros((batch, S), dtype=np.int64)
+    for b, row in enumerate(rows):
+        ids[b, S - len(row):] = row
+        mask[b, S - len(row):] = 1
+    pix = np.zeros((batch, C, 3, 336, 336), dtype=np.float32)
+    for b in range(batch):
+        pix[b, :ncrops[b]] = synth_pixels(seed, f"pixel_values.{b}", (ncrops[b], 3, 336, 336))
+    sizes = np.array([[336 * hc, 336 * wc] for hc, wc in grids], dtype=np.int64)
+    return dict(input_ids=ids, attention_mask=mask, pixel_values=pix, image_sizes=sizes)

@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE ITSELF (imported from /root/reference).
+
+Runs only in the build container (the reference never travels to the GPU box).  The JSON it
+writes holds data only: config, seed, input recipe and the reference's outputs.  Inputs and weights
+are regenerated anywhere from (config, seed) by llava_reward_amd.synth, so nothing large is stored.
+
+    python tests/golden/make_goldens.py small        # ref_small_* cases (minutes)
+    python tests/golden/make_goldens.py full         # full-size Phi-3.5-V, B=1 (~20 min, ~35 GB RSS)
+
+Import recipe = SURVEY.md Appendix A (stubs for deepspeed/peft/loralib, use_cache=False, eager
+attention, un-patched get_img_features == hidden_states[-2][:,1:]).
+"""
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "llava-reward_amd"))
+from llava_reward_amd import synth  # noqa: E402
+
+
+def import_reference():
+    import transformers  # noqa: F401  (real imports first: availability checks choke on stub modules)
+    from unittest.mock import MagicMock
+    from transformers import (AutoConfig, AutoModel, AutoModelForCausalLM, BitsAndBytesConfig,  # noqa: F401
+                              CLIPVisionModel, Qwen2_5_VLModel, Qwen2_5_VLForConditionalGeneration,
+                              LlavaNextForConditionalGeneration)
+    import transformers.generation.utils  # noqa: F401
+    from transformers.integrations.deepspeed import HfDeepSpeedConfig  # noqa: F401
+
+    class _Stub(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return MagicMock()
+
+    for n in ["deepspeed", "deepspeed.ops", "deepspeed.ops.adam", "deepspeed.runtime", "deepspeed.runtime.zero",
+              "deepspeed.runtime.zero.partition_parameters", "peft", "peft.tuners", "peft.tuners.lora", "loralib"]:
+        m = _Stub(n)
+        m.__path__ = []
+        sys.modules[n] = m
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, "/root/reference")
+    from llava_reward.models.rw_model_general_preference import _get_reward_model, Phi3RMSNorm
+    from llava_reward.models.base_mllm.phi3_v.modeling_phi3_v import Phi3VModel, Phi3VForCausalLM
+    from llava_reward.models.base_mllm.phi3_v.configuration_phi3_v import Phi3VConfig
+    return _get_reward_model, Phi3RMSNorm, Phi3VModel, Phi3VForCausalLM, Phi3VConfig
+
+
+def build_reference_model(ref, cfg: synth.RewardConfig, seed: int):
+    _get_reward_model, Phi3RMSNorm, Phi3VModel, Phi3VForCausalLM, Phi3VConfig = ref
+    assert cfg.clip == synth.ClipConfig(), "the reference hard-wires CLIP ViT-L/14-336"
+    hcfg = Phi3VConfig(
+        vocab_size=cfg.vocab_size, hidden_size=cfg.hidden, intermediate_size=cfg.intermediate,
+        num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads, num_key_value_heads=cfg.heads,
+        max_position_embeddings=cfg.max_pos, original_max_position_embeddings=cfg.orig_max_pos,
+        rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta,
+        rope_scaling={"type": "su", "short_factor": list(cfg.short_factor), "long_factor": list(cfg.long_factor)},
+        sliding_window=262144, use_cache=False, pad_token_id=min(32000, cfg.vocab_size - 1),
+        bos_token_id=1, eos_token_id=min(32000, cfg.vocab_size - 1),
+        embd_layer={"embedding_cls": "image", "hd_transform_order": "sub_glb", "projection_cls": "mlp",
+                    "use_hd_transform": True, "with_learnable_separator": True},
+        img_processor={"image_dim_out": 1024, "model_name": "openai/clip-vit-large-patch14-336",
+                       "name": "clip_vision_model", "num_img_tokens": 144})
+    hcfg._attn_implementation = "eager"
+    cls = _get_reward_model(Phi3VForCausalLM, Phi3VModel, RMSNorm_class=Phi3RMSNorm, RMSNorm_class_eps=cfg.ca_eps,
+                            is_general_preference=cfg.is_general_preference,
+                            add_cross_attention=cfg.add_cross_attention, value_head_dim=cfg.value_head_dim)
+    t0 = time.time()
+    # meta-device construction skips the reference's random init of parameters we overwrite anyway
+    model = cls(hcfg)
+    model.model_type = "phi3v"
+    model.eval()
+    print(f"  reference model built in {time.time() - t0:.1f}s", flush=True)
+    # load synthetic weights by (canonicalised) name
+    specs = {n: (shape, std, off) for n, shape, std, off in synth.weight_specs(cfg)}
+    used = set()
+    with torch.no_grad():
+        for name, p in list(model.named_parameters()) + list(model.named_buffers()):
+            canon = name
+            if "img_processor." in name and "img_processor.vision_model." not in name:
+                canon = name.replace("img_processor.", "img_processor.vision_model.")
+            if canon in specs:
+                shape, std, off = specs[canon]
+                assert tuple(p.shape) == tuple(shape), (name, p.shape, shape)
+                p.copy_(torch.from_numpy(synth.gen_tensor(seed, canon, shape, std, off)))
+                used.add(canon)
+    missing = set(specs) - used
+    assert not missing, f"weights not consumed by the reference: {sorted(missing)[:5]}"
+    return model
+
+
+def fingerprint(t: torch.Tensor, n: int = 16):
+    """Deterministic sample of n elements + abs-mean, enough to localise a divergence."""
+    f = t.detach().float().reshape(-1)
+    idx = torch.linspace(0, f.numel() - 1, n).long()
+    return {"shape": list(t.shape), "abs_mean": float(f.abs().mean()), "idx": idx.tolist(),
+            "vals": [float(v) for v in f[idx]]}
+
+
+def run_case(ref, name, cfg, seed, caption_lens, grids, max_crops, taps=True):
+    print(f"[{name}] building", flush=True)
+    model = build_reference_model(ref, cfg, seed)
+    batch = synth.synth_batch(cfg, seed, caption_lens, grids, max_crops=max_crops)
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    t0 = time.time()
+    with torch.no_grad():
+        reward, outputs = model.custom_forward(tb["input_ids"], tb["attention_mask"], tb["pixel_values"],
+                                               tb["image_sizes"], return_output=True)
+    dt = time.time() - t0
+    print(f"[{name}] reference custom_forward {dt:.1f}s reward={reward.flatten().tolist()}", flush=True)
+    out = {"name": name, "config": cfg.to_json(), "seed": seed, "caption_lens": caption_lens,
+           "grids": [list(g) for g in grids] if not isinstance(grids[0], int) else list(grids),
+           "max_crops": max_crops, "reward": reward.float().tolist(),
+           "reference_forward_seconds": dt, "threads": torch.get_num_threads(),
+           "torch": torch.__version__, "dtype": "float32"}
+    if taps:
+        hs = outputs["hidden_states"]
+        out["taps"] = {"embeds": fingerprint(hs[0]), "vision_embeds": fingerprint(hs[-1]),
+                       "final_norm": fingerprint(outputs["last_hidden_state"])}
+        for l in range(cfg.layers):
+            if l in (0, 1, cfg.layers // 2, cfg.layers - 1) and l + 1 < len(hs) - 2:
+                out["taps"][f"layer{l}"] = fingerprint(hs[l + 1])
+    path = os.path.join(HERE, f"{name}.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print(f"[{name}] wrote {path}", flush=True)
+    del model
+    return out
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "small"
+    torch.manual_seed(0)
+    ref = import_reference()
+    if which == "small":
+        C = synth.ref_small_config
+        run_case(ref, "ref_small_bt_ca", C(), 1234, [6, 3], (1, 1), None)
+        run_case(ref, "ref_small_gpm2_ca", C(is_general_preference=True, value_head_dim=2), 1234, [6, 3], (1, 1), None)
+        run_case(ref, "ref_small_bt_noca", C(add_cross_attention=False), 4321, [4], (1, 1), None)
+        run_case(ref, "ref_small_bt_ca_ragged", C(), 99, [5, 9], [(1, 1), (1, 2)], 3)
+        run_case(ref, "ref_small_gpm4_ca", C(is_general_preference=True, value_head_dim=4), 7, [2], (1, 1), None)
+    elif which == "full":
+        run_case(ref, "ref_full_bt_ca", synth.full_config(), 1234, [128], (4, 4), None)
+    elif which == "full_gpm":
+        run_case(ref, "ref_full_gpm2_ca", synth.full_config(is_general_preference=True, value_head_dim=2),
+                 1234, [128], (4, 4), None)
+    else:
+        raise SystemExit(f"unknown set {which}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,76 @@
+"""Pin the CPU oracle (oracle/phi3v_reward_oracle.py) against outputs of the reference itself.
+
+The goldens in tests/golden/ref_small_*.json were produced by tests/golden/make_goldens.py, which
+imports /root/reference and runs CustomRewardModel.custom_forward in fp32 on seeded synthetic
+weights/inputs.  Tolerance: 2e-5 absolute on rewards and stage fingerprints (fp32 vs fp32; only
+summation order differs)."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from llava_reward_amd import synth
+from oracle import phi3v_reward_oracle as orc
+
+TOL = 2e-5
+CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref_small_*.json")))
+
+
+def _fp(t, idx):
+    return t.detach().float().reshape(-1)[torch.tensor(idx)].tolist()
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-5] for p in CASES])
+def test_oracle_matches_reference(path):
+    g = json.load(open(path))
+    cfg = synth.RewardConfig.from_json(g["config"])
+    W = orc.weights_to_torch(synth.make_weights(cfg, g["seed"]))
+    grids = g["grids"]
+    grids = tuple(grids) if isinstance(grids[0], int) else [tuple(x) for x in grids]
+    batch = synth.synth_batch(cfg, g["seed"], g["caption_lens"], grids, max_crops=g["max_crops"])
+    taps = {}
+    r = orc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"],
+                           batch["image_sizes"], taps=taps)
+    ref = np.array(g["reward"], dtype=np.float32).reshape(r.shape)
+    assert np.abs(r.numpy() - ref).max() < TOL, (r, ref)
+    # stage fingerprints localise any divergence; only valid (non-pad) rows are comparable
+    mask = torch.from_numpy(batch["attention_mask"]).bool()
+    tp = g["taps"]
+    np.testing.assert_allclose(_fp(taps["embeds"], tp["embeds"]["idx"]), tp["embeds"]["vals"], atol=TOL)
+    for k, v in tp.items():
+        if not k.startswith("layer"):
+            continue
+        mine = taps[k]
+        idx = torch.tensor(v["idx"])
+        rows = idx // mine.shape[-1]
+        valid = mask.reshape(-1)[rows]
+        a = torch.tensor(_fp(mine, v["idx"]))[valid]
+        b = torch.tensor(v["vals"])[valid]
+        assert (a - b).abs().max() < 5 * TOL, (k, a, b)
+
+
+def test_preference_compute_formulas():
+    cfg = synth.tiny_config(is_general_preference=True, value_head_dim=2, general_preference_tau=0.1)
+    c = torch.tensor([[0.3, -0.2], [1.0, 0.5]])
+    r = torch.tensor([[0.1, 0.4], [-0.5, 0.25]])
+    p = orc.preference_compute(cfg, c, r)
+    exp = 1 / (1 + np.exp(-np.array([0.3 * 0.4 - (-0.2) * 0.1, 1.0 * 0.25 - 0.5 * (-0.5)]) / 0.1))
+    np.testing.assert_allclose(p, exp, rtol=1e-6)
+    cfg = synth.tiny_config(general_preference_tau=0.5)
+    p = orc.preference_compute(cfg, torch.tensor([[0.3], [0.0]]), torch.tensor([[0.1], [0.2]]))
+    np.testing.assert_allclose(p, 1 / (1 + np.exp(-np.array([0.2, -0.2]) / 0.5)), rtol=1e-6)
+    assert p.dtype == np.float32 and p.shape == (2,)
+
+
+def test_token_count_kats():
+    # SURVEY.md §8c KATs of processing_phi3_v.py:83-104,269
+    assert synth.num_img_tokens(1344, 1344) == 2509
+    assert synth.hd_target_size(336, 336, 16)[:2] == (1344, 1344)
+    assert synth.hd_target_size(512, 640, 16)[:2] == (1344, 1344)
+    assert synth.hd_target_size(768, 768, 16)[:2] == (1344, 1344)
+    h, w, _ = synth.hd_target_size(336, 336, 4)
+    assert synth.num_img_tokens(h, w) == 757
+    assert synth.num_img_tokens(336, 336) == 313 and synth.num_img_tokens(336, 672) == 457
