@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""reward-pairs/sec of the HIP scoring path (BASELINE.json metric), one process per GPU.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A "step" = one custom_forward over one batch of 32 synthetic (caption, image) rows per GPU
+(BASELINE.json configs[1]: Phi-3.5-V BT head + SkipCA, 336x336 image -> 17 crops -> 2509 image
+tokens, 128-token caption, S = 2643) followed by the all-gather of the rewards (the only
+collective of the path).  Weak scaling: rows per GPU fixed.
+Inputs are resident in HBM before the timed region.  Weights: seeded synthetic (no checkpoint exists
+offline); rank 0 at N=1 also times the CPU oracle on a bounded sample (cpu_baseline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "llava-reward_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FLOP_PER_PAIR = 26.86e12          # algorithmic 2*MAC per (caption, image) row, num_crops=16
+PEAK_TFLOPS = 2500.0              # dense bf16/f16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def cpu_baseline(cfg_full):
+    """Time the CPU oracle (oracle/phi3v_reward_oracle.py, 'port') on a bounded sample of the same
+    workload: ONE row at full shapes, with 2 of the 23 CLIP layers and 2 of the 32 decoder layers
+    executed; per-layer cost is measured as the difference between the 2-layer and 1-layer runs and
+    scaled to the full depth (every layer of a tower has identical shapes)."""
+    import dataclasses
+    from llava_reward_amd import synth
+    from oracle import phi3v_reward_oracle as orc
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    g = torch.Generator().manual_seed(0)
+
+    def weights(cfg):
+        W = {}
+        for name, shape, std, off in synth.weight_specs(cfg):
+            W[name] = torch.randn(shape, generator=g) * std + off
+        return W
+
+    batch = synth.synth_batch(cfg_full, 1234, [128], (4, 4), with_pixels=False)
+    pix = torch.randn(1, 17, 3, 336, 336, generator=g)
+    times = {}
+    for nl in (1, 2):
+        cfg = dataclasses.replace(cfg_full, layers=nl, clip=dataclasses.replace(cfg_full.clip, layers_used=nl))
+        W = weights(cfg)
+        t0 = time.time()
+        feats = orc.clip_tower(W, pix.flatten(0, 1), cfg.clip)
+        t1 = time.time()
+        orc.custom_forward(W, dataclasses.replace(cfg, clip=dataclasses.replace(cfg.clip, layers_used=0)),
+                           batch["input_ids"], batch["attention_mask"], pix, batch["image_sizes"])
+        t2 = time.time()
+        times[nl] = (t1 - t0, t2 - t1)
+        del W, feats
+    clip_layer = max(times[2][0] - times[1][0], 1e-6)
+    clip_base = max(times[1][0] - clip_layer, 0.0)
+    dec_layer = max(times[2][1] - times[1][1], 1e-6)
+    dec_base = max(times[1][1] - dec_layer, 0.0)
+    total = clip_base + cfg_full.clip.layers_used * clip_layer + dec_base + cfg_full.layers * dec_layer
+    spent = sum(a + b for a, b in times.values())
+    return {"value": 1.0 / total, "unit": "reward-pairs/sec", "cores": cores, "kind": "port",
+            "sample": f"1 row at full shapes (17 crops, S={batch['input_ids'].shape[1]}); 2/23 CLIP + 2/32 decoder layers "
+                      f"timed ({spent:.1f}s CPU), per-layer cost scaled to full depth -> {total:.1f}s per row, fp32 torch"}
+
+
+def dominant_kernel_probe(dtype_code, tile, steps=5):
+    """HIP-event timing of the dominant kernel (gemm_bt at the gate_up shape) on the launch stream."""
+    import ctypes as C
+    from llava_reward_amd import _lib as L
+    lib = L.load()
+    M, N, K = 32 * 2643, 16384, 3072
+    tdt = torch.float16 if dtype_code == L.LR_DT_F16 else torch.bfloat16
+    A = (torch.randn(M, K, device="cuda") * 1.0).to(tdt)
+    W = (torch.randn(N, K, device="cuda") * 0.02).to(tdt)
+    out = torch.empty(M, N // 2, device="cuda", dtype=tdt)
+    st = torch.cuda.current_stream()
+    args = (C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(0), M, N, K, K, K, N // 2,
+            L.EPI_SWIGLU_OP, 0, dtype_code, tile, C.c_void_p(st.cuda_stream))
+    lib.lr_op_gemm_bt(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(steps):
+        lib.lr_op_gemm_bt(*args)
+    e1.record(st)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    return {"kernel": "gemm_bt_kernel (gate_up + SwiGLU epilogue)", "shape": [M, N, K], "avg_ms": ms,
+            "tflops": 2.0 * M * N * K / (ms * 1e-3) / 1e12}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="rows per GPU")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="MFMA operand type")
+    ap.add_argument("--tile", type=int, default=-1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from llava_reward_amd import synth, _lib as L
+    from llava_reward_amd.model import RewardModel
+    from llava_reward_amd.scoring import gather_rewards
+
+    cfg = synth.full_config()                       # BT head (d=1) + SkipCA
+    B = a.batch
+    gb = synth.synth_batch(cfg, 1234, [128] * (B * world), (4, 4), with_pixels=False)
+    S = gb["input_ids"].shape[1]
+    rows = slice(rank * B, (rank + 1) * B)          # contiguous shard: gathered order == input order
+    ids = torch.from_numpy(gb["input_ids"][rows]).cuda()
+    mask = torch.from_numpy(gb["attention_mask"][rows]).cuda()
+    sizes = torch.from_numpy(gb["image_sizes"][rows])
+    gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    pix = torch.randn(B, 17, 3, 336, 336, device="cuda", generator=gen)      # CLIP-normalised pixel noise, fp32
+
+    model = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=S, max_crops=17, operand_dtype=a.dtype).to(f"cuda:{local}").eval()
+    if a.tile >= 0:
+        model.engine.set_gemm_tile(a.tile)
+
+    def step():
+        r = model.engine.forward(ids, mask, pix, sizes)
+        return gather_rewards(r) if world > 1 else r
+
+    for _ in range(a.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out).all(), "non-finite rewards"
+
+    if rank == 0:
+        value = world * B * a.steps / dt
+        tf_per_gpu = value * FLOP_PER_PAIR / world / 1e12
+        res = {
+            "metric": "reward-pairs/sec (336px img, 128-tok caption) Phi-3.5-V", "value": value, "unit": "reward-pairs/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": f"{a.dtype} MFMA operands (bf16-valued weights), f32 accumulate/residual/softmax",
+            "data": "synthetic (seeded weights and inputs; no checkpoint offline)",
+            "config": {"workload": "BASELINE configs[1]: Phi-3.5-V BT head + SkipCA, 17 crops/img, V=2509, S=%d" % S,
+                       "rows_per_gpu": B, "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
+                       "collective": "all_gather rewards [B,1] fp32" if world > 1 else "none"},
+            "roofline": {"bound": "mfma", "achieved": tf_per_gpu, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf_per_gpu / PEAK_TFLOPS, "traffic": None,
+                         "note": "whole pass: pairs/s x 26.86 TFLOP algorithmic per pair, per GPU"},
+        }
+        if world == 1:
+            res["roofline"]["dominant_kernel"] = dominant_kernel_probe(L.LR_DT_F16 if a.dtype == "f16" else L.LR_DT_BF16, a.tile)
+            if not a.no_cpu_baseline:
+                del model
+                torch.cuda.empty_cache()
+                res["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,115 @@
+/* C ABI of the MI355X (gfx950) reward-scoring engine -- libllava_reward_hip.so
+ *
+ * The reference (sjz5202/LLaVA-Reward) has no FFI for this path: its boundary is four Python
+ * callables.  This header is the seam a maintainer binds instead of the torch
+ * modules behind them; INTEGRATION.md shows the ctypes stub.  Entry point -> what it replaces:
+ *
+ *   lr_create / lr_upload_weight / lr_finalize
+ *        eval/reward_adaptor_loader.py:32-60   building CustomRewardModel and loading base weights,
+ *                                              the (merged) LoRA adapter and the reward heads
+ *   lr_forward
+ *        llava_reward/models/rw_model_general_preference.py:334-448  CustomRewardModel.custom_forward
+ *        (phi3v branch), i.e. modeling_phi3_v.py:1376-1516 Phi3VModel.forward with :221-362
+ *        Phi3ImageEmbedding, the CLIP tower (utils/utils.py:264-282), the decoder stack
+ *        (:1144-1205), SkipCA (rw_model:376-386) and the value head + EOS gather (:407-448)
+ *   lr_all_gather_plan: none (the reference scores on one GPU, eval/batch_inference_rm_phi.py:50-57)
+ *
+ * Conventions: every function returns 0 on success and a non-zero LR_E* code on failure; nothing
+ * throws across the ABI; lr_last_error() returns a message for the last failing call on that
+ * handle (or for lr_create when handle is NULL).  No torch types appear here: tensors are plain
+ * device pointers owned by the caller.  A handle is bound to one HIP device and is not
+ * thread-safe.  lr_forward only enqueues work on `stream` and never synchronises; the caller
+ * synchronises before reading `rewards_out`.
+ */
+#ifndef LLAVA_REWARD_HIP_H
+#define LLAVA_REWARD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LR_ABI_VERSION 1
+
+enum { LR_OK = 0, LR_EINVAL = 1, LR_EHIP = 2, LR_ESTATE = 3, LR_ENOTFOUND = 4, LR_ENOMEM = 5 };
+enum { LR_DT_BF16 = 0, LR_DT_F16 = 1, LR_DT_F32 = 2 };
+/* lr_forward flags */
+enum { LR_FWD_TRAINING_LAST_TOKEN = 1 };   /* self.training reward selection (rw_model:410-415,429-434) */
+
+#define LR_MAX_HALF_HEAD 64
+
+typedef struct lr_engine* lr_handle;
+
+typedef struct lr_model_desc {
+    int32_t struct_size;          /* sizeof(lr_model_desc), ABI guard */
+    /* Phi-3 decoder (configuration_phi3_v.py:119-145) */
+    int32_t vocab_size, hidden, intermediate, layers, heads;
+    float rms_eps;
+    int32_t orig_max_pos;         /* original_max_position_embeddings */
+    float rope_scaling;           /* sqrt(1 + ln(max_pos/orig)/ln(orig)), modeling_phi3_v.py:468-472 */
+    float inv_freq_short[LR_MAX_HALF_HEAD];   /* 1/(short_factor * theta^(2i/hd)), modeling_phi3_v.py:455 */
+    float inv_freq_long[LR_MAX_HALF_HEAD];
+    /* CLIP tower (modeling_phi3_v.py:68-83; layers = encoder layers actually used) */
+    int32_t clip_hidden, clip_heads, clip_mlp, clip_layers, clip_image, clip_patch;
+    float clip_ln_eps;
+    /* reward head (reward_config.yaml, eval/reward_adaptor_loader.py:25-30) */
+    int32_t value_head_dim, add_cross_attention;
+    float ca_eps;
+    /* capacity: workspace is sized for these at lr_finalize */
+    int32_t max_batch, max_seq, max_crops;    /* max_crops counts the global crop */
+    int32_t operand_dtype;        /* LR_DT_BF16 or LR_DT_F16: element type of MFMA operands */
+} lr_model_desc;
+
+int lr_abi_version(void);
+int lr_create(const lr_model_desc* desc, int device, lr_handle* out);
+int lr_destroy(lr_handle h);
+const char* lr_last_error(lr_handle h);
+
+/* Copy one tensor under its reference state_dict name (e.g. "model.layers.0.mlp.down_proj.weight").
+ * `data` is host memory unless is_device != 0; dtype is LR_DT_*; shape is checked against the
+ * model description.  The engine converts to its packed operand layouts immediately. */
+int lr_upload_weight(lr_handle h, const char* name, const void* data, const int64_t* shape, int ndim, int dtype,
+                     int is_device);
+/* Fill every tensor with the deterministic synthetic weights of llava_reward_amd.synth (same
+ * integer hash, generated directly in HBM).  Used by bench.py and the full-size parity test. */
+int lr_synth_weights(lr_handle h, uint64_t seed);
+/* Number of expected weight tensors / name of the i-th one (for loaders and tests). */
+int lr_num_weights(lr_handle h);
+const char* lr_weight_name(lr_handle h, int i);
+/* Checks that every tensor was provided and allocates the activation workspace. */
+int lr_finalize(lr_handle h);
+size_t lr_workspace_bytes(lr_handle h);
+
+/* One scoring pass.  input_ids/attention_mask: device int64 [B,S] (image slots are negative ids);
+ * pixel_values: device [B, n_crops, 3, img, img] of pix_dtype (F32 or BF16); image_sizes: HOST int64
+ * [B,2] = HD-transformed (h, w); rewards_out: device fp32 [B, value_head_dim]. */
+int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_mask, const void* pixel_values,
+               int pix_dtype, const int64_t* image_sizes_host, int B, int S, int n_crops, int flags, float* rewards_out,
+               void* hip_stream);
+
+/* Debug taps: copy an internal fp32 buffer of the last forward to host (synchronises).  Names:
+ * "clip_x" [crops*T, Hc], "ev" [sumV, D], "x" [B*S, D] (residual stream after the last layer),
+ * "hL" [B, D].  Returns the number of floats copied through *n. */
+int lr_read_tap(lr_handle h, const char* name, float* host_out, size_t capacity, size_t* n);
+/* Stop after `n_clip_layers` / `n_layers` (-1 = all); for stage-wise parity tests. */
+int lr_set_layer_limits(lr_handle h, int n_clip_layers, int n_layers);
+/* GEMM tile selection: -1 heuristic, 0 = 128x128, 1 = 256x128, 2 = 256x256. */
+int lr_set_gemm_tile(lr_handle h, int tile);
+
+/* ---- single-kernel entry points (per-kernel parity tests and microbenchmarks) ---- */
+int lr_op_gemm_bt(const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int lda, int ldw,
+                  int ldc, int epi, int act, int operand_dtype, int tile, void* hip_stream);
+int lr_op_attention(const void* Q, const void* K, const void* V, void* O, const int64_t* mask, const int* kmin, int ldq,
+                    int ldo, int qoff, int koff, int voff, int batch, int S, int heads, int head_dim, int causal,
+                    float scale, int operand_dtype, void* hip_stream);
+int lr_op_norm_rows(const float* x, const float* w, const float* b, void* y, int rows, int H, float eps,
+                    int operand_dtype, void* hip_stream);
+int lr_op_synth_fill(float* out, size_t n, uint64_t seed, const char* name, float std, float offset, int bf16_round,
+                     void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLAVA_REWARD_HIP_H */

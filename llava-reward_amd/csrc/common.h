@@ -1,0 +1,109 @@
+// Shared device/host helpers for the gfx950 reward-scoring kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+namespace lr {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+// Operand element types of the MFMA contractions (2 bytes each).  bf16 is the reference's
+// checkpoint dtype; f16 has 3 more mantissa bits at the same MFMA rate.
+struct BF16 {};
+struct F16 {};
+
+template <typename OT> struct Op;
+template <> struct Op<BF16> {
+    typedef bf16x8 vec8;
+    static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned short from_f32(float x) {
+        return __builtin_bit_cast(unsigned short, (__bf16)x);
+    }
+    static __device__ __forceinline__ float to_f32(unsigned short u) {
+        return __builtin_bit_cast(float, ((unsigned)u) << 16);
+    }
+};
+template <> struct Op<F16> {
+    typedef f16x8 vec8;
+    static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned short from_f32(float x) {
+        // saturate instead of overflowing to inf (f16 max 65504); NaN stays NaN
+        x = __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f);
+        return __builtin_bit_cast(unsigned short, (_Float16)x);
+    }
+    static __device__ __forceinline__ float to_f32(unsigned short u) {
+        return (float)__builtin_bit_cast(_Float16, u);
+    }
+};
+
+template <typename OT> __device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    return (unsigned)Op<OT>::from_f32(lo) | ((unsigned)Op<OT>::from_f32(hi) << 16);
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short u) {
+    return __builtin_bit_cast(float, ((unsigned)u) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- epilogue selectors of gemm_bt ----
+enum : int {
+    EPI_OUT_OP = 0,      // C_op[m][n]   = act(acc + bias)
+    EPI_OUT_F32 = 1,     // C_f32[m][n]  = acc + bias
+    EPI_RESADD_F32 = 2,  // C_f32[m][n] += acc + bias
+    EPI_SWIGLU_OP = 3,   // C_op[m][n/2] = silu(gate) * up, weight rows interleaved in blocks of 32
+};
+enum : int { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU_ERF = 2 };
+enum : int { DT_BF16 = 0, DT_F16 = 1, DT_F32 = 2 };
+
+struct GemmParams {
+    const void* A;      // [M, lda] operand dtype, row-major
+    const void* W;      // [N, ldw] operand dtype, row-major (C = A * W^T)
+    void* C;            // see epilogue
+    const float* bias;  // [N] or null
+    int M, N, K;        // K multiple of 64, N multiple of the block's BN
+    int lda, ldw, ldc;  // in elements
+    int epi, act;
+};
+
+struct AttnParams {
+    const void* Q;  // operand dtype rows [b*S + t][ldq], head h at column qoff + h*HD
+    const void* K;
+    const void* V;
+    void* O;        // operand dtype [b*S + t][ldo], head h at column h*HD
+    const int64_t* mask;   // [B, S] or null (non-causal towers)
+    const int* kmin;       // first valid key of sequence b at kmin[b*kmin_stride] (or null)
+    int kmin_stride;
+    int ldq, ldo;
+    int qoff, koff, voff;
+    int S;          // tokens per sequence
+    int heads;
+    float scale;    // 1/sqrt(HD)
+};
+
+}  // namespace lr
+
+#define LR_HIP_CHECK(expr)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e));     \
+        }                                                                                    \
+    } while (0)

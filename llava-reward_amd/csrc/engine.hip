@@ -1,0 +1,588 @@
+// C-ABI engine: weight store, workspace and the launch sequence of one scoring pass.
+// See include/llava_reward_hip.h for the contract and the reference lines each entry replaces.
+#include "../../include/llava_reward_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using namespace lr;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+uint64_t fnv1a64(const char* s) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (; *s; ++s) { h ^= (unsigned char)*s; h *= 0x100000001B3ull; }
+    return h;
+}
+uint64_t splitmix64_host(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+uint64_t tensor_seed(uint64_t seed, const char* name) { return splitmix64_host(seed ^ fnv1a64(name)); }
+float uniform_scale(double std) { return (float)(std * std::sqrt(12.0) / 16777216.0); }
+
+struct Slot {
+    std::string name;
+    std::vector<int64_t> shape;
+    int rows, cols;            // 2-D view: [shape[0], prod(rest)] (1-D: [1, n])
+    void* dst;                 // destination (already offset for concatenated tensors)
+    int ld_dst, cols_dst, dst_dtype, mode;
+    double std_, offset;       // synthetic init (llava_reward_amd.synth.weight_specs)
+    bool provided = false;
+};
+
+struct ClipLayer {
+    void *qkv_w, *out_w, *fc1_w, *fc2_w;
+    float *qkv_b, *out_b, *fc1_b, *fc2_b, *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+};
+struct DecLayer {
+    void *qkv_w, *o_w, *gu_w, *down_w;
+    float *ln1, *ln2;
+};
+
+}  // namespace
+
+struct lr_engine {
+    lr_model_desc d;
+    int device = 0;
+    std::string err;
+    bool finalized = false;
+    std::vector<void*> allocs;
+    std::vector<Slot> slots;
+    std::unordered_map<std::string, int> index;
+    size_t ws_bytes = 0, weight_bytes = 0;
+    int gemm_tile = -1, lim_clip = -1, lim_layers = -1;
+
+    // derived
+    int T = 0, G = 0, Kpatch = 0, Kpad = 0, hd = 0, half = 0, Vcap = 0;
+    int op_dt = DT_BF16;
+
+    // weights
+    float *cls = nullptr, *pos = nullptr, *pre_w = nullptr, *pre_b = nullptr;
+    void* patch_w = nullptr;
+    std::vector<ClipLayer> cl;
+    float *sub_gn = nullptr, *glb_gn = nullptr, *p0_b = nullptr, *p2_b = nullptr;
+    void *p0_w = nullptr, *p2_w = nullptr;
+    unsigned short* wte = nullptr;
+    std::vector<DecLayer> dl;
+    float* norm_w = nullptr;
+    unsigned short *Wq = nullptr, *WkT = nullptr, *Wv = nullptr;
+    float *ca_w = nullptr, *vh = nullptr;
+    float *inv_s = nullptr, *inv_l = nullptr;
+
+    // staging for uploads
+    void* stage_raw = nullptr; size_t stage_raw_cap = 0;
+    float* stage_f32 = nullptr; size_t stage_f32_cap = 0;
+
+    // workspace
+    void *patchA = nullptr, *clip_h = nullptr, *clip_qkv = nullptr, *clip_att = nullptr, *clip_ff = nullptr;
+    float *patch_out = nullptr, *clip_x = nullptr;
+    void *hdA = nullptr, *proj1 = nullptr;
+    float* ev = nullptr;
+    float *x = nullptr, *qkv32 = nullptr, *cs = nullptr;
+    void *h = nullptr, *qkv = nullptr, *att = nullptr, *ff = nullptr;
+    int *pos_ids = nullptr, *img_row = nullptr, *tstat = nullptr;
+    float *hL = nullptr, *tq = nullptr, *tkq = nullptr, *tsc = nullptr, *tctx = nullptr, *tao = nullptr;
+    // per-forward tables (ring of pinned host slots + device mirrors)
+    static constexpr int NSLOT = 4;
+    int slot_i = 0;
+    char* tab_host = nullptr; char* tab_dev = nullptr; size_t tab_bytes = 0;
+    hipEvent_t tab_ev[NSLOT] = {}; bool tab_used[NSLOT] = {};
+    // last forward geometry (for taps)
+    int lastB = 0, lastS = 0, lastNC = 0, lastSV = 0;
+
+    void* dalloc(size_t bytes, bool weight) {
+        void* p = nullptr;
+        bytes = (bytes + 255) & ~(size_t)255;
+        LR_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 256));
+        allocs.push_back(p);
+        (weight ? weight_bytes : ws_bytes) += bytes;
+        return p;
+    }
+    size_t opsz() const { return 2; }
+};
+
+namespace {
+
+void add_slot(lr_engine* e, const std::string& name, std::vector<int64_t> shape, void* dst, int ld_dst, int cols_dst,
+              int dst_dtype, int mode, double std_, double offset) {
+    Slot s;
+    s.name = name;
+    s.shape = shape;
+    if (shape.size() == 1) { s.rows = 1; s.cols = (int)shape[0]; }
+    else { s.rows = (int)shape[0]; int64_t c = 1; for (size_t i = 1; i < shape.size(); ++i) c *= shape[i]; s.cols = (int)c; }
+    s.dst = dst; s.ld_dst = ld_dst; s.cols_dst = cols_dst; s.dst_dtype = dst_dtype; s.mode = mode;
+    s.std_ = std_; s.offset = offset;
+    e->index[name] = (int)e->slots.size();
+    e->slots.push_back(s);
+}
+
+float* falloc(lr_engine* e, size_t n) { return (float*)e->dalloc(n * 4, true); }
+void* oalloc(lr_engine* e, size_t n) { return e->dalloc(n * 2, true); }
+
+void vec_slot(lr_engine* e, const std::string& name, std::vector<int64_t> shape, float* dst, double std_, double off) {
+    int64_t n = 1; for (auto v : shape) n *= v;
+    add_slot(e, name, shape, dst, (int)n, (int)n, DT_F32, PACK_PLAIN, std_, off);
+    // 1-D view of multi-dim vectors (glb_GN [1,1,4H]) : force [1, n]
+    e->slots.back().rows = 1; e->slots.back().cols = (int)n;
+}
+
+void build_weight_table(lr_engine* e) {
+    const lr_model_desc& d = e->d;
+    const int Hc = d.clip_hidden, Mc = d.clip_mlp, D = d.hidden, I = d.intermediate;
+    const int od = e->op_dt;
+    const std::string cp = "model.vision_embed_tokens.img_processor.vision_model.";
+    const std::string ep = "model.vision_embed_tokens.";
+    e->wte = (unsigned short*)oalloc(e, (size_t)d.vocab_size * D);
+    add_slot(e, "model.embed_tokens.weight", {d.vocab_size, D}, e->wte, D, D, DT_BF16, PACK_PLAIN, 0.02, 0);
+    e->cls = falloc(e, Hc);
+    vec_slot(e, cp + "embeddings.class_embedding", {Hc}, e->cls, 0.02, 0);
+    e->patch_w = oalloc(e, (size_t)Hc * e->Kpad);
+    add_slot(e, cp + "embeddings.patch_embedding.weight", {Hc, 3, d.clip_patch, d.clip_patch}, e->patch_w, e->Kpad, e->Kpad, od,
+             PACK_PLAIN, 0.02, 0);
+    e->pos = falloc(e, (size_t)e->T * Hc);
+    add_slot(e, cp + "embeddings.position_embedding.weight", {e->T, Hc}, e->pos, Hc, Hc, DT_F32, PACK_PLAIN, 0.02, 0);
+    e->pre_w = falloc(e, Hc); e->pre_b = falloc(e, Hc);
+    vec_slot(e, cp + "pre_layrnorm.weight", {Hc}, e->pre_w, 0.05, 1.0);
+    vec_slot(e, cp + "pre_layrnorm.bias", {Hc}, e->pre_b, 0.02, 0);
+    e->cl.resize(d.clip_layers);
+    for (int l = 0; l < d.clip_layers; ++l) {
+        ClipLayer& c = e->cl[l];
+        const std::string p = cp + "encoder.layers." + std::to_string(l) + ".";
+        c.qkv_w = oalloc(e, (size_t)3 * Hc * Hc); c.qkv_b = falloc(e, 3 * Hc);
+        const char* nm[3] = {"q_proj", "k_proj", "v_proj"};
+        for (int i = 0; i < 3; ++i) {
+            add_slot(e, p + "self_attn." + nm[i] + ".weight", {Hc, Hc}, (char*)c.qkv_w + (size_t)i * Hc * Hc * 2, Hc, Hc, od,
+                     PACK_PLAIN, 0.02, 0);
+            vec_slot(e, p + "self_attn." + nm[i] + ".bias", {Hc}, c.qkv_b + i * Hc, 0.02, 0);
+        }
+        c.out_w = oalloc(e, (size_t)Hc * Hc); c.out_b = falloc(e, Hc);
+        add_slot(e, p + "self_attn.out_proj.weight", {Hc, Hc}, c.out_w, Hc, Hc, od, PACK_PLAIN, 0.02, 0);
+        vec_slot(e, p + "self_attn.out_proj.bias", {Hc}, c.out_b, 0.02, 0);
+        c.ln1_w = falloc(e, Hc); c.ln1_b = falloc(e, Hc); c.ln2_w = falloc(e, Hc); c.ln2_b = falloc(e, Hc);
+        vec_slot(e, p + "layer_norm1.weight", {Hc}, c.ln1_w, 0.05, 1.0);
+        vec_slot(e, p + "layer_norm1.bias", {Hc}, c.ln1_b, 0.02, 0);
+        c.fc1_w = oalloc(e, (size_t)Mc * Hc); c.fc1_b = falloc(e, Mc);
+        add_slot(e, p + "mlp.fc1.weight", {Mc, Hc}, c.fc1_w, Hc, Hc, od, PACK_PLAIN, 0.02, 0);
+        vec_slot(e, p + "mlp.fc1.bias", {Mc}, c.fc1_b, 0.02, 0);
+        c.fc2_w = oalloc(e, (size_t)Hc * Mc); c.fc2_b = falloc(e, Hc);
+        add_slot(e, p + "mlp.fc2.weight", {Hc, Mc}, c.fc2_w, Mc, Mc, od, PACK_PLAIN, 0.02, 0);
+        vec_slot(e, p + "mlp.fc2.bias", {Hc}, c.fc2_b, 0.02, 0);
+        vec_slot(e, p + "layer_norm2.weight", {Hc}, c.ln2_w, 0.05, 1.0);
+        vec_slot(e, p + "layer_norm2.bias", {Hc}, c.ln2_b, 0.02, 0);
+    }
+    e->glb_gn = falloc(e, 4 * Hc); e->sub_gn = falloc(e, 4 * Hc);
+    vec_slot(e, ep + "glb_GN", {1, 1, 4 * Hc}, e->glb_gn, 0.02, 0);
+    vec_slot(e, ep + "sub_GN", {1, 1, 1, 4 * Hc}, e->sub_gn, 0.02, 0);
+    e->p0_w = oalloc(e, (size_t)D * 4 * Hc); e->p0_b = falloc(e, D);
+    e->p2_w = oalloc(e, (size_t)D * D); e->p2_b = falloc(e, D);
+    add_slot(e, ep + "img_projection.0.weight", {D, 4 * Hc}, e->p0_w, 4 * Hc, 4 * Hc, od, PACK_PLAIN, 0.02, 0);
+    vec_slot(e, ep + "img_projection.0.bias", {D}, e->p0_b, 0.02, 0);
+    add_slot(e, ep + "img_projection.2.weight", {D, D}, e->p2_w, D, D, od, PACK_PLAIN, 0.02, 0);
+    vec_slot(e, ep + "img_projection.2.bias", {D}, e->p2_b, 0.02, 0);
+    e->dl.resize(d.layers);
+    for (int l = 0; l < d.layers; ++l) {
+        DecLayer& L = e->dl[l];
+        const std::string p = "model.layers." + std::to_string(l) + ".";
+        L.ln1 = falloc(e, D); L.ln2 = falloc(e, D);
+        L.qkv_w = oalloc(e, (size_t)3 * D * D); L.o_w = oalloc(e, (size_t)D * D);
+        L.gu_w = oalloc(e, (size_t)2 * I * D); L.down_w = oalloc(e, (size_t)D * I);
+        vec_slot(e, p + "input_layernorm.weight", {D}, L.ln1, 0.05, 1.0);
+        add_slot(e, p + "self_attn.qkv_proj.weight", {3 * D, D}, L.qkv_w, D, D, od, PACK_PLAIN, 0.02, 0);
+        add_slot(e, p + "self_attn.o_proj.weight", {D, D}, L.o_w, D, D, od, PACK_PLAIN, 0.02, 0);
+        vec_slot(e, p + "post_attention_layernorm.weight", {D}, L.ln2, 0.05, 1.0);
+        add_slot(e, p + "mlp.gate_up_proj.weight", {2 * I, D}, L.gu_w, D, D, od, PACK_SWIGLU, 0.02, 0);
+        add_slot(e, p + "mlp.down_proj.weight", {D, I}, L.down_w, I, I, od, PACK_PLAIN, 0.02, 0);
+    }
+    e->norm_w = falloc(e, D);
+    vec_slot(e, "model.norm.weight", {D}, e->norm_w, 0.05, 1.0);
+    if (d.add_cross_attention) {
+        e->Wq = (unsigned short*)oalloc(e, (size_t)D * D);
+        e->WkT = (unsigned short*)oalloc(e, (size_t)D * D);
+        e->Wv = (unsigned short*)oalloc(e, (size_t)D * D);
+        e->ca_w = falloc(e, D);
+        add_slot(e, "W_q.weight", {D, D}, e->Wq, D, D, DT_BF16, PACK_PLAIN, 0.02, 0);
+        add_slot(e, "W_k.weight", {D, D}, e->WkT, D, D, DT_BF16, PACK_TRANSPOSE, 0.02, 0);
+        add_slot(e, "W_v.weight", {D, D}, e->Wv, D, D, DT_BF16, PACK_PLAIN, 0.02, 0);
+        vec_slot(e, "ca_layernorm.weight", {D}, e->ca_w, 0.05, 1.0);
+    }
+    e->vh = falloc(e, (size_t)d.value_head_dim * D);
+    add_slot(e, "value_head.weight", {d.value_head_dim, D}, e->vh, D, D, DT_F32, PACK_PLAIN, 1.0 / std::sqrt((double)D), 0);
+    // rope tables
+    e->inv_s = falloc(e, LR_MAX_HALF_HEAD); e->inv_l = falloc(e, LR_MAX_HALF_HEAD);
+    LR_HIP_CHECK(hipMemcpy(e->inv_s, d.inv_freq_short, sizeof(d.inv_freq_short), hipMemcpyHostToDevice));
+    LR_HIP_CHECK(hipMemcpy(e->inv_l, d.inv_freq_long, sizeof(d.inv_freq_long), hipMemcpyHostToDevice));
+}
+
+void ensure_stage(lr_engine* e, size_t raw_bytes, size_t n_f32) {
+    if (raw_bytes > e->stage_raw_cap) {
+        if (e->stage_raw) LR_HIP_CHECK(hipFree(e->stage_raw));
+        LR_HIP_CHECK(hipMalloc(&e->stage_raw, raw_bytes));
+        e->stage_raw_cap = raw_bytes;
+    }
+    if (n_f32 > e->stage_f32_cap) {
+        if (e->stage_f32) LR_HIP_CHECK(hipFree(e->stage_f32));
+        LR_HIP_CHECK(hipMalloc((void**)&e->stage_f32, n_f32 * 4));
+        e->stage_f32_cap = n_f32;
+    }
+}
+
+void pack_slot(lr_engine* e, Slot& s, const float* src_f32) {
+    launch_pack(src_f32, s.dst, s.rows, s.cols, s.ld_dst, s.mode == PACK_TRANSPOSE ? s.cols : s.cols_dst, s.dst_dtype, s.mode, 0);
+    s.provided = true;
+}
+
+void validate_desc(const lr_model_desc& d) {
+    auto bad = [](const char* m) { throw std::invalid_argument(m); };
+    if (d.struct_size != (int)sizeof(lr_model_desc)) bad("lr_model_desc.struct_size mismatch (ABI)");
+    if (d.hidden <= 0 || d.heads <= 0 || d.hidden % d.heads) bad("hidden must be divisible by heads");
+    const int hd = d.hidden / d.heads;
+    if (hd != 96 && hd != 64) bad("decoder head_dim must be 96 or 64");
+    if (d.clip_hidden % d.clip_heads || d.clip_hidden / d.clip_heads != 64) bad("CLIP head_dim must be 64");
+    if (d.hidden % 64 || d.intermediate % 64 || d.clip_hidden % 64 || d.clip_mlp % 64) bad("widths must be multiples of 64");
+    if (d.hidden > 4096 || d.clip_hidden > 4096) bad("hidden sizes above 4096 are not supported by the norm kernels");
+    if (d.clip_image % d.clip_patch || (d.clip_image / d.clip_patch) % 2) bad("CLIP grid must be even");
+    if (d.value_head_dim < 1 || d.value_head_dim > 64) bad("value_head_dim out of range");
+    if (d.max_batch < 1 || d.max_seq < 1 || d.max_crops < 2) bad("capacity fields must be positive (max_crops >= 2)");
+    if (d.operand_dtype != LR_DT_BF16 && d.operand_dtype != LR_DT_F16) bad("operand_dtype must be BF16 or F16");
+    if (d.layers < 0 || d.clip_layers < 0) bad("layer counts must be non-negative");
+}
+
+template <typename F> int guarded(lr_engine* e, F&& f) {
+    try {
+        if (e) LR_HIP_CHECK(hipSetDevice(e->device));
+        f();
+        return LR_OK;
+    } catch (const std::invalid_argument& ex) {
+        (e ? e->err : g_create_error) = ex.what();
+        return LR_EINVAL;
+    } catch (const std::logic_error& ex) {
+        (e ? e->err : g_create_error) = ex.what();
+        return LR_ESTATE;
+    } catch (const std::exception& ex) {
+        (e ? e->err : g_create_error) = ex.what();
+        return LR_EHIP;
+    }
+}
+
+void gemm(lr_engine* e, hipStream_t st, const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int lda,
+          int ldw, int ldc, int epi, int act) {
+    GemmParams p{A, W, C, bias, M, N, K, lda, ldw, ldc, epi, act};
+    launch_gemm_bt(p, e->op_dt, e->gemm_tile, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int lr_abi_version(void) { return LR_ABI_VERSION; }
+
+const char* lr_last_error(lr_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int lr_create(const lr_model_desc* desc, int device, lr_handle* out) {
+    if (!desc || !out) { g_create_error = "lr_create: null argument"; return LR_EINVAL; }
+    lr_engine* e = nullptr;
+    int rc = guarded(nullptr, [&] {
+        validate_desc(*desc);
+        int ndev = 0;
+        LR_HIP_CHECK(hipGetDeviceCount(&ndev));
+        if (device < 0 || device >= ndev) throw std::invalid_argument("lr_create: no such HIP device");
+        LR_HIP_CHECK(hipSetDevice(device));
+        e = new lr_engine();
+        e->d = *desc;
+        e->device = device;
+        e->op_dt = desc->operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16;
+        e->G = desc->clip_image / desc->clip_patch;
+        e->T = e->G * e->G + 1;
+        e->Kpatch = 3 * desc->clip_patch * desc->clip_patch;
+        e->Kpad = (e->Kpatch + 63) / 64 * 64;
+        e->hd = desc->hidden / desc->heads;
+        e->half = e->hd / 2;
+        const int g2 = e->G / 2;
+        e->Vcap = desc->max_crops * g2 * g2 + 1 + desc->max_crops * g2;
+        build_weight_table(e);
+    });
+    if (rc != LR_OK) {
+        if (e) { g_create_error = g_create_error.empty() ? e->err : g_create_error; lr_destroy(e); }
+        return rc;
+    }
+    *out = e;
+    return LR_OK;
+}
+
+int lr_destroy(lr_handle h) {
+    if (!h) return LR_OK;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    for (void* p : h->allocs) hipFree(p);
+    if (h->stage_raw) hipFree(h->stage_raw);
+    if (h->stage_f32) hipFree(h->stage_f32);
+    if (h->tab_host) hipHostFree(h->tab_host);
+    for (int i = 0; i < lr_engine::NSLOT; ++i) if (h->tab_ev[i]) hipEventDestroy(h->tab_ev[i]);
+    delete h;
+    return LR_OK;
+}
+
+int lr_num_weights(lr_handle h) { return h ? (int)h->slots.size() : 0; }
+const char* lr_weight_name(lr_handle h, int i) {
+    if (!h || i < 0 || i >= (int)h->slots.size()) return nullptr;
+    return h->slots[i].name.c_str();
+}
+
+int lr_upload_weight(lr_handle h, const char* name, const void* data, const int64_t* shape, int ndim, int dtype, int is_device) {
+    if (!h) return LR_EINVAL;
+    return guarded(h, [&] {
+        if (!name || !data || !shape) throw std::invalid_argument("lr_upload_weight: null argument");
+        auto it = h->index.find(name);
+        if (it == h->index.end()) throw std::invalid_argument(std::string("lr_upload_weight: unknown tensor ") + name);
+        Slot& s = h->slots[it->second];
+        if ((int)s.shape.size() != ndim) throw std::invalid_argument(std::string("lr_upload_weight: rank mismatch for ") + name);
+        size_t n = 1;
+        for (int i = 0; i < ndim; ++i) {
+            if (shape[i] != s.shape[i]) throw std::invalid_argument(std::string("lr_upload_weight: shape mismatch for ") + name);
+            n *= (size_t)shape[i];
+        }
+        const size_t esz = dtype == LR_DT_F32 ? 4 : 2;
+        if (dtype != LR_DT_F32 && dtype != LR_DT_BF16 && dtype != LR_DT_F16) throw std::invalid_argument("lr_upload_weight: bad dtype");
+        ensure_stage(h, is_device ? 0 : n * esz, n);
+        const void* dev_src = data;
+        if (!is_device) {
+            LR_HIP_CHECK(hipMemcpy(h->stage_raw, data, n * esz, hipMemcpyHostToDevice));
+            dev_src = h->stage_raw;
+        }
+        const float* f32 = (const float*)dev_src;
+        if (dtype != LR_DT_F32) {
+            launch_cvt_to_f32(dev_src, dtype == LR_DT_F16 ? DT_F16 : DT_BF16, h->stage_f32, n, 0);
+            f32 = h->stage_f32;
+        }
+        pack_slot(h, s, f32);
+        LR_HIP_CHECK(hipStreamSynchronize(0));
+    });
+}
+
+int lr_synth_weights(lr_handle h, uint64_t seed) {
+    if (!h) return LR_EINVAL;
+    return guarded(h, [&] {
+        for (Slot& s : h->slots) {
+            const size_t n = (size_t)s.rows * s.cols;
+            ensure_stage(h, 0, n);
+            launch_synth_fill(h->stage_f32, n, tensor_seed(seed, s.name.c_str()), uniform_scale(s.std_), (float)s.offset, 1, 0);
+            pack_slot(h, s, h->stage_f32);
+        }
+        LR_HIP_CHECK(hipStreamSynchronize(0));
+    });
+}
+
+size_t lr_workspace_bytes(lr_handle h) { return h ? h->ws_bytes : 0; }
+
+int lr_finalize(lr_handle h) {
+    if (!h) return LR_EINVAL;
+    return guarded(h, [&] {
+        if (h->finalized) return;
+        for (const Slot& s : h->slots)
+            if (!s.provided) throw std::logic_error("lr_finalize: tensor never provided: " + s.name);
+        if (h->stage_raw) { LR_HIP_CHECK(hipFree(h->stage_raw)); h->stage_raw = nullptr; h->stage_raw_cap = 0; }
+        if (h->stage_f32) { LR_HIP_CHECK(hipFree(h->stage_f32)); h->stage_f32 = nullptr; h->stage_f32_cap = 0; }
+        const lr_model_desc& d = h->d;
+        const size_t B = d.max_batch, S = d.max_seq, C = d.max_crops;
+        const size_t Hc = d.clip_hidden, Mc = d.clip_mlp, D = d.hidden, I = d.intermediate;
+        const size_t PAD = 256;
+        const size_t NC = B * C, Rc = NC * h->T + PAD, Rp = NC * (h->T - 1) + PAD, SV = B * (size_t)h->Vcap + PAD, Rl = B * S + PAD;
+        auto W = [&](size_t bytes) { return h->dalloc(bytes, false); };
+        h->patchA = W(Rp * h->Kpad * 2); h->patch_out = (float*)W(Rp * Hc * 4);
+        h->clip_x = (float*)W(Rc * Hc * 4); h->clip_h = W(Rc * Hc * 2); h->clip_qkv = W(Rc * 3 * Hc * 2);
+        h->clip_att = W(Rc * Hc * 2); h->clip_ff = W(Rc * Mc * 2);
+        h->hdA = W(SV * 4 * Hc * 2); h->proj1 = W(SV * D * 2); h->ev = (float*)W(SV * D * 4);
+        h->x = (float*)W(Rl * D * 4); h->h = W(Rl * D * 2); h->qkv32 = (float*)W(Rl * 3 * D * 4); h->qkv = W(Rl * 3 * D * 2);
+        h->att = W(Rl * D * 2); h->ff = W(Rl * I * 2); h->cs = (float*)W(Rl * h->hd * 4);
+        h->pos_ids = (int*)W(Rl * 4); h->img_row = (int*)W(Rl * 4); h->tstat = (int*)W(B * 16);
+        h->hL = (float*)W(B * D * 4); h->tq = (float*)W(B * D * 4); h->tkq = (float*)W(B * D * 4);
+        h->tsc = (float*)W(B * (size_t)h->Vcap * 4); h->tctx = (float*)W(B * D * 4); h->tao = (float*)W(B * D * 4);
+        // tables: crop_src[NC] | HdSample[B] | voff[B+1]
+        h->tab_bytes = ((NC * 4 + B * sizeof(HdSample) + (B + 1) * 4) + 255) & ~(size_t)255;
+        LR_HIP_CHECK(hipHostMalloc((void**)&h->tab_host, h->tab_bytes * lr_engine::NSLOT));
+        h->tab_dev = (char*)W(h->tab_bytes * lr_engine::NSLOT);
+        for (int i = 0; i < lr_engine::NSLOT; ++i) LR_HIP_CHECK(hipEventCreateWithFlags(&h->tab_ev[i], hipEventDisableTiming));
+        LR_HIP_CHECK(hipMemset(h->tstat, 0, B * 16));
+        h->finalized = true;
+    });
+}
+
+int lr_set_layer_limits(lr_handle h, int n_clip_layers, int n_layers) {
+    if (!h) return LR_EINVAL;
+    h->lim_clip = n_clip_layers; h->lim_layers = n_layers;
+    return LR_OK;
+}
+int lr_set_gemm_tile(lr_handle h, int tile) {
+    if (!h || tile < -1 || tile > 2) return LR_EINVAL;
+    h->gemm_tile = tile;
+    return LR_OK;
+}
+
+int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_mask, const void* pixel_values, int pix_dtype,
+               const int64_t* image_sizes_host, int B, int S, int n_crops, int flags, float* rewards_out, void* hip_stream) {
+    if (!h) return LR_EINVAL;
+    return guarded(h, [&] {
+        if (!h->finalized) throw std::logic_error("lr_forward: call lr_finalize first");
+        if (!input_ids || !attention_mask || !pixel_values || !image_sizes_host || !rewards_out)
+            throw std::invalid_argument("lr_forward: null argument (every row must carry an image, modeling_phi3_v.py:252)");
+        const lr_model_desc& d = h->d;
+        if (B < 1 || B > d.max_batch) throw std::invalid_argument("lr_forward: batch exceeds max_batch");
+        if (S < 1 || S > d.max_seq) throw std::invalid_argument("lr_forward: sequence exceeds max_seq");
+        if (n_crops < 2 || n_crops > d.max_crops) throw std::invalid_argument("lr_forward: n_crops exceeds max_crops");
+        if (pix_dtype != LR_DT_F32 && pix_dtype != LR_DT_BF16) throw std::invalid_argument("lr_forward: pixel dtype must be F32 or BF16");
+        hipStream_t st = (hipStream_t)hip_stream;
+        const int Hc = d.clip_hidden, Mc = d.clip_mlp, D = d.hidden, I = d.intermediate, T = h->T, g2 = h->G / 2;
+        const int img = d.clip_image;
+
+        // ---- host plan: active crops, HD layout, image-token offsets (modeling_phi3_v.py:276-297) ----
+        const int slot = h->slot_i; h->slot_i = (h->slot_i + 1) % lr_engine::NSLOT;
+        if (h->tab_used[slot]) LR_HIP_CHECK(hipEventSynchronize(h->tab_ev[slot]));   // bounds host run-ahead to NSLOT passes
+        char* th = h->tab_host + (size_t)slot * h->tab_bytes;
+        char* td = h->tab_dev + (size_t)slot * h->tab_bytes;
+        const size_t NCcap = (size_t)d.max_batch * d.max_crops;
+        int* crop_src = (int*)th;
+        HdSample* smp = (HdSample*)(th + NCcap * 4);
+        int* voff = (int*)(th + NCcap * 4 + (size_t)d.max_batch * sizeof(HdSample));
+        int NC = 0, SV = 0, Vmax = 0;
+        for (int b = 0; b < B; ++b) {
+            const int64_t hh = image_sizes_host[2 * b], ww = image_sizes_host[2 * b + 1];
+            if (hh <= 0 || ww <= 0 || hh % img || ww % img) throw std::invalid_argument("lr_forward: image_sizes must be positive multiples of the crop size");
+            const int hc = (int)(hh / img), wc = (int)(ww / img);
+            if (hc * wc + 1 > n_crops) throw std::invalid_argument("lr_forward: image_sizes needs more crops than pixel_values holds");
+            smp[b] = HdSample{hc, wc, NC, SV};
+            voff[b] = SV;
+            for (int c = 0; c <= hc * wc; ++c) crop_src[NC++] = b * n_crops + c;
+            const int V = hc * g2 * (wc * g2 + 1) + 1 + g2 * (g2 + 1);
+            SV += V;
+            Vmax = V > Vmax ? V : Vmax;
+        }
+        voff[B] = SV;
+        LR_HIP_CHECK(hipMemcpyAsync(td, th, h->tab_bytes, hipMemcpyHostToDevice, st));
+        LR_HIP_CHECK(hipEventRecord(h->tab_ev[slot], st));
+        h->tab_used[slot] = true;
+        const int* d_crop_src = (const int*)td;
+        const HdSample* d_smp = (const HdSample*)(td + NCcap * 4);
+        const int* d_voff = (const int*)(td + NCcap * 4 + (size_t)d.max_batch * sizeof(HdSample));
+        h->lastB = B; h->lastS = S; h->lastNC = NC; h->lastSV = SV;
+
+        // ---- CLIP tower (utils/utils.py:266-273) ----
+        const int Rp = NC * (T - 1), Rc = NC * T;
+        launch_im2col(pixel_values, pix_dtype == LR_DT_F32 ? DT_F32 : DT_BF16, d_crop_src, NC, img, d.clip_patch, h->Kpad, h->patchA, h->op_dt, st);
+        gemm(h, st, h->patchA, h->patch_w, h->patch_out, nullptr, Rp, Hc, h->Kpad, h->Kpad, h->Kpad, Hc, EPI_OUT_F32, ACT_NONE);
+        launch_clip_embed(h->patch_out, h->cls, h->pos, h->pre_w, h->pre_b, h->clip_x, NC, T, Hc, d.clip_ln_eps, st);
+        const int ncl = h->lim_clip >= 0 && h->lim_clip < d.clip_layers ? h->lim_clip : d.clip_layers;
+        for (int l = 0; l < ncl; ++l) {
+            const ClipLayer& c = h->cl[l];
+            launch_norm_rows(h->clip_x, c.ln1_w, c.ln1_b, h->clip_h, Rc, Hc, d.clip_ln_eps, h->op_dt, st);
+            gemm(h, st, h->clip_h, c.qkv_w, h->clip_qkv, c.qkv_b, Rc, 3 * Hc, Hc, Hc, Hc, 3 * Hc, EPI_OUT_OP, ACT_NONE);
+            AttnParams ap{h->clip_qkv, h->clip_qkv, h->clip_qkv, h->clip_att, nullptr, nullptr, 0, 3 * Hc, Hc, 0, Hc, 2 * Hc, T, d.clip_heads, 0.125f};
+            launch_attention(ap, NC, 64, false, h->op_dt, st);
+            gemm(h, st, h->clip_att, c.out_w, h->clip_x, c.out_b, Rc, Hc, Hc, Hc, Hc, Hc, EPI_RESADD_F32, ACT_NONE);
+            launch_norm_rows(h->clip_x, c.ln2_w, c.ln2_b, h->clip_h, Rc, Hc, d.clip_ln_eps, h->op_dt, st);
+            gemm(h, st, h->clip_h, c.fc1_w, h->clip_ff, c.fc1_b, Rc, Mc, Hc, Hc, Hc, Mc, EPI_OUT_OP, ACT_QUICK_GELU);
+            gemm(h, st, h->clip_ff, c.fc2_w, h->clip_x, c.fc2_b, Rc, Hc, Mc, Mc, Mc, Hc, EPI_RESADD_F32, ACT_NONE);
+        }
+        // ---- HD transform + projector (modeling_phi3_v.py:254-303) ----
+        launch_hd_gather(h->clip_x, d_smp, B, SV, T, Hc, h->sub_gn, h->glb_gn, h->hdA, h->op_dt, st);
+        gemm(h, st, h->hdA, h->p0_w, h->proj1, h->p0_b, SV, D, 4 * Hc, 4 * Hc, 4 * Hc, D, EPI_OUT_OP, ACT_GELU_ERF);
+        gemm(h, st, h->proj1, h->p2_w, h->ev, h->p2_b, SV, D, D, D, D, D, EPI_OUT_F32, ACT_NONE);
+        // ---- embeddings, positions (modeling_phi3_v.py:228-249, rw_model:344-345) ----
+        const int Rl = B * S;
+        launch_token_plan(input_ids, attention_mask, B, S, d_voff, h->img_row, h->pos_ids, h->tstat, st);
+        launch_embed(input_ids, h->img_row, h->wte, h->ev, h->x, Rl, D, d.vocab_size, st);
+        launch_rope_table(h->pos_ids, h->tstat, B, S, h->inv_s, h->inv_l, d.rope_scaling, d.orig_max_pos, h->half, h->cs, st);
+        // ---- decoder stack (modeling_phi3_v.py:1144-1205) ----
+        const int nl = h->lim_layers >= 0 && h->lim_layers < d.layers ? h->lim_layers : d.layers;
+        const float ascale = 1.0f / std::sqrt((float)h->hd);
+        for (int l = 0; l < nl; ++l) {
+            const DecLayer& L = h->dl[l];
+            launch_norm_rows(h->x, L.ln1, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st);
+            gemm(h, st, h->h, L.qkv_w, h->qkv32, nullptr, Rl, 3 * D, D, D, D, 3 * D, EPI_OUT_F32, ACT_NONE);
+            launch_rope_split(h->qkv32, h->cs, h->qkv, Rl, D, d.heads, h->op_dt, st);
+            AttnParams ap{h->qkv, h->qkv, h->qkv, h->att, attention_mask, h->tstat + 1, 4, 3 * D, D, 0, D, 2 * D, S, d.heads, ascale};
+            launch_attention(ap, B, h->hd, true, h->op_dt, st);
+            gemm(h, st, h->att, L.o_w, h->x, nullptr, Rl, D, D, D, D, D, EPI_RESADD_F32, ACT_NONE);
+            launch_norm_rows(h->x, L.ln2, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st);
+            gemm(h, st, h->h, L.gu_w, h->ff, nullptr, Rl, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE);
+            gemm(h, st, h->ff, L.down_w, h->x, nullptr, Rl, D, I, I, I, D, EPI_RESADD_F32, ACT_NONE);
+        }
+        // ---- tail: final norm of the gathered row, SkipCA, value head (rw_model:376-448) ----
+        launch_gather_norm_rows(h->x, h->tstat, S, (flags & LR_FWD_TRAINING_LAST_TOKEN) ? 1 : 0, h->norm_w, d.rms_eps, h->hL, B, D, st);
+        const float* ao = nullptr;
+        if (d.add_cross_attention) {
+            launch_rowvec_linear(h->hL, h->Wq, h->tq, B, D, D, st);
+            launch_rowvec_linear(h->tq, h->WkT, h->tkq, B, D, D, st);
+            launch_ca_scores(h->ev, h->tkq, d_voff, B, Vmax, D, 1.0f / std::sqrt((float)D), h->tsc, st);
+            launch_ca_softmax(h->tsc, B, Vmax, st);
+            launch_ca_context(h->ev, h->tsc, d_voff, B, Vmax, D, h->tctx, st);
+            launch_rowvec_linear(h->tctx, h->Wv, h->tao, B, D, D, st);
+            ao = h->tao;
+        }
+        launch_reward_head(h->hL, ao, h->ca_w, d.ca_eps, h->vh, d.value_head_dim, rewards_out, B, D, st);
+        LR_HIP_CHECK(hipGetLastError());
+    });
+}
+
+int lr_read_tap(lr_handle h, const char* name, float* host_out, size_t capacity, size_t* n) {
+    if (!h || !name || !host_out || !n) return LR_EINVAL;
+    return guarded(h, [&] {
+        const float* src = nullptr; size_t cnt = 0;
+        const std::string nm = name;
+        if (nm == "clip_x") { src = h->clip_x; cnt = (size_t)h->lastNC * h->T * h->d.clip_hidden; }
+        else if (nm == "ev") { src = h->ev; cnt = (size_t)h->lastSV * h->d.hidden; }
+        else if (nm == "x") { src = h->x; cnt = (size_t)h->lastB * h->lastS * h->d.hidden; }
+        else if (nm == "hL") { src = h->hL; cnt = (size_t)h->lastB * h->d.hidden; }
+        else throw std::invalid_argument("lr_read_tap: unknown tap");
+        if (cnt > capacity) throw std::invalid_argument("lr_read_tap: buffer too small");
+        LR_HIP_CHECK(hipDeviceSynchronize());
+        LR_HIP_CHECK(hipMemcpy(host_out, src, cnt * 4, hipMemcpyDeviceToHost));
+        *n = cnt;
+    });
+}
+
+// ------------------------------------------------------------------------- single-kernel entries
+static int op_guard(const std::function<void()>& f) {
+    try { f(); LR_HIP_CHECK(hipGetLastError()); return LR_OK; }
+    catch (const std::exception& ex) { g_create_error = ex.what(); return LR_EINVAL; }
+}
+
+int lr_op_gemm_bt(const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int lda, int ldw, int ldc,
+                  int epi, int act, int operand_dtype, int tile, void* hip_stream) {
+    return op_guard([&] {
+        GemmParams p{A, W, C, bias, M, N, K, lda, ldw, ldc, epi, act};
+        launch_gemm_bt(p, operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16, tile, (hipStream_t)hip_stream);
+    });
+}
+
+int lr_op_attention(const void* Q, const void* K, const void* V, void* O, const int64_t* mask, const int* kmin, int ldq, int ldo,
+                    int qoff, int koff, int voff, int batch, int S, int heads, int head_dim, int causal, float scale,
+                    int operand_dtype, void* hip_stream) {
+    return op_guard([&] {
+        AttnParams p{Q, K, V, O, mask, kmin, 1, ldq, ldo, qoff, koff, voff, S, heads, scale};
+        launch_attention(p, batch, head_dim, causal != 0, operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16, (hipStream_t)hip_stream);
+    });
+}
+
+int lr_op_norm_rows(const float* x, const float* w, const float* b, void* y, int rows, int H, float eps, int operand_dtype,
+                    void* hip_stream) {
+    return op_guard([&] { launch_norm_rows(x, w, b, y, rows, H, eps, operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16, (hipStream_t)hip_stream); });
+}
+
+int lr_op_synth_fill(float* out, size_t n, uint64_t seed, const char* name, float std_, float offset, int bf16_round,
+                     void* hip_stream) {
+    return op_guard([&] { launch_synth_fill(out, n, tensor_seed(seed, name), uniform_scale(std_), offset, bf16_round, (hipStream_t)hip_stream); });
+}
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+// Host-side launchers of the gfx950 kernels (definitions in gemm.hip / attention.hip / rowops.hip).
+#pragma once
+#include "common.h"
+#include <stdexcept>
+
+namespace lr {
+
+// gemm.hip
+void launch_gemm_bt(const GemmParams& p, int operand_dtype, int tile, hipStream_t st);
+// attention.hip
+void launch_attention(const AttnParams& p, int batch, int head_dim, bool causal, int operand_dtype, hipStream_t st);
+
+// rowops.hip ------------------------------------------------------------------------------------
+// y_op[r][:] = LN(x[r][:]) * w + b   (b == null -> RMSNorm: x * rsqrt(mean x^2 + eps) * w)
+void launch_norm_rows(const float* x, const float* w, const float* b, void* y, int rows, int H, float eps,
+                      int operand_dtype, hipStream_t st);
+// pixels [B, C, 3, img, img] (fp32/bf16) -> patch matrix [ncrop*g*g, Kpad] operand dtype; crop_src[i] = b*C + c
+void launch_im2col(const void* pixels, int pix_dtype, const int* crop_src, int ncrop, int img, int patch, int Kpad,
+                   void* out, int operand_dtype, hipStream_t st);
+// x[crop*T + t] = pre_LN( (t ? patch_out[crop*(T-1) + t-1] : cls) + pos[t] )
+void launch_clip_embed(const float* patch_out, const float* cls, const float* pos, const float* lnw, const float* lnb,
+                       float* x, int ncrop, int T, int H, float eps, hipStream_t st);
+// per-sample token plan: positions, image-slot ranks, last valid index, first valid index
+// tstat[b] = {last valid index, first valid index, #image slots, #valid tokens}
+void launch_token_plan(const int64_t* ids, const int64_t* mask, int B, int S, const int* voff, int* img_row, int* pos,
+                       int* tstat, hipStream_t st);
+// x[b*S+s] = img_row >= 0 ? ev[img_row] : wte[clamp(id)]
+void launch_embed(const int64_t* ids, const int* img_row, const unsigned short* wte_bf16, const float* ev, float* x,
+                  int rows, int D, int vocab, hipStream_t st);
+// cos/sin table [rows][hd/2][2] from positions (su-scaled RoPE); picks long factors if max(pos)+1 > orig_max
+void launch_rope_table(const int* pos, const int* tstat, int B, int S, const float* inv_freq_short,
+                       const float* inv_freq_long, float scaling, int orig_max_pos, int half, float* cs, hipStream_t st);
+// qkv32 [rows, 3D] fp32 -> qkv operand dtype with RoPE applied to q and k heads
+void launch_rope_split(const float* qkv32, const float* cs, void* out, int rows, int D, int heads, int operand_dtype,
+                       hipStream_t st);
+// HD transform gather (modeling_phi3_v.py:254-362): rows of [sum V, 4H] from CLIP features x [ncrop*T, H]
+struct HdSample { int hc, wc, crop0, voff; };
+void launch_hd_gather(const float* clipx, const HdSample* samples, int B, int total_rows, int T, int H,
+                      const float* sub_gn, const float* glb_gn, void* out, int operand_dtype, hipStream_t st);
+
+// tail (fp32) -----------------------------------------------------------------------------------
+// y[b] = RMSNorm(x[b*S + (use_last_pos ? S-1 : tstat[b].last_valid)])
+void launch_gather_norm_rows(const float* x, const int* tstat, int S, int use_last_pos, const float* w, float eps,
+                             float* y, int B, int D, hipStream_t st);
+void launch_rowvec_linear(const float* x, const unsigned short* W_bf16, float* y, int B, int N, int K, hipStream_t st);
+void launch_ca_scores(const float* ev, const float* kq, const int* voff, int B, int Vmax, int D, float scale, float* sc,
+                      hipStream_t st);
+void launch_ca_softmax(float* sc, int B, int Vmax, hipStream_t st);
+void launch_ca_context(const float* ev, const float* pr, const int* voff, int B, int Vmax, int D, float* ctx,
+                       hipStream_t st);
+void launch_reward_head(const float* hL, const float* attn_o, const float* ca_w, float ca_eps, const float* vh, int d,
+                        float* out, int B, int D, hipStream_t st);
+
+// weights ---------------------------------------------------------------------------------------
+void launch_synth_fill(float* out, size_t n, uint64_t tseed, float scale, float offset, int bf16_round, hipStream_t st);
+enum : int { PACK_PLAIN = 0, PACK_SWIGLU = 1, PACK_TRANSPOSE = 2 };
+// dst[f(r)][c] (ld_dst elements, zero-padded columns up to cols_dst) = convert(src[r][c])
+void launch_pack(const float* src, void* dst, int rows, int cols, int ld_dst, int cols_dst, int dst_dtype, int mode,
+                 hipStream_t st);
+void launch_cvt_to_f32(const void* src, int src_dtype, float* dst, size_t n, hipStream_t st);
+
+}  // namespace lr

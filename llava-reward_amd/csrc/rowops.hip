@@ -1,0 +1,637 @@
+// HBM-bound row kernels of the scoring path: norms, patchify, embedding scatter, RoPE, HD gather,
+// the fp32 reward tail, and weight packing / synthesis.  One wave (64 lanes) per row wherever a
+// row reduction is needed; 16-byte fp32 loads and 8-byte operand stores.
+#include "common.h"
+#include "kernels.h"
+
+namespace lr {
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+template <typename OT> __device__ __forceinline__ void store4(void* base, size_t elem, float a, float b, float c, float d) {
+    uint2 w;
+    w.x = pack2<OT>(a, b);
+    w.y = pack2<OT>(c, d);
+    *(uint2*)((unsigned short*)base + elem) = w;
+}
+
+// ------------------------------------------------------------------------------------------ norms
+// modeling_phi3_v.py:377-391 (RMSNorm: w * (x * rsqrt(mean(x^2) + eps))) and CLIP LayerNorm.
+constexpr int NORM_MAXC = 16;   // H <= 4096
+
+template <typename OT, bool LAYERNORM>
+__global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, void* __restrict__ y, int rows,
+                                                        int H, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int nch = H >> 2;
+    const float4* xr = (const float4*)(x + (size_t)row * H);
+    float4 v[NORM_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NORM_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            v[i] = xr[c];
+            s += LAYERNORM ? (v[i].x + v[i].y + v[i].z + v[i].w)
+                           : (v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+    }
+    s = wave_sum(s);
+    float mean = 0.f, rstd;
+    if (LAYERNORM) {
+        mean = s / H;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NORM_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+                q += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+            }
+        }
+        q = wave_sum(q);
+        rstd = rsqrtf(q / H + eps);
+    } else {
+        rstd = rsqrtf(s / H + eps);
+    }
+#pragma unroll
+    for (int i = 0; i < NORM_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            const float4 ww = ((const float4*)w)[c];
+            float o0 = (v[i].x - mean) * rstd * ww.x, o1 = (v[i].y - mean) * rstd * ww.y;
+            float o2 = (v[i].z - mean) * rstd * ww.z, o3 = (v[i].w - mean) * rstd * ww.w;
+            if (LAYERNORM) {
+                const float4 bb = ((const float4*)b)[c];
+                o0 += bb.x; o1 += bb.y; o2 += bb.z; o3 += bb.w;
+            }
+            store4<OT>(y, (size_t)row * H + 4 * c, o0, o1, o2, o3);
+        }
+    }
+}
+
+void launch_norm_rows(const float* x, const float* w, const float* b, void* y, int rows, int H, float eps,
+                      int operand_dtype, hipStream_t st) {
+    if (rows <= 0) return;
+    if (H % 4 || H > NORM_MAXC * 256) throw std::runtime_error("norm_rows: H must be a multiple of 4 and <= 4096");
+    dim3 g(cdiv(rows, 4)), t(256);
+    const bool f16 = operand_dtype == DT_F16;
+    if (b) {
+        if (f16) hipLaunchKernelGGL((norm_rows_kernel<F16, true>), g, t, 0, st, x, w, b, y, rows, H, eps);
+        else hipLaunchKernelGGL((norm_rows_kernel<BF16, true>), g, t, 0, st, x, w, b, y, rows, H, eps);
+    } else {
+        if (f16) hipLaunchKernelGGL((norm_rows_kernel<F16, false>), g, t, 0, st, x, w, b, y, rows, H, eps);
+        else hipLaunchKernelGGL((norm_rows_kernel<BF16, false>), g, t, 0, st, x, w, b, y, rows, H, eps);
+    }
+}
+
+// ------------------------------------------------------------------------------------- patchify
+// Conv2d(3,H,k=p,s=p,bias=False) as a GEMM: row = (crop, py, px), column k = c*p*p + ky*p + kx, zero
+// padded to Kpad.  One block per (crop, py): reads p pixel rows of each channel, writes g patch rows.
+template <typename OT, typename PT>
+__global__ __launch_bounds__(256) void im2col_kernel(const PT* __restrict__ pix, const int* __restrict__ crop_src,
+                                                     int img, int patch, int Kpad, void* __restrict__ out) {
+    const int g = img / patch;
+    const int crop = blockIdx.x / g, py = blockIdx.x % g;
+    const PT* src = pix + (size_t)crop_src[crop] * 3 * img * img;
+    const int K = 3 * patch * patch;
+    unsigned short* dst = (unsigned short*)out + ((size_t)crop * g * g + (size_t)py * g) * Kpad;
+    for (int idx = threadIdx.x; idx < g * Kpad; idx += 256) {
+        const int px = idx / Kpad, k = idx - px * Kpad;
+        float v = 0.f;
+        if (k < K) {
+            const int c = k / (patch * patch), rem = k - c * patch * patch;
+            const int ky = rem / patch, kx = rem - ky * patch;
+            v = (float)src[((size_t)c * img + (py * patch + ky)) * img + px * patch + kx];
+        }
+        dst[idx] = Op<OT>::from_f32(v);
+    }
+}
+
+void launch_im2col(const void* pixels, int pix_dtype, const int* crop_src, int ncrop, int img, int patch, int Kpad,
+                   void* out, int operand_dtype, hipStream_t st) {
+    if (ncrop <= 0) return;
+    dim3 g(ncrop * (img / patch)), t(256);
+    const bool f16 = operand_dtype == DT_F16;
+    if (pix_dtype == DT_F32) {
+        if (f16) hipLaunchKernelGGL((im2col_kernel<F16, float>), g, t, 0, st, (const float*)pixels, crop_src, img, patch, Kpad, out);
+        else hipLaunchKernelGGL((im2col_kernel<BF16, float>), g, t, 0, st, (const float*)pixels, crop_src, img, patch, Kpad, out);
+    } else if (pix_dtype == DT_BF16) {
+        if (f16) hipLaunchKernelGGL((im2col_kernel<F16, __bf16>), g, t, 0, st, (const __bf16*)pixels, crop_src, img, patch, Kpad, out);
+        else hipLaunchKernelGGL((im2col_kernel<BF16, __bf16>), g, t, 0, st, (const __bf16*)pixels, crop_src, img, patch, Kpad, out);
+    } else {
+        throw std::runtime_error("im2col: pixel dtype must be f32 or bf16");
+    }
+}
+
+// --------------------------------------------------------------- CLIP embeddings + pre_layrnorm
+__global__ __launch_bounds__(256) void clip_embed_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls,
+                                                         const float* __restrict__ pos, const float* __restrict__ lnw,
+                                                         const float* __restrict__ lnb, float* __restrict__ x, int rows,
+                                                         int T, int H, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int crop = row / T, t = row - crop * T;
+    const int nch = H >> 2;
+    const float4* src = t ? (const float4*)(patch_out + ((size_t)crop * (T - 1) + (t - 1)) * H) : (const float4*)cls;
+    const float4* pp = (const float4*)(pos + (size_t)t * H);
+    float4 v[NORM_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NORM_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            const float4 a = src[c], p = pp[c];
+            v[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+            s += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+    }
+    const float mean = wave_sum(s) / H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NORM_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            q += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / H + eps);
+    float4* dst = (float4*)(x + (size_t)row * H);
+#pragma unroll
+    for (int i = 0; i < NORM_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            const float4 ww = ((const float4*)lnw)[c], bb = ((const float4*)lnb)[c];
+            dst[c] = make_float4((v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y,
+                                 (v[i].z - mean) * rstd * ww.z + bb.z, (v[i].w - mean) * rstd * ww.w + bb.w);
+        }
+    }
+}
+
+void launch_clip_embed(const float* patch_out, const float* cls, const float* pos, const float* lnw, const float* lnb,
+                       float* x, int ncrop, int T, int H, float eps, hipStream_t st) {
+    const int rows = ncrop * T;
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(clip_embed_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, patch_out, cls, pos, lnw, lnb, x, rows, T, H, eps);
+}
+
+// ------------------------------------------------------------------------------------ token plan
+// rw_model_general_preference.py:344-345 (position ids), modeling_phi3_v.py:228-249 (image slots in
+// row-major order), rw_model:420/439 (last valid index).  tstat[b] = {last_valid, first_valid, n_img, n_valid}.
+__global__ __launch_bounds__(256) void token_plan_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask,
+                                                         int S, const int* __restrict__ voff, int* __restrict__ img_row,
+                                                         int* __restrict__ pos, int* __restrict__ tstat) {
+    __shared__ int wsum[2][4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int run_m = 0, run_n = 0, last = -1, first = S;
+    for (int base = 0; base < S; base += 256) {
+        const int s = base + tid;
+        bool m = false, n = false;
+        if (s < S) {
+            m = mask[(size_t)b * S + s] != 0;
+            const int64_t id = ids[(size_t)b * S + s];
+            n = id < 0 && id > -1000000000LL;
+        }
+        const unsigned long long bm = __ballot(m), bn = __ballot(n);
+        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const int pm = __popcll(bm & lt), pn = __popcll(bn & lt);
+        if (lane == 0) { wsum[0][wave] = __popcll(bm); wsum[1][wave] = __popcll(bn); }
+        __syncthreads();
+        int om = run_m, on = run_n, tm = 0, tn = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) { om += wsum[0][w]; on += wsum[1][w]; }
+            tm += wsum[0][w]; tn += wsum[1][w];
+        }
+        if (s < S) {
+            pos[(size_t)b * S + s] = m ? (om + pm) : 1;         // cumsum(mask) - 1, pads -> 1
+            img_row[(size_t)b * S + s] = n ? (voff[b] + on + pn) : -1;
+            if (m) { last = s; if (s < first) first = s; }
+        }
+        run_m += tm; run_n += tn;
+        __syncthreads();
+    }
+    // block reduce last (max) / first (min)
+    __shared__ int rl[256], rf[256];
+    rl[tid] = last; rf[tid] = first;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { rl[tid] = max(rl[tid], rl[tid + o]); rf[tid] = min(rf[tid], rf[tid + o]); }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        tstat[b * 4 + 0] = rl[0] >= 0 ? rl[0] : S - 1;   // S-1-argmax(flip(mask)); all-zero mask -> S-1
+        tstat[b * 4 + 1] = rf[0];
+        tstat[b * 4 + 2] = run_n;
+        tstat[b * 4 + 3] = run_m;
+    }
+}
+
+void launch_token_plan(const int64_t* ids, const int64_t* mask, int B, int S, const int* voff, int* img_row, int* pos,
+                       int* tstat, hipStream_t st) {
+    if (B <= 0) return;
+    hipLaunchKernelGGL(token_plan_kernel, dim3(B), dim3(256), 0, st, ids, mask, S, voff, img_row, pos, tstat);
+}
+
+// --------------------------------------------------------------------------------------- embedding
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ ids, const int* __restrict__ img_row,
+                                                    const unsigned short* __restrict__ wte, const float* __restrict__ ev,
+                                                    float* __restrict__ x, int rows, int D, int vocab) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float4* dst = (float4*)(x + (size_t)row * D);
+    const int ir = img_row[row];
+    const int nch = D >> 2;
+    if (ir >= 0) {
+        const float4* src = (const float4*)(ev + (size_t)ir * D);
+        for (int c = lane; c < nch; c += 64) dst[c] = src[c];
+    } else {
+        int64_t id = ids[row];
+        id = id < 0 ? 0 : (id > vocab - 1 ? vocab - 1 : id);
+        const uint2* src = (const uint2*)(wte + (size_t)id * D);
+        for (int c = lane; c < nch; c += 64) {
+            const uint2 u = src[c];
+            dst[c] = make_float4(bf16_bits_to_f32(u.x & 0xFFFF), bf16_bits_to_f32(u.x >> 16),
+                                 bf16_bits_to_f32(u.y & 0xFFFF), bf16_bits_to_f32(u.y >> 16));
+        }
+    }
+}
+
+void launch_embed(const int64_t* ids, const int* img_row, const unsigned short* wte_bf16, const float* ev, float* x,
+                  int rows, int D, int vocab, hipStream_t st) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(embed_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, ids, img_row, wte_bf16, ev, x, rows, D, vocab);
+}
+
+// ------------------------------------------------------------------------------------------ RoPE
+// modeling_phi3_v.py:446-476: freqs = pos * inv_freq; cos/sin scaled by sqrt(1 + ln(s)/ln(orig)); long
+// factors when max(pos)+1 > original_max_position_embeddings.  cs layout: [row][2][half].
+__global__ __launch_bounds__(256) void rope_table_kernel(const int* __restrict__ pos, const int* __restrict__ tstat, int B,
+                                                         int rows, const float* __restrict__ inv_s,
+                                                         const float* __restrict__ inv_l, float scaling, int orig_max,
+                                                         int half, float* __restrict__ cs) {
+    int nv = 0;
+    for (int b = 0; b < B; ++b) nv = max(nv, tstat[b * 4 + 3]);
+    const float* inv = (max(nv, 2) > orig_max) ? inv_l : inv_s;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * half) return;
+    const int row = (int)(i / half), k = (int)(i - (size_t)row * half);
+    const float ang = (float)pos[row] * inv[k];
+    cs[(size_t)row * 2 * half + k] = cosf(ang) * scaling;
+    cs[(size_t)row * 2 * half + half + k] = sinf(ang) * scaling;
+}
+
+void launch_rope_table(const int* pos, const int* tstat, int B, int S, const float* inv_freq_short,
+                       const float* inv_freq_long, float scaling, int orig_max_pos, int half, float* cs, hipStream_t st) {
+    const int rows = B * S;
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(rope_table_kernel, dim3(cdiv((long)rows * half, 256)), dim3(256), 0, st, pos, tstat, B, rows,
+                       inv_freq_short, inv_freq_long, scaling, orig_max_pos, half, cs);
+}
+
+// modeling_phi3_v.py:521-553: q' = q*cos + rotate_half(q)*sin on the half-split convention.
+template <typename OT>
+__global__ __launch_bounds__(256) void rope_split_kernel(const float* __restrict__ qkv, const float* __restrict__ cs,
+                                                         void* __restrict__ out, int D, int heads) {
+    const int row = blockIdx.x;
+    const int hd = D / heads, half = hd >> 1, qh = half >> 2;      // quads per half head
+    const float* src = qkv + (size_t)row * 3 * D;
+    const float4* c4 = (const float4*)(cs + (size_t)row * 2 * half);
+    const float4* s4 = c4 + qh;
+    const int items = 2 * heads * qh;                              // q and k
+    for (int it = threadIdx.x; it < items; it += 256) {
+        const int hsel = it / qh, qd = it - hsel * qh;             // hsel in [0, 2*heads)
+        const size_t base = (size_t)hsel * hd + 4 * qd;
+        const float4 lo = *(const float4*)(src + base), hi = *(const float4*)(src + base + half);
+        const float4 c = c4[qd], s = s4[qd];
+        store4<OT>(out, (size_t)row * 3 * D + base, lo.x * c.x - hi.x * s.x, lo.y * c.y - hi.y * s.y,
+                   lo.z * c.z - hi.z * s.z, lo.w * c.w - hi.w * s.w);
+        store4<OT>(out, (size_t)row * 3 * D + base + half, hi.x * c.x + lo.x * s.x, hi.y * c.y + lo.y * s.y,
+                   hi.z * c.z + lo.z * s.z, hi.w * c.w + lo.w * s.w);
+    }
+    for (int c = threadIdx.x; c < (D >> 2); c += 256) {
+        const float4 v = *(const float4*)(src + 2 * D + 4 * c);
+        store4<OT>(out, (size_t)row * 3 * D + 2 * D + 4 * c, v.x, v.y, v.z, v.w);
+    }
+}
+
+void launch_rope_split(const float* qkv32, const float* cs, void* out, int rows, int D, int heads, int operand_dtype,
+                       hipStream_t st) {
+    if (rows <= 0) return;
+    if ((D / heads) % 8) throw std::runtime_error("rope_split: head_dim must be a multiple of 8");
+    if (operand_dtype == DT_F16) hipLaunchKernelGGL((rope_split_kernel<F16>), dim3(rows), dim3(256), 0, st, qkv32, cs, out, D, heads);
+    else hipLaunchKernelGGL((rope_split_kernel<BF16>), dim3(rows), dim3(256), 0, st, qkv32, cs, out, D, heads);
+}
+
+// ------------------------------------------------------------------------------------- HD gather
+// modeling_phi3_v.py:254-362.  Output row layout per sample: (hc*g2) rows of (wc*g2 patches + sub_GN),
+// then glb_GN, then g2 rows of (g2 patches + sub_GN) of the global crop; a patch row is the 2x2
+// neighbourhood (2i+di, 2j+dj) concatenated as (di, dj, channel).
+template <typename OT>
+__global__ __launch_bounds__(256) void hd_gather_kernel(const float* __restrict__ clipx, const HdSample* __restrict__ smp,
+                                                        int B, int total_rows, int T, int H, int g,
+                                                        const float* __restrict__ sub_gn, const float* __restrict__ glb_gn,
+                                                        void* __restrict__ out) {
+    const int R = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (R >= total_rows) return;
+    int b = 0;
+    while (b + 1 < B && smp[b + 1].voff <= R) ++b;
+    const HdSample sm = smp[b];
+    const int g2 = g / 2;
+    const int local = R - sm.voff;
+    const int wrow = sm.wc * g2 + 1;
+    const int nsub = sm.hc * g2 * wrow;
+    const float* special = nullptr;
+    int crop = 0, pi = 0, pj = 0;
+    if (local < nsub) {
+        const int i = local / wrow, j = local - i * wrow;
+        if (j == sm.wc * g2) special = sub_gn;
+        else { crop = sm.crop0 + 1 + (i / g2) * sm.wc + (j / g2); pi = i % g2; pj = j % g2; }
+    } else if (local == nsub) {
+        special = glb_gn;
+    } else {
+        const int q = local - nsub - 1;
+        const int i = q / (g2 + 1), j = q - i * (g2 + 1);
+        if (j == g2) special = sub_gn;
+        else { crop = sm.crop0; pi = i; pj = j; }
+    }
+    const int nch = H;          // 4H values / 4 per chunk
+    for (int c = lane; c < nch; c += 64) {
+        float4 v;
+        if (special) v = ((const float4*)special)[c];
+        else {
+            const int blk = (4 * c) / H, within = 4 * c - blk * H;
+            const int t = 1 + (2 * pi + (blk >> 1)) * g + (2 * pj + (blk & 1));
+            v = *(const float4*)(clipx + ((size_t)crop * T + t) * H + within);
+        }
+        store4<OT>(out, (size_t)R * 4 * H + 4 * c, v.x, v.y, v.z, v.w);
+    }
+}
+
+void launch_hd_gather(const float* clipx, const HdSample* samples, int B, int total_rows, int T, int H,
+                      const float* sub_gn, const float* glb_gn, void* out, int operand_dtype, hipStream_t st) {
+    if (total_rows <= 0) return;
+    int g = 1;
+    while (g * g + 1 < T) ++g;
+    dim3 gr(cdiv(total_rows, 4)), t(256);
+    if (operand_dtype == DT_F16) hipLaunchKernelGGL((hd_gather_kernel<F16>), gr, t, 0, st, clipx, samples, B, total_rows, T, H, g, sub_gn, glb_gn, out);
+    else hipLaunchKernelGGL((hd_gather_kernel<BF16>), gr, t, 0, st, clipx, samples, B, total_rows, T, H, g, sub_gn, glb_gn, out);
+}
+
+// ------------------------------------------------------------------------------------------- tail
+// rw_model_general_preference.py:376-448 evaluated for the gathered (EOS) row only, all in fp32.
+__global__ __launch_bounds__(256) void gather_norm_kernel(const float* __restrict__ x, const int* __restrict__ tstat, int S,
+                                                          int use_last_pos, const float* __restrict__ w, float eps,
+                                                          float* __restrict__ y, int B, int D) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const int idx = use_last_pos ? S - 1 : tstat[b * 4 + 0];
+    const float* xr = x + ((size_t)b * S + idx) * D;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += xr[c] * xr[c];
+    const float rstd = rsqrtf(wave_sum(s) / D + eps);
+    for (int c = lane; c < D; c += 64) y[(size_t)b * D + c] = w[c] * (xr[c] * rstd);
+}
+
+void launch_gather_norm_rows(const float* x, const int* tstat, int S, int use_last_pos, const float* w, float eps,
+                             float* y, int B, int D, hipStream_t st) {
+    if (B <= 0) return;
+    hipLaunchKernelGGL(gather_norm_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, x, tstat, S, use_last_pos, w, eps, y, B, D);
+}
+
+__global__ __launch_bounds__(256) void rowvec_linear_kernel(const float* __restrict__ x, const unsigned short* __restrict__ W,
+                                                            float* __restrict__ y, int N, int K) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    const float* xr = x + (size_t)b * K;
+    const uint4* wr = (const uint4*)(W + (size_t)n * K);
+    float s = 0.f;
+    for (int c = lane; c < (K >> 3); c += 64) {
+        const uint4 u = wr[c];
+        const float4 a = *(const float4*)(xr + 8 * c), d = *(const float4*)(xr + 8 * c + 4);
+        s += a.x * bf16_bits_to_f32(u.x & 0xFFFF) + a.y * bf16_bits_to_f32(u.x >> 16) +
+             a.z * bf16_bits_to_f32(u.y & 0xFFFF) + a.w * bf16_bits_to_f32(u.y >> 16) +
+             d.x * bf16_bits_to_f32(u.z & 0xFFFF) + d.y * bf16_bits_to_f32(u.z >> 16) +
+             d.z * bf16_bits_to_f32(u.w & 0xFFFF) + d.w * bf16_bits_to_f32(u.w >> 16);
+    }
+    s = wave_sum(s);
+    if (lane == 0) y[(size_t)b * N + n] = s;
+}
+
+void launch_rowvec_linear(const float* x, const unsigned short* W_bf16, float* y, int B, int N, int K, hipStream_t st) {
+    if (B <= 0) return;
+    if (K % 8) throw std::runtime_error("rowvec_linear: K must be a multiple of 8");
+    hipLaunchKernelGGL(rowvec_linear_kernel, dim3(cdiv(N, 4), B), dim3(256), 0, st, x, W_bf16, y, N, K);
+}
+
+// scores over the zero-padded vision rows: rows j >= V_b are all-zero keys -> score 0 (rw_model:381-385
+// with modeling_phi3_v.py:245); they take part in the softmax un-masked.
+__global__ __launch_bounds__(256) void ca_scores_kernel(const float* __restrict__ ev, const float* __restrict__ kq,
+                                                        const int* __restrict__ voff, int Vmax, int D, float scale,
+                                                        float* __restrict__ sc) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    if (j >= Vmax) return;
+    const int vb = voff[b + 1] - voff[b];
+    float s = 0.f;
+    if (j < vb) {
+        const float4* e = (const float4*)(ev + ((size_t)voff[b] + j) * D);
+        const float4* q = (const float4*)(kq + (size_t)b * D);
+        for (int c = lane; c < (D >> 2); c += 64) {
+            const float4 a = e[c], w = q[c];
+            s += a.x * w.x + a.y * w.y + a.z * w.z + a.w * w.w;
+        }
+        s = wave_sum(s) * scale;
+    }
+    if (lane == 0) sc[(size_t)b * Vmax + j] = s;
+}
+
+void launch_ca_scores(const float* ev, const float* kq, const int* voff, int B, int Vmax, int D, float scale, float* sc,
+                      hipStream_t st) {
+    if (B <= 0 || Vmax <= 0) return;
+    hipLaunchKernelGGL(ca_scores_kernel, dim3(cdiv(Vmax, 4), B), dim3(256), 0, st, ev, kq, voff, Vmax, D, scale, sc);
+}
+
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* sh) {
+    v = is_max ? wave_max(v) : wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = is_max ? fmaxf(r, sh[w]) : r + sh[w];
+    return r;
+}
+
+__global__ __launch_bounds__(256) void ca_softmax_kernel(float* __restrict__ sc, int Vmax) {
+    __shared__ float sh[4];
+    float* r = sc + (size_t)blockIdx.x * Vmax;
+    float mx = -INFINITY;
+    for (int j = threadIdx.x; j < Vmax; j += 256) mx = fmaxf(mx, r[j]);
+    mx = block_reduce(mx, true, sh);
+    float s = 0.f;
+    for (int j = threadIdx.x; j < Vmax; j += 256) s += expf(r[j] - mx);
+    s = block_reduce(s, false, sh);
+    const float inv = 1.f / s;
+    for (int j = threadIdx.x; j < Vmax; j += 256) r[j] = expf(r[j] - mx) * inv;
+}
+
+void launch_ca_softmax(float* sc, int B, int Vmax, hipStream_t st) {
+    if (B <= 0 || Vmax <= 0) return;
+    hipLaunchKernelGGL(ca_softmax_kernel, dim3(B), dim3(256), 0, st, sc, Vmax);
+}
+
+__global__ __launch_bounds__(256) void ca_context_kernel(const float* __restrict__ ev, const float* __restrict__ pr,
+                                                         const int* __restrict__ voff, int Vmax, int D,
+                                                         float* __restrict__ ctx) {
+    const int d = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (d >= D) return;
+    const int vb = voff[b + 1] - voff[b];
+    const float* e = ev + (size_t)voff[b] * D + d;
+    const float* p = pr + (size_t)b * Vmax;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int j = 0;
+    for (; j + 4 <= vb; j += 4) {
+        a0 += p[j] * e[(size_t)j * D];
+        a1 += p[j + 1] * e[(size_t)(j + 1) * D];
+        a2 += p[j + 2] * e[(size_t)(j + 2) * D];
+        a3 += p[j + 3] * e[(size_t)(j + 3) * D];
+    }
+    for (; j < vb; ++j) a0 += p[j] * e[(size_t)j * D];
+    ctx[(size_t)b * D + d] = (a0 + a1) + (a2 + a3);
+}
+
+void launch_ca_context(const float* ev, const float* pr, const int* voff, int B, int Vmax, int D, float* ctx,
+                       hipStream_t st) {
+    if (B <= 0) return;
+    hipLaunchKernelGGL(ca_context_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, st, ev, pr, voff, Vmax, D, ctx);
+}
+
+// reward[b][k] = value_head[k] . (attn_o ? RMSNorm_ca(hL + attn_o) : hL)       (rw_model:386,408/427)
+__global__ __launch_bounds__(256) void reward_head_kernel(const float* __restrict__ hL, const float* __restrict__ attn_o,
+                                                          const float* __restrict__ ca_w, float ca_eps,
+                                                          const float* __restrict__ vh, int d, float* __restrict__ out,
+                                                          int D) {
+    __shared__ float sh[4];
+    const int b = blockIdx.x;
+    const float* h = hL + (size_t)b * D;
+    float rstd = 1.f;
+    if (attn_o) {
+        const float* o = attn_o + (size_t)b * D;
+        float s = 0.f;
+        for (int c = threadIdx.x; c < D; c += 256) { const float v = h[c] + o[c]; s += v * v; }
+        s = block_reduce(s, false, sh);
+        rstd = rsqrtf(s / D + ca_eps);
+    }
+    for (int k = 0; k < d; ++k) {
+        float s = 0.f;
+        for (int c = threadIdx.x; c < D; c += 256) {
+            float v = h[c];
+            if (attn_o) v = ca_w[c] * ((v + attn_o[(size_t)b * D + c]) * rstd);
+            s += v * vh[(size_t)k * D + c];
+        }
+        s = block_reduce(s, false, sh);
+        if (threadIdx.x == 0) out[(size_t)b * d + k] = s;
+    }
+}
+
+void launch_reward_head(const float* hL, const float* attn_o, const float* ca_w, float ca_eps, const float* vh, int d,
+                        float* out, int B, int D, hipStream_t st) {
+    if (B <= 0) return;
+    hipLaunchKernelGGL(reward_head_kernel, dim3(B), dim3(256), 0, st, hL, attn_o, ca_w, ca_eps, vh, d, out, D);
+}
+
+// --------------------------------------------------------------------------------------- weights
+// Bit-identical to llava_reward_amd.synth.gen_tensor (splitmix64 counter hash, one fp32 multiply).
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void synth_fill_kernel(float* __restrict__ out, size_t n, uint64_t tseed, float scale,
+                                                         float offset, int has_offset, int bf16_round) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint64_t h = splitmix64(tseed + i);
+        const int c = (int)(h >> 40) - (1 << 23);
+        float v = __fmul_rn((float)c, scale);
+        if (has_offset) v = __fadd_rn(v, offset);
+        if (bf16_round) {
+            unsigned u = __builtin_bit_cast(unsigned, v);
+            u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+            v = __builtin_bit_cast(float, u);
+        }
+        out[i] = v;
+    }
+}
+
+void launch_synth_fill(float* out, size_t n, uint64_t tseed, float scale, float offset, int bf16_round, hipStream_t st) {
+    if (!n) return;
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(synth_fill_kernel, dim3(grid), dim3(256), 0, st, out, n, tseed, scale, offset, offset != 0.f ? 1 : 0, bf16_round);
+}
+
+__device__ __forceinline__ void store_elem(void* dst, size_t i, float v, int dt) {
+    if (dt == DT_F32) ((float*)dst)[i] = v;
+    else if (dt == DT_F16) ((unsigned short*)dst)[i] = Op<F16>::from_f32(v);
+    else ((unsigned short*)dst)[i] = Op<BF16>::from_f32(v);
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, void* __restrict__ dst, int rows, int cols,
+                                                   int ld_dst, int cols_dst, int dst_dtype, int mode) {
+    const size_t total = (size_t)rows * cols_dst;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / cols_dst), c = (int)(i - (size_t)r * cols_dst);
+        const float v = c < cols ? src[(size_t)r * cols + c] : 0.f;
+        size_t o;
+        if (mode == PACK_SWIGLU) {
+            const int I = rows >> 1;
+            const int g = r < I ? r : r - I;
+            const int rr = (g >> 5) * 64 + (r < I ? 0 : 32) + (g & 31);
+            o = (size_t)rr * ld_dst + c;
+        } else if (mode == PACK_TRANSPOSE) {
+            o = (size_t)c * ld_dst + r;
+        } else {
+            o = (size_t)r * ld_dst + c;
+        }
+        store_elem(dst, o, v, dst_dtype);
+    }
+}
+
+void launch_pack(const float* src, void* dst, int rows, int cols, int ld_dst, int cols_dst, int dst_dtype, int mode,
+                 hipStream_t st) {
+    const size_t total = (size_t)rows * cols_dst;
+    if (!total) return;
+    if (mode == PACK_SWIGLU && ((rows >> 1) % 32)) throw std::runtime_error("pack: SwiGLU interleave needs I % 32 == 0");
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
+    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, st, src, dst, rows, cols, ld_dst, cols_dst, dst_dtype, mode);
+}
+
+__global__ __launch_bounds__(256) void cvt_to_f32_kernel(const void* __restrict__ src, int dt, float* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v;
+        if (dt == DT_F32) v = ((const float*)src)[i];
+        else if (dt == DT_F16) v = Op<F16>::to_f32(((const unsigned short*)src)[i]);
+        else v = Op<BF16>::to_f32(((const unsigned short*)src)[i]);
+        dst[i] = v;
+    }
+}
+
+void launch_cvt_to_f32(const void* src, int src_dtype, float* dst, size_t n, hipStream_t st) {
+    if (!n) return;
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 16384);
+    hipLaunchKernelGGL(cvt_to_f32_kernel, dim3(grid), dim3(256), 0, st, src, src_dtype, dst, n);
+}
+
+}  // namespace lr

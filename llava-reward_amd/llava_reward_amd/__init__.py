@@ -5,5 +5,7 @@ Drop-in surface (mirrors eval/reward_adaptor_loader.py of the reference):
     ``custom_forward`` runs the hand-written HIP path through the C-ABI in ``include/llava_reward_hip.h``.
 """
 from . import synth  # noqa: F401
+from .model import RewardModel  # noqa: F401
+from .reward_adaptor_loader import inference_process_phi3v, load_reward_adaptor, preference_compute  # noqa: F401
 
-__all__ = ["synth"]
+__all__ = ["synth", "RewardModel", "load_reward_adaptor", "inference_process_phi3v", "preference_compute"]

@@ -1,0 +1,136 @@
+"""Readers for the on-disk layout `load_reward_adaptor` consumes:
+
+    <pretrain>/config.json + *.safetensors         HF base checkpoint (bf16)
+    <pm_path>/reward_config.yaml                   4 keys (utils/deepspeed.py:402-404)
+    <pm_path>/pytorch_model.bin                    value_head / W_q / W_k / W_v / ca_layernorm / img_projection
+    <pm_path>/lora/adapter_config.json + adapter_model.{bin,safetensors}   PEFT LoRA adapter
+
+LoRA is merged on the host in fp32, W' = W + (alpha/r) * B @ A, and rounded once when the engine
+packs it into its operand dtype (the reference runs the adapter un-merged in bf16,
+eval/reward_adaptor_loader.py:44-45; merged == un-merged in exact arithmetic).
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+import re
+from typing import Dict, Tuple
+
+import torch
+
+from .synth import ClipConfig, RewardConfig
+
+
+def config_from_hf(path: str, reward_cfg: dict) -> RewardConfig:
+    """Phi3VConfig fields (configuration_phi3_v.py:119-145) + reward_config.yaml -> RewardConfig."""
+    with open(os.path.join(path, "config.json")) as f:
+        c = json.load(f)
+    ip = c.get("img_processor") or {}
+    if ip.get("name", "clip_vision_model") != "clip_vision_model":
+        raise NotImplementedError(f"img_processor = {ip}, not implemented")       # modeling_phi3_v.py:151
+    el = c.get("embd_layer") or {}
+    if isinstance(el, dict) and el:
+        if el.get("hd_transform_order", "sub_glb") != "sub_glb":
+            raise AssertionError(f"hd_transform_order `{el.get('hd_transform_order')}` not implemented")   # :259
+        if el.get("projection_cls", "mlp") != "mlp" or not el.get("use_hd_transform", True):
+            raise NotImplementedError("only the HD-transform MLP projector is implemented")
+    rs = c.get("rope_scaling")
+    if not rs or rs.get("type", rs.get("rope_type")) not in ("su", "longrope"):
+        raise ValueError("rope_scaling of type 'su' with short_factor/long_factor is required")
+    clip = ClipConfig(hidden=ip.get("clip_hidden", 1024), heads=ip.get("clip_heads", 16), mlp=ip.get("clip_mlp", 4096),
+                      layers_used=ip.get("clip_layers_used", 23))
+    return RewardConfig(
+        vocab_size=c["vocab_size"], hidden=c["hidden_size"], intermediate=c["intermediate_size"],
+        layers=c["num_hidden_layers"], heads=c["num_attention_heads"], rms_eps=c.get("rms_norm_eps", 1e-5),
+        rope_theta=c.get("rope_theta", 10000.0), max_pos=c.get("max_position_embeddings", 4096),
+        orig_max_pos=c.get("original_max_position_embeddings", 4096),
+        short_factor=tuple(rs["short_factor"]), long_factor=tuple(rs["long_factor"]), clip=clip,
+        is_general_preference=bool(reward_cfg["is_general_preference"]),
+        add_cross_attention=bool(reward_cfg["add_cross_attention"]),
+        value_head_dim=int(reward_cfg["value_head_dim"]),
+        general_preference_tau=float(reward_cfg["general_preference_tau"]))
+
+
+def read_base_weights(path: str, wanted) -> Dict[str, torch.Tensor]:
+    """Read the tensors named in `wanted` from *.safetensors (or pytorch_model*.bin) under `path`."""
+    wanted = set(wanted)
+    out: Dict[str, torch.Tensor] = {}
+    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    if files:
+        from safetensors import safe_open
+        for fn in files:
+            with safe_open(fn, framework="pt", device="cpu") as f:
+                for k in f.keys():
+                    if k in wanted:
+                        out[k] = f.get_tensor(k)
+    else:
+        for fn in sorted(glob.glob(os.path.join(path, "pytorch_model*.bin"))):
+            sd = torch.load(fn, map_location="cpu")
+            out.update({k: v for k, v in sd.items() if k in wanted})
+    missing = wanted - set(out)
+    if missing:
+        raise FileNotFoundError(f"{path}: base checkpoint lacks {sorted(missing)[:4]} (+{max(0, len(missing) - 4)} more)")
+    return out
+
+
+_LORA_RE = re.compile(r"^(?:base_model\.model\.)?(.+)\.lora_([AB])(?:\.[^.]+)?\.weight$")
+
+
+def read_lora(lora_dir: str) -> Tuple[Dict[str, Tuple[torch.Tensor, torch.Tensor]], float]:
+    """-> ({module name: (A [r,in], B [out,r])}, alpha/r)."""
+    with open(os.path.join(lora_dir, "adapter_config.json")) as f:
+        ac = json.load(f)
+    scale = float(ac["lora_alpha"]) / float(ac["r"])
+    st = os.path.join(lora_dir, "adapter_model.safetensors")
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+        sd = load_file(st)
+    else:
+        sd = torch.load(os.path.join(lora_dir, "adapter_model.bin"), map_location="cpu")
+    pairs: Dict[str, dict] = {}
+    for k, v in sd.items():
+        m = _LORA_RE.match(k)
+        if m:
+            pairs.setdefault(m.group(1), {})[m.group(2)] = v
+    out = {}
+    for mod, ab in pairs.items():
+        if "A" not in ab or "B" not in ab:
+            raise KeyError(f"LoRA adapter: incomplete pair for {mod}")
+        out[mod] = (ab["A"], ab["B"])
+    return out, scale
+
+
+def merge_lora(weights: Dict[str, torch.Tensor], lora: Dict[str, Tuple[torch.Tensor, torch.Tensor]], scale: float) -> int:
+    """In place: weights[mod + '.weight'] += scale * B @ A (fp32).  Returns the number of merged modules."""
+    n = 0
+    for mod, (A, B) in lora.items():
+        key = mod + ".weight"
+        if key not in weights:
+            continue                 # adapter targets outside the scoring path (e.g. CLIP layer 24)
+        w = weights[key].float()
+        weights[key] = w + scale * (B.float() @ A.float())
+        n += 1
+    return n
+
+
+def read_heads(pm_path: str, cfg: RewardConfig, ft_projector: bool) -> Dict[str, torch.Tensor]:
+    """pytorch_model.bin keys filtered by substring exactly as eval/reward_adaptor_loader.py:46-60."""
+    sd = torch.load(os.path.join(pm_path, "pytorch_model.bin"), map_location="cpu")
+    out = {}
+
+    def pick(sub, dst_prefix, nparts=1):
+        found = {".".join(k.split(".")[-nparts:]): v for k, v in sd.items() if sub in k}
+        for tail, v in found.items():
+            out[dst_prefix + tail] = v
+        return found
+
+    if not pick("value_head", "value_head."):
+        raise KeyError("pytorch_model.bin has no value_head")
+    if cfg.add_cross_attention:
+        for nm in ("W_q", "W_k", "W_v", "ca_layernorm"):
+            if not pick(nm, nm + "."):
+                raise KeyError(f"pytorch_model.bin has no {nm}")
+    if ft_projector:
+        pick("img_projection", "model.vision_embed_tokens.img_projection.", nparts=2)
+    return out

@@ -1,0 +1,164 @@
+"""Python handle on the HIP scoring engine.  PyTorch is used only for device memory and streams."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Iterable, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .synth import RewardConfig
+
+_DT = {"bf16": L.LR_DT_BF16, "f16": L.LR_DT_F16, "fp16": L.LR_DT_F16}
+
+
+def rope_inv_freq(factors, head_dim: int, theta: float) -> torch.Tensor:
+    """1 / (ext_factors * base ** (arange(0, dim, 2) / dim)) with the reference's exact torch ops
+    (modeling_phi3_v.py:454-455), so the device table matches the oracle bit for bit."""
+    ext = torch.tensor(list(factors), dtype=torch.float32)
+    inv_shape = torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim
+    return 1.0 / (ext * theta ** inv_shape)
+
+
+def make_desc(cfg: RewardConfig, max_batch: int, max_seq: int, max_crops: int, operand_dtype: str) -> L.ModelDesc:
+    d = L.ModelDesc()
+    d.struct_size = C.sizeof(L.ModelDesc)
+    d.vocab_size, d.hidden, d.intermediate = cfg.vocab_size, cfg.hidden, cfg.intermediate
+    d.layers, d.heads = cfg.layers, cfg.heads
+    d.rms_eps = cfg.rms_eps
+    d.orig_max_pos = cfg.orig_max_pos
+    scale = cfg.max_pos / cfg.orig_max_pos
+    d.rope_scaling = 1.0 if scale <= 1.0 else math.sqrt(1 + math.log(scale) / math.log(cfg.orig_max_pos))
+    half = cfg.head_dim // 2
+    if half > L.LR_MAX_HALF_HEAD:
+        raise ValueError("head_dim too large")
+    for dst, fac in ((d.inv_freq_short, cfg.short_factor), (d.inv_freq_long, cfg.long_factor)):
+        inv = rope_inv_freq(fac, cfg.head_dim, cfg.rope_theta)
+        for i in range(half):
+            dst[i] = float(inv[i])
+    c = cfg.clip
+    d.clip_hidden, d.clip_heads, d.clip_mlp, d.clip_layers = c.hidden, c.heads, c.mlp, c.layers_used
+    d.clip_image, d.clip_patch, d.clip_ln_eps = c.image, c.patch, c.ln_eps
+    d.value_head_dim = cfg.value_head_dim
+    d.add_cross_attention = int(bool(cfg.add_cross_attention))
+    d.ca_eps = cfg.ca_eps
+    d.max_batch, d.max_seq, d.max_crops = max_batch, max_seq, max_crops
+    d.operand_dtype = _DT[operand_dtype]
+    return d
+
+
+class RewardEngine:
+    """Owns one lr_handle (one GPU).  Not thread-safe; forward() enqueues on the current torch stream."""
+
+    def __init__(self, cfg: RewardConfig, device: int = 0, max_batch: int = 32, max_seq: int = 2816,
+                 max_crops: int = 17, operand_dtype: str = "f16"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("RewardEngine needs a HIP device (torch.cuda.is_available() is False); "
+                               "the scoring path has no CPU fallback")
+        self.lib = L.load()
+        self.cfg = cfg
+        self.device = int(device)
+        self.operand_dtype = operand_dtype
+        self.max_batch, self.max_seq, self.max_crops = max_batch, max_seq, max_crops
+        torch.cuda.set_device(self.device)
+        torch.zeros(1, device=f"cuda:{self.device}")       # make sure torch owns a context on this device
+        self._desc = make_desc(cfg, max_batch, max_seq, max_crops, operand_dtype)
+        h = C.c_void_p()
+        L.check(self.lib, self.lib.lr_create(C.byref(self._desc), self.device, C.byref(h)), None, "lr_create")
+        self.h = h
+        self.finalized = False
+
+    # ------------------------------------------------------------------ weights
+    def weight_names(self):
+        n = self.lib.lr_num_weights(self.h)
+        return [self.lib.lr_weight_name(self.h, i).decode() for i in range(n)]
+
+    def upload(self, name: str, t) -> None:
+        if isinstance(t, np.ndarray):
+            t = torch.from_numpy(np.ascontiguousarray(t))
+        t = t.detach()
+        if t.dtype == torch.float32:
+            dt = L.LR_DT_F32
+        elif t.dtype == torch.bfloat16:
+            dt = L.LR_DT_BF16
+        elif t.dtype == torch.float16:
+            dt = L.LR_DT_F16
+        else:
+            t, dt = t.float(), L.LR_DT_F32
+        t = t.contiguous()
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        L.check(self.lib, self.lib.lr_upload_weight(self.h, name.encode(), C.c_void_p(t.data_ptr()), shape, t.dim(), dt,
+                                                    1 if t.is_cuda else 0), self.h, f"lr_upload_weight({name})")
+
+    def load_state_dict(self, sd: Dict[str, "torch.Tensor"], strict: bool = True) -> None:
+        names = set(self.weight_names())
+        for k, v in sd.items():
+            if k in names:
+                self.upload(k, v)
+                names.discard(k)
+        if strict and names:
+            raise KeyError(f"missing weights: {sorted(names)[:8]}{' ...' if len(names) > 8 else ''}")
+
+    def synth_weights(self, seed: int) -> None:
+        L.check(self.lib, self.lib.lr_synth_weights(self.h, C.c_uint64(seed)), self.h, "lr_synth_weights")
+
+    def finalize(self) -> None:
+        L.check(self.lib, self.lib.lr_finalize(self.h), self.h, "lr_finalize")
+        self.finalized = True
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, pixel_values: torch.Tensor,
+                image_sizes, training: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        dev = torch.device("cuda", self.device)
+        ids = input_ids.to(dev, torch.int64).contiguous()
+        mask = attention_mask.to(dev, torch.int64).contiguous()
+        if pixel_values.dtype == torch.bfloat16:
+            pdt = L.LR_DT_BF16
+        else:
+            pixel_values, pdt = pixel_values.to(torch.float32), L.LR_DT_F32
+        pix = pixel_values.to(dev).contiguous()
+        sizes = torch.as_tensor(image_sizes).to("cpu", torch.int64).contiguous()
+        B, S = ids.shape
+        if pix.dim() != 5 or pix.shape[0] != B:
+            raise ValueError("pixel_values must be [B, crops, 3, H, W]")
+        if out is None:
+            out = torch.empty(B, self.cfg.value_head_dim, device=dev, dtype=torch.float32)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = self.lib.lr_forward(self.h, C.c_void_p(ids.data_ptr()), C.c_void_p(mask.data_ptr()), C.c_void_p(pix.data_ptr()),
+                                 pdt, C.cast(sizes.data_ptr(), C.POINTER(C.c_int64)), B, S, pix.shape[1],
+                                 L.LR_FWD_TRAINING_LAST_TOKEN if training else 0, C.c_void_p(out.data_ptr()),
+                                 C.c_void_p(stream))
+        L.check(self.lib, rc, self.h, "lr_forward")
+        # keep inputs alive until the stream has consumed them
+        for t in (ids, mask, pix):
+            t.record_stream(torch.cuda.current_stream(dev))
+        return out
+
+    def read_tap(self, name: str, numel: int) -> np.ndarray:
+        buf = np.empty(numel, dtype=np.float32)
+        n = C.c_size_t(0)
+        L.check(self.lib, self.lib.lr_read_tap(self.h, name.encode(), buf.ctypes.data_as(C.c_void_p), numel, C.byref(n)),
+                self.h, "lr_read_tap")
+        return buf[: n.value]
+
+    def set_layer_limits(self, n_clip: int = -1, n_layers: int = -1) -> None:
+        self.lib.lr_set_layer_limits(self.h, n_clip, n_layers)
+
+    def set_gemm_tile(self, tile: int) -> None:
+        L.check(self.lib, self.lib.lr_set_gemm_tile(self.h, tile), self.h, "lr_set_gemm_tile")
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.lr_workspace_bytes(self.h))
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.lr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

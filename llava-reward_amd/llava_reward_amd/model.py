@@ -1,0 +1,108 @@
+"""The object that stands where the reference's CustomRewardModel stands
+(llava_reward/models/rw_model_general_preference.py:290-448): `.to(device)`, `.eval()`,
+`.model_type`, and `custom_forward(...) -> (reward, outputs | None)`.
+
+Weights live on the host until `.to('cuda')`, which creates the HIP engine on that GPU (the
+reference's `load_reward_adaptor` also returns a CPU model that the caller moves).
+Deviations, on purpose: rewards come back in fp32 (the reference returns the model dtype, bf16;
+SURVEY.md §7 shows bf16 rounding alone costs up to 2e-3); `outputs` for return_output=True holds
+only the tensors the engine keeps (final hidden row + projected vision tokens)."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .synth import RewardConfig
+
+
+class RewardModel:
+    model_type = "phi3v"
+
+    def __init__(self, cfg: RewardConfig, weights: Optional[Dict[str, torch.Tensor]] = None, synth_seed: Optional[int] = None,
+                 max_batch: int = 32, max_seq: int = 2816, max_crops: int = 17, operand_dtype: str = "f16",
+                 layer_id: int = 32, mean_hidden_state=None):
+        if weights is None and synth_seed is None:
+            raise ValueError("RewardModel needs weights or a synth_seed")
+        if mean_hidden_state:
+            raise NotImplementedError("mean_hidden_state pooling (rw_model:398-406) is not on the accelerated path yet")
+        if layer_id not in (32, cfg.layers):
+            raise NotImplementedError("only the last-layer hidden state (layer_id == 32) is implemented")
+        self.config = cfg
+        self._weights = weights
+        self._synth_seed = synth_seed
+        self._opts = dict(max_batch=max_batch, max_seq=max_seq, max_crops=max_crops, operand_dtype=operand_dtype)
+        self.engine = None
+        self.training = False
+        self.device = torch.device("cpu")
+        self.is_general_preference = cfg.is_general_preference
+        self.add_cross_attention = cfg.add_cross_attention
+        self.value_head_dim = cfg.value_head_dim
+
+    # -- nn.Module-like surface used by the reference's callers (eval/simple_inference.py:17-18) --
+    def to(self, device):
+        device = torch.device(device)
+        if device.type == "cpu":
+            return self
+        if device.type != "cuda":
+            raise ValueError(f"unsupported device {device}")
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if self.engine is not None and self.engine.device == idx:
+            return self
+        from .engine import RewardEngine
+        eng = RewardEngine(self.config, device=idx, **self._opts)
+        if self._weights is not None:
+            eng.load_state_dict(self._weights, strict=True)
+        else:
+            eng.synth_weights(self._synth_seed)
+        eng.finalize()
+        if self.engine is not None:
+            self.engine.close()
+        self.engine = eng
+        self.device = torch.device("cuda", idx)
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", device if device is not None else torch.cuda.current_device()))
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True):
+        self.training = bool(mode)
+        return self
+
+    def custom_forward(self, input_ids=None, attention_mask=None, pixel_values=None, image_sizes=None,
+                       return_output=False, inputs_batch=None):
+        """rw_model_general_preference.py:334-448, phi3v branch (positional order kept:
+        eval/batch_inference_rm_phi.py:93)."""
+        if self.engine is None:
+            raise RuntimeError("custom_forward: model is on CPU; call model.to('cuda') first "
+                               "(the scoring path has no CPU fallback)")
+        if inputs_batch is not None and input_ids is None:
+            input_ids = inputs_batch["input_ids"]
+            attention_mask = inputs_batch["attention_mask"]
+            pixel_values = inputs_batch["pixel_values"]
+            image_sizes = inputs_batch["image_sizes"]
+        if pixel_values is None or image_sizes is None:
+            # the reference cannot run text-only rows either (modeling_phi3_v.py:252 unbound local)
+            raise UnboundLocalError("img_token_batch_embedding: every row must carry an image")
+        if input_ids.dim() == 3:
+            input_ids = input_ids.squeeze(1)
+        n_slots = (input_ids < 0).sum(dim=1).cpu()
+        g2 = self.config.clip.grid // 2
+        sz = torch.as_tensor(image_sizes).cpu().long()
+        img = self.config.clip.image
+        expect = (sz[:, 0] // img) * g2 * ((sz[:, 1] // img) * g2 + 1) + 1 + g2 * (g2 + 1)
+        if not torch.equal(n_slots.long(), expect):
+            raise RuntimeError(f"shape mismatch: image slots per row {n_slots.tolist()} != projected image tokens "
+                               f"{expect.tolist()} (modeling_phi3_v.py:247 index_put)")
+        reward = self.engine.forward(input_ids, attention_mask, pixel_values, sz, training=self.training)
+        if return_output:
+            B, D = reward.shape[0], self.config.hidden
+            hl = torch.from_numpy(self.engine.read_tap("hL", B * D).reshape(B, D).copy())
+            return reward, {"last_hidden_state_at_reward_token": hl}
+        return reward, None
+
+    __call__ = custom_forward

@@ -1,0 +1,87 @@
+"""Drop-in counterparts of the reference's eval/reward_adaptor_loader.py callables:
+load_reward_adaptor (:24-156), inference_process_phi3v (:158-173), preference_compute (:174-181).
+Same names, argument order, `args` mutation and return conventions."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import yaml
+
+from . import checkpoint as ckpt
+from .model import RewardModel
+from .synth import weight_specs
+
+
+class UnknownModelType(UnboundLocalError, ValueError):
+    """The reference falls off its if/elif chain and dies with UnboundLocalError (:156)."""
+
+
+def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=False):
+    with open(reward_config_path) as f:
+        reward_cfg = yaml.safe_load(f)
+    args.is_general_preference = reward_cfg["is_general_preference"]
+    args.add_cross_attention = reward_cfg["add_cross_attention"]
+    args.value_head_dim = reward_cfg["value_head_dim"]
+    args.general_preference_tau = reward_cfg["general_preference_tau"]
+    if model_type == "phi3v":
+        if not os.path.isdir(args.pretrain):
+            raise FileNotFoundError(f"args.pretrain={args.pretrain!r} must be a local checkpoint directory "
+                                    "(config.json + *.safetensors); hub download is not available offline")
+        cfg = ckpt.config_from_hf(args.pretrain, reward_cfg)
+        names = [n for n, *_ in weight_specs(cfg)]
+        head_names = {n for n in names if n.split(".")[0] in ("value_head", "W_q", "W_k", "W_v", "ca_layernorm")}
+        weights = ckpt.read_base_weights(args.pretrain, [n for n in names if n not in head_names])
+        lora_dir = os.path.join(args.pm_path, "lora")
+        lora, scale = ckpt.read_lora(lora_dir)
+        ckpt.merge_lora(weights, lora, scale)
+        heads = ckpt.read_heads(args.pm_path, cfg, getattr(args, "ft_projector", False))
+        weights.update(heads)
+        model = RewardModel(cfg, weights=weights,
+                            max_batch=getattr(args, "max_batch", 32), max_seq=getattr(args, "max_seq", 2816),
+                            max_crops=getattr(args, "max_crops", 17),
+                            operand_dtype=getattr(args, "operand_dtype", "f16"))
+        model.model_type = "phi3v"
+        if load_tokenizer:
+            from transformers import AutoProcessor
+            processor = AutoProcessor.from_pretrained(args.pretrain, cache_dir=getattr(args, "cache_dir", None),
+                                                      padding_side="left", trust_remote_code=True, num_crops=16,
+                                                      model_max_length=131072)     # utils/utils.py:19-32
+            tokenizer = processor.tokenizer
+            tokenizer.padding_side = "left"
+            if tokenizer.pad_token is None:
+                tokenizer.pad_token = tokenizer.eos_token
+                tokenizer.pad_token_id = tokenizer.eos_token_id
+            tokenizer.truncation_side = "right"
+    elif model_type in ("qwen", "llava"):
+        raise NotImplementedError(f"model_type={model_type!r}: the Qwen2.5-VL / LLaVA-1.6 backbones are SURVEY.md §8f "
+                                  "'next' rows; only 'phi3v' runs on the HIP path in this round")
+    else:
+        raise UnknownModelType(f"local variable 'model' referenced before assignment (model_type={model_type!r})")
+    if load_tokenizer:
+        return args, model, processor, tokenizer
+    return args, model
+
+
+def inference_process_phi3v(args, processor, tokenizer, img_dir_list, caption, device="cuda"):
+    from PIL import Image
+    img_list = [Image.open(d).convert("RGB") for d in img_dir_list]
+    prompt_messages = {"role": "user", "content": f"<|image_1|>\n{caption}"}
+    prompt = tokenizer.apply_chat_template([prompt_messages], tokenize=False, add_generation_prompt=True)[:-22] + tokenizer.eos_token
+    img_inputs = []
+    for img in img_list:
+        img_input = processor(text=prompt, images=[img], return_tensors="pt", padding=True, truncation=True)
+        for k in img_input:
+            img_input[k] = img_input[k].to(device)
+        img_inputs.append(img_input)
+    return img_inputs
+
+
+def preference_compute(args, chosen_rewards, reject_rewards):
+    if args.is_general_preference and args.value_head_dim == 2:
+        gpm_product = chosen_rewards[:, 0] * reject_rewards[:, 1] - chosen_rewards[:, 1] * reject_rewards[:, 0]
+        prob = torch.sigmoid(gpm_product / args.general_preference_tau)
+    else:
+        prob = torch.sigmoid((chosen_rewards - reject_rewards) / args.general_preference_tau).squeeze(-1)
+    return prob.float().cpu().numpy()

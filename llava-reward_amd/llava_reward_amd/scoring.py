@@ -1,0 +1,116 @@
+"""Batch scoring loop and its multi-GPU sharding.
+
+Counterpart of the reference's eval/batch_inference_rm_phi.py:79-152 (pairwise and non-pairwise
+modes), which runs on one GPU (DistributedSampler(num_replicas=1, rank=0), :50-57).  Here rows are
+independent units (custom_forward has no cross-sample op), so a global batch is cut into contiguous
+per-rank shards and the only collective is one all-gather of the fp32 rewards per batch
+(SURVEY.md §8e).  A preference pair's chosen and rejected rows go to the same rank.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .reward_adaptor_loader import preference_compute
+
+
+def world() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_rows(n: int, rank: int, world_size: int) -> slice:
+    """Contiguous shard [lo, hi) of n rows for `rank`; sizes differ by at most one and concatenating the
+    shards in rank order restores the input order."""
+    base, rem = divmod(n, world_size)
+    lo = rank * base + min(rank, rem)
+    return slice(lo, lo + base + (1 if rank < rem else 0))
+
+
+def gather_rewards(local: torch.Tensor, n_total: Optional[int] = None) -> torch.Tensor:
+    """All-gather per-rank rewards [n_r, d] -> [n_total, d] on every rank (RCCL over xGMI on GPUs,
+    gloo on CPU tensors).  Ragged shards are padded to the largest shard for the collective."""
+    rank, ws = world()
+    if ws == 1:
+        return local
+    n_local = local.shape[0]
+    if n_total is None:
+        out = torch.empty((ws * n_local,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous())
+        return out
+    sizes = [shard_rows(n_total, r, ws) for r in range(ws)]
+    cap = max(s.stop - s.start for s in sizes)
+    buf = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    buf[:n_local] = local
+    outs = [torch.empty_like(buf) for _ in range(ws)]
+    dist.all_gather(outs, buf)
+    return torch.cat([o[: s.stop - s.start] for o, s in zip(outs, sizes)], dim=0)
+
+
+def _squeeze(b: Dict[str, torch.Tensor], rows: slice, device) -> Tuple[torch.Tensor, ...]:
+    def f(k):
+        t = b[k]
+        t = t.squeeze(1) if t.dim() > (2 if k != "pixel_values" else 5) else t      # collate adds a dim (:82-90)
+        return t[rows].to(device)
+    return f("input_ids"), f("attention_mask"), f("pixel_values"), f("image_sizes")
+
+
+@torch.no_grad()
+def score_pairwise(model, args, batches: Iterable, device=None) -> Dict[str, object]:
+    """batches yields (inputs_c, inputs_r, c_rates, r_rates) as the reference's DataLoader does.
+    Returns the quantities the reference prints: prob_mean, proportion (prob > 0.5), proportion w/o ties."""
+    rank, ws = world()
+    device = device or model.device
+    all_probs: List[float] = []
+    chosen_list: List[float] = []
+    reject_list: List[float] = []
+    for inputs_c, inputs_r, *_ in batches:
+        n = inputs_c["input_ids"].shape[0]
+        rows = shard_rows(n, rank, ws)
+        c, _ = model.custom_forward(*_squeeze(inputs_c, rows, device))
+        r, _ = model.custom_forward(*_squeeze(inputs_r, rows, device))
+        c, r = gather_rewards(c, n), gather_rewards(r, n)
+        if not args.is_general_preference:
+            chosen_list.extend(c.squeeze(-1).tolist())
+            reject_list.extend(r.squeeze(-1).tolist())
+        all_probs.extend(preference_compute(args, c, r).tolist())
+    total = len(all_probs)
+    gt = sum(1 for x in all_probs if x > 0.5)
+    ties = sum(1 for x in all_probs if x == 0.5)
+    return {"prob_mean": sum(all_probs) / max(total, 1), "proportion": gt / max(total, 1),
+            "proportion_wo_tie": gt / (total - ties) if total - ties else None, "probs": all_probs,
+            "chosen_rewards": chosen_list, "reject_rewards": reject_list}
+
+
+@torch.no_grad()
+def score_single(model, args, batches: Iterable, cls_based: bool = False, device=None) -> Dict[str, object]:
+    """Non-pairwise mode (:123-152): batches yields (inputs, labels)."""
+    if args.is_general_preference:
+        raise ValueError("General preference loss-based model is not supported for single image evaluation. "
+                         "Please use BT model instead.")
+    rank, ws = world()
+    device = device or model.device
+    rewards: List[float] = []
+    labels: List[int] = []
+    for inputs, lab in batches:
+        n = inputs["input_ids"].shape[0]
+        rows = shard_rows(n, rank, ws)
+        r, _ = model.custom_forward(*_squeeze(inputs, rows, device))
+        rewards.extend(gather_rewards(r, n).squeeze(-1).tolist())
+        labels.extend(torch.as_tensor(lab).tolist())
+    out: Dict[str, object] = {"rewards": rewards, "labels": labels}
+    if cls_based:
+        pred = (1.0 / (1.0 + np.exp(-np.asarray(rewards))) >= 0.5).astype(np.int64)
+        lab = np.asarray(labels).astype(np.int64)
+        tp = int(((pred == 1) & (lab == 1)).sum())
+        fp = int(((pred == 1) & (lab == 0)).sum())
+        fn = int(((pred == 0) & (lab == 1)).sum())
+        out["accuracy"] = float((pred == lab).mean()) if len(lab) else None
+        out["recall"] = tp / (tp + fn) if tp + fn else 0.0
+        prec = tp / (tp + fp) if tp + fp else 0.0
+        out["f1"] = 2 * prec * out["recall"] / (prec + out["recall"]) if prec + out["recall"] else 0.0
+    return out

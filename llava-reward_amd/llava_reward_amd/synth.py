@@ -313,7 +313,7 @@ def synth_pixels(seed: int, name: str, shape: Tuple[int, ...]) -> np.ndarray:
 
 
 def synth_batch(cfg: RewardConfig, seed: int, caption_lens: List[int], grids, max_crops: int = None,
-                pad_token_id: int = None):
+                pad_token_id: int = None, with_pixels: bool = True):
     """Token/mask/pixel tensors shaped like collate_fn output (reward_dataset.py:137-202, Appendix B
     of SURVEY.md): each row is [bos, <|user|>, \\n, -1 x V_b, \\n, caption..., eos]; rows are LEFT-padded
     with pad_token_id / mask 0 to the longest row (datasets/utils.py:5-13).
@@ -345,8 +345,10 @@ def synth_batch(cfg: RewardConfig, seed: int, caption_lens: List[int], grids, ma
     for b, row in enumerate(rows):
         ids[b, S - len(row):] = row
         mask[b, S - len(row):] = 1
-    pix = np.zeros((batch, C, 3, 336, 336), dtype=np.float32)
-    for b in range(batch):
-        pix[b, :ncrops[b]] = synth_pixels(seed, f"pixel_values.{b}", (ncrops[b], 3, 336, 336))
+    pix = None
+    if with_pixels:
+        pix = np.zeros((batch, C, 3, 336, 336), dtype=np.float32)
+        for b in range(batch):
+            pix[b, :ncrops[b]] = synth_pixels(seed, f"pixel_values.{b}", (ncrops[b], 3, 336, 336))
     sizes = np.array([[336 * hc, 336 * wc] for hc, wc in grids], dtype=np.int64)
     return dict(input_ids=ids, attention_mask=mask, pixel_values=pix, image_sizes=sizes)

@@ -1,0 +1,174 @@
+"""Per-kernel parity on a real MI355X: every HIP kernel, called through the C ABI, against a plain
+torch fp32 computation of the same op on the SAME (already rounded) operands.
+
+Tolerances: GEMM/attention accumulate in fp32 like the checker, so fp32-output results must agree
+to 2e-5 relative to the output scale (summation order only); operand-dtype outputs additionally
+carry one rounding of the output (bf16: 2^-8 relative, f16: 2^-11)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from llava_reward_amd import _lib as L
+from llava_reward_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+DTS = [("bf16", L.LR_DT_BF16, torch.bfloat16, 2.0 ** -8), ("f16", L.LR_DT_F16, torch.float16, 2.0 ** -11)]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return L.load()
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).cuda()
+
+
+def test_synth_fill_bit_exact(lib):
+    for name, n, std, off in (("model.layers.0.mlp.down_proj.weight", 1 << 20, 0.02, 0.0), ("x.norm", 3072, 0.05, 1.0)):
+        out = torch.empty(n, device="cuda", dtype=torch.float32)
+        assert lib.lr_op_synth_fill(P(out), n, 1234, name.encode(), std, off, 1, stream()) == 0
+        ref = synth.gen_tensor(1234, name, (n,), std, off)
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("dt", DTS, ids=[d[0] for d in DTS])
+@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(300, 256, 128), (1000, 512, 640), (257, 1024, 1024), (4100, 768, 3072)])
+def test_gemm_f32_out_and_resadd(lib, dt, tile, shape):
+    _, code, tdt, _ = dt
+    M, N, K = shape
+    A = rnd((M, K), 1).to(tdt)
+    W = rnd((N, K), 2, 0.05).to(tdt)
+    bias = rnd((N,), 3)
+    ref = A.float() @ W.float().t() + bias
+    Cb = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    assert lib.lr_op_gemm_bt(P(A), P(W), P(Cb), P(bias), M, N, K, K, K, N, L.EPI_OUT_F32, 0, code, tile, stream()) == 0
+    scale = ref.abs().max().item()
+    assert (Cb - ref).abs().max().item() < 2e-5 * scale * math.sqrt(K / 64)
+    # residual add in place, no bias
+    res = rnd((M, N), 4)
+    Cr = res.clone()
+    assert lib.lr_op_gemm_bt(P(A), P(W), P(Cr), P(None), M, N, K, K, K, N, L.EPI_RESADD_F32, 0, code, tile, stream()) == 0
+    ref2 = res + A.float() @ W.float().t()
+    assert (Cr - ref2).abs().max().item() < 2e-5 * scale * math.sqrt(K / 64)
+
+
+@pytest.mark.parametrize("dt", DTS, ids=[d[0] for d in DTS])
+@pytest.mark.parametrize("tile", [0, 2])
+@pytest.mark.parametrize("act", [L.ACT_NONE, L.ACT_QUICK_GELU, L.ACT_GELU_ERF])
+def test_gemm_operand_out_activations(lib, dt, tile, act):
+    _, code, tdt, ulp = dt
+    M, N, K = 777, 512, 256
+    A = rnd((M, K), 5).to(tdt)
+    W = rnd((N, K), 6, 0.1).to(tdt)
+    bias = rnd((N,), 7)
+    y = A.float() @ W.float().t() + bias
+    if act == L.ACT_QUICK_GELU:
+        y = y * torch.sigmoid(1.702 * y)
+    elif act == L.ACT_GELU_ERF:
+        y = torch.nn.functional.gelu(y)
+    out = torch.zeros(M, N, device="cuda", dtype=tdt)
+    assert lib.lr_op_gemm_bt(P(A), P(W), P(out), P(bias), M, N, K, K, K, N, L.EPI_OUT_OP, act, code, tile, stream()) == 0
+    err = (out.float() - y).abs()
+    assert (err <= ulp * y.abs() + 1e-4).all(), err.max().item()
+
+
+@pytest.mark.parametrize("dt", DTS, ids=[d[0] for d in DTS])
+@pytest.mark.parametrize("tile", [0, 1, 2])
+def test_gemm_swiglu(lib, dt, tile):
+    _, code, tdt, ulp = dt
+    M, I, K = 515, 512, 384
+    A = rnd((M, K), 8).to(tdt)
+    W = rnd((2 * I, K), 9, 0.1).to(tdt)
+    gu = A.float() @ W.float().t()
+    ref = gu[:, I:] * torch.nn.functional.silu(gu[:, :I])
+    # pack rows as the engine does: [g0..31, u0..31, g32..63, u32..63, ...]
+    g = torch.arange(I)
+    perm = torch.empty(2 * I, dtype=torch.long)
+    perm[(g // 32) * 64 + g % 32] = g
+    perm[(g // 32) * 64 + 32 + g % 32] = I + g
+    Wp = W[perm.cuda()].contiguous()
+    out = torch.zeros(M, I, device="cuda", dtype=tdt)
+    assert lib.lr_op_gemm_bt(P(A), P(Wp), P(out), P(None), M, 2 * I, K, K, K, I, L.EPI_SWIGLU_OP, 0, code, tile, stream()) == 0
+    err = (out.float() - ref).abs()
+    assert (err <= ulp * ref.abs() + 1e-4).all(), err.max().item()
+
+
+def _attn_ref(q, k, v, mask, causal, scale):
+    # q,k,v [B,H,S,hd] fp32; mask [B,S] or None
+    B, H, S, _ = q.shape
+    s = torch.matmul(q, k.transpose(2, 3)) * scale
+    ok = torch.ones(B, 1, S, S, dtype=torch.bool, device=q.device)
+    if causal:
+        ok = ok & torch.tril(torch.ones(S, S, dtype=torch.bool, device=q.device))[None, None]
+    if mask is not None:
+        ok = ok & mask.bool()[:, None, None, :]
+    s = s.masked_fill(~ok, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    p = torch.nan_to_num(p, nan=0.0)
+    return torch.matmul(p, v)
+
+
+@pytest.mark.parametrize("dt", DTS, ids=[d[0] for d in DTS])
+@pytest.mark.parametrize("case", [(2, 3, 300, 96, True), (3, 2, 577, 64, False), (1, 4, 1000, 96, True), (2, 2, 130, 64, True)])
+def test_attention(lib, dt, case):
+    _, code, tdt, ulp = dt
+    B, H, S, hd, causal = case
+    D = H * hd
+    qkv = rnd((B * S, 3 * D), 11).to(tdt)
+    mask = None
+    kmin = None
+    if causal:
+        mask = torch.ones(B, S, dtype=torch.int64)
+        for b in range(B):
+            mask[b, : 37 * b] = 0          # left padding, different per row
+        kmin = torch.tensor([37 * b for b in range(B)], dtype=torch.int32).cuda()
+        mask = mask.cuda()
+    out = torch.zeros(B * S, D, device="cuda", dtype=tdt)
+    scale = 1.0 / math.sqrt(hd)
+    rc = lib.lr_op_attention(P(qkv), P(qkv), P(qkv), P(out), P(mask), P(kmin), 3 * D, D, 0, D, 2 * D, B, S, H, hd, int(causal),
+                             scale, code, stream())
+    assert rc == 0
+    f = qkv.float().view(B, S, 3, H, hd)
+    q, k, v = (f[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    ref = _attn_ref(q, k, v, mask, causal, scale).permute(0, 2, 1, 3).reshape(B * S, D)
+    got = out.float()
+    valid = torch.ones(B * S, dtype=torch.bool, device="cuda") if mask is None else mask.bool().reshape(-1)
+    err = (got - ref).abs()[valid]
+    # P is rounded to the operand dtype before the PV product: error ~ ulp * |v|max
+    assert err.max().item() < 2.5 * ulp * v.abs().max().item(), err.max().item()
+    # fully masked (pad) query rows come out as exact zeros
+    if mask is not None:
+        assert (got[~valid] == 0).all()
+
+
+@pytest.mark.parametrize("dt", DTS, ids=[d[0] for d in DTS])
+@pytest.mark.parametrize("H", [128, 384, 1024, 3072])
+def test_norm_rows(lib, dt, H):
+    _, code, tdt, ulp = dt
+    rows = 1001
+    x = rnd((rows, H), 21, 3.0) + 0.5
+    w = rnd((H,), 22) * 0.1 + 1
+    b = rnd((H,), 23) * 0.1
+    y = torch.zeros(rows, H, device="cuda", dtype=tdt)
+    assert lib.lr_op_norm_rows(P(x), P(w), P(b), P(y), rows, H, 1e-5, code, stream()) == 0
+    ref = torch.nn.functional.layer_norm(x, (H,), w, b, 1e-5)
+    assert ((y.float() - ref).abs() <= ulp * ref.abs() + 1e-5).all()
+    assert lib.lr_op_norm_rows(P(x), P(w), P(None), P(y), rows, H, 1e-5, code, stream()) == 0
+    ref = w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5))
+    assert ((y.float() - ref).abs() <= ulp * ref.abs() + 1e-5).all()

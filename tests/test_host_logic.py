@@ -1,0 +1,217 @@
+"""CPU-only checks of the host side: the C-ABI library exports what include/*.h declares, the
+checkpoint importer (HF safetensors + PEFT LoRA merge + reward heads), the drop-in callables'
+contracts, and the multi-process shard/all-gather path (gloo, world_size 2)."""
+import json
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from llava_reward_amd import _lib, checkpoint, synth
+from llava_reward_amd.model import RewardModel
+from llava_reward_amd.reward_adaptor_loader import UnknownModelType, load_reward_adaptor, preference_compute
+from llava_reward_amd.scoring import gather_rewards, score_pairwise, score_single, shard_rows
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported():
+    hdr = open(os.path.join(ROOT, "include", "llava_reward_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|size_t|const char\*)\s+(lr_\w+)\(", hdr, flags=re.M))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    lib = _lib.load()                      # resolves every symbol; no compute without a GPU
+    assert lib.lr_abi_version() == 1
+    assert _lib.ModelDesc.struct_size.offset == 0
+
+
+def test_desc_validation_without_gpu():
+    """lr_create must reject a bad descriptor with an error message instead of crashing."""
+    import ctypes as C
+    lib = _lib.load()
+    d = _lib.ModelDesc()
+    d.struct_size = 4
+    h = C.c_void_p()
+    assert lib.lr_create(C.byref(d), 0, C.byref(h)) != 0
+    assert b"struct_size" in lib.lr_last_error(None)
+
+
+def _write_fake_checkpoint(tmp, cfg, seed, reward_cfg, with_lora=True):
+    from safetensors.torch import save_file
+    pre = os.path.join(tmp, "pretrain")
+    pm = os.path.join(tmp, "pm")
+    os.makedirs(pre)
+    os.makedirs(os.path.join(pm, "lora"))
+    hf = {"vocab_size": cfg.vocab_size, "hidden_size": cfg.hidden, "intermediate_size": cfg.intermediate,
+          "num_hidden_layers": cfg.layers, "num_attention_heads": cfg.heads, "rms_norm_eps": cfg.rms_eps,
+          "rope_theta": cfg.rope_theta, "max_position_embeddings": cfg.max_pos,
+          "original_max_position_embeddings": cfg.orig_max_pos,
+          "rope_scaling": {"type": "su", "short_factor": list(cfg.short_factor), "long_factor": list(cfg.long_factor)},
+          "embd_layer": {"embedding_cls": "image", "hd_transform_order": "sub_glb", "projection_cls": "mlp",
+                         "use_hd_transform": True, "with_learnable_separator": True},
+          "img_processor": {"name": "clip_vision_model", "clip_hidden": cfg.clip.hidden, "clip_heads": cfg.clip.heads,
+                            "clip_mlp": cfg.clip.mlp, "clip_layers_used": cfg.clip.layers_used}}
+    json.dump(hf, open(os.path.join(pre, "config.json"), "w"))
+    W = {k: torch.from_numpy(v) for k, v in synth.make_weights(cfg, seed).items()}
+    heads = {k: v for k, v in W.items() if k.split(".")[0] in ("value_head", "W_q", "W_k", "W_v", "ca_layernorm")}
+    base = {k: v.to(torch.bfloat16) for k, v in W.items() if k not in heads}
+    base["lm_head.weight"] = torch.zeros(4, 4, dtype=torch.bfloat16)          # ignored by the importer
+    save_file(base, os.path.join(pre, "model-00001-of-00001.safetensors"))
+    # heads as DeepspeedStrategy.save_model_lora writes them (utils/deepspeed.py:343-357)
+    sd = {("base_model.model." + k): v for k, v in heads.items()}
+    g = torch.Generator().manual_seed(1)
+    proj = {f"base_model.model.model.vision_embed_tokens.img_projection.{i}.{p}":
+            torch.randn(W[f"model.vision_embed_tokens.img_projection.{i}.{p}"].shape, generator=g) * 0.02
+            for i in (0, 2) for p in ("weight", "bias")}
+    sd.update(proj)
+    torch.save(sd, os.path.join(pm, "pytorch_model.bin"))
+    yaml.safe_dump(reward_cfg, open(os.path.join(pm, "reward_config.yaml"), "w"))
+    r = 4
+    lora = {}
+    for mod in ("model.layers.0.self_attn.qkv_proj", "model.layers.1.mlp.down_proj"):
+        out_f, in_f = W[mod + ".weight"].shape
+        lora[f"base_model.model.{mod}.lora_A.weight"] = torch.randn(r, in_f, generator=g) * 0.1
+        lora[f"base_model.model.{mod}.lora_B.weight"] = torch.randn(out_f, r, generator=g) * 0.1
+    json.dump({"r": r, "lora_alpha": 8, "target_modules": ["qkv_proj", "down_proj"]}, open(os.path.join(pm, "lora", "adapter_config.json"), "w"))
+    torch.save(lora, os.path.join(pm, "lora", "adapter_model.bin"))
+    return pre, pm, W, lora, proj
+
+
+def test_load_reward_adaptor_contract(tmp_path):
+    cfg = synth.tiny_config(is_general_preference=True, value_head_dim=2)
+    reward_cfg = {"is_general_preference": True, "add_cross_attention": True, "value_head_dim": 2, "general_preference_tau": 0.1}
+    pre, pm, W, lora, proj = _write_fake_checkpoint(str(tmp_path), cfg, 3, reward_cfg)
+    args = types.SimpleNamespace(pm_path=pm, pretrain=pre, cache_dir=None, ft_projector=True, disable_fast_tokenizer=False)
+    ret = load_reward_adaptor(args, "phi3v", os.path.join(pm, "reward_config.yaml"))
+    assert len(ret) == 2 and ret[0] is args                    # (args, model); args mutated in place (:27-30)
+    assert args.is_general_preference is True and args.value_head_dim == 2 and args.general_preference_tau == 0.1
+    model = ret[1]
+    assert model.model_type == "phi3v" and model.device.type == "cpu"
+    assert model.eval() is model and model.to("cpu") is model
+    w = model._weights
+    # LoRA merged: W + (alpha/r) B A
+    mod = "model.layers.0.self_attn.qkv_proj"
+    exp = W[mod + ".weight"] + 2.0 * lora[f"base_model.model.{mod}.lora_B.weight"] @ lora[f"base_model.model.{mod}.lora_A.weight"]
+    assert torch.allclose(w[mod + ".weight"], exp, atol=1e-6)
+    assert torch.equal(w["model.layers.1.self_attn.qkv_proj.weight"].float(), W["model.layers.1.self_attn.qkv_proj.weight"])
+    # ft_projector override and heads (substring-filtered, reward_adaptor_loader.py:46-60)
+    assert torch.equal(w["model.vision_embed_tokens.img_projection.2.bias"], proj["base_model.model.model.vision_embed_tokens.img_projection.2.bias"])
+    assert torch.equal(w["value_head.weight"], W["value_head.weight"]) and w["W_k.weight"].shape == (cfg.hidden, cfg.hidden)
+    assert set(n for n, *_ in synth.weight_specs(model.config)) <= set(w)
+    # fails loudly on CPU: no fallback path
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.custom_forward(torch.zeros(1, 4, dtype=torch.long), torch.ones(1, 4, dtype=torch.long), torch.zeros(1, 2, 3, 336, 336), torch.tensor([[336, 336]]))
+    # error behaviour
+    with pytest.raises(UnboundLocalError):
+        load_reward_adaptor(args, "gemma", os.path.join(pm, "reward_config.yaml"))
+    with pytest.raises(NotImplementedError):
+        load_reward_adaptor(args, "qwen", os.path.join(pm, "reward_config.yaml"))
+    with pytest.raises(FileNotFoundError):
+        load_reward_adaptor(args, "phi3v", os.path.join(pm, "missing.yaml"))
+    bad = os.path.join(str(tmp_path), "bad.yaml")
+    yaml.safe_dump({"is_general_preference": False}, open(bad, "w"))
+    with pytest.raises(KeyError):
+        load_reward_adaptor(args, "phi3v", bad)
+    assert issubclass(UnknownModelType, UnboundLocalError)
+
+
+def test_preference_compute_matches_reference_formula():
+    a = types.SimpleNamespace(is_general_preference=True, value_head_dim=2, general_preference_tau=0.1)
+    c = torch.tensor([[0.3, -0.2], [1.0, 0.5]], dtype=torch.bfloat16)
+    r = torch.tensor([[0.1, 0.4], [-0.5, 0.25]], dtype=torch.bfloat16)
+    p = preference_compute(a, c, r)
+    exp = torch.sigmoid((c[:, 0] * r[:, 1] - c[:, 1] * r[:, 0]) / 0.1).float().numpy()
+    assert p.dtype == np.float32 and p.shape == (2,) and np.array_equal(p, exp)
+    a = types.SimpleNamespace(is_general_preference=False, value_head_dim=1, general_preference_tau=0.5)
+    p = preference_compute(a, torch.tensor([[0.3], [0.0]]), torch.tensor([[0.1], [0.2]]))
+    np.testing.assert_allclose(p, 1 / (1 + np.exp(-np.array([0.2, -0.2]) / 0.5)), rtol=1e-6)
+    # GPM with d=4 falls to the BT-style branch exactly like the reference (:175-180)
+    a = types.SimpleNamespace(is_general_preference=True, value_head_dim=4, general_preference_tau=1.0)
+    assert preference_compute(a, torch.zeros(2, 4), torch.zeros(2, 4)).shape == (2, 4)
+
+
+def test_shard_rows_partition():
+    for n in (0, 1, 7, 32, 33):
+        for ws in (1, 2, 3, 8):
+            sl = [shard_rows(n, r, ws) for r in range(ws)]
+            assert sl[0].start == 0 and sl[-1].stop == n
+            assert all(a.stop == b.start for a, b in zip(sl, sl[1:]))
+            sizes = [s.stop - s.start for s in sl]
+            assert max(sizes) - min(sizes) <= 1
+
+
+class _FakeModel:
+    """Deterministic stand-in for the HIP model: reward = f(row content), so sharding must not change it."""
+    device = torch.device("cpu")
+
+    def __init__(self, d):
+        self.d = d
+
+    def custom_forward(self, ids, mask, pix, sizes, return_output=False, inputs_batch=None):
+        base = (ids.float() * mask.float()).sum(dim=1, keepdim=True) * 1e-3 + pix.flatten(1).sum(dim=1, keepdim=True)
+        return torch.cat([base * (k + 1) for k in range(self.d)], dim=1), None
+
+
+def _batches(n_batches, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n_batches):
+        def one():
+            return {"input_ids": torch.randint(0, 50, (n, 1, 6), generator=g), "attention_mask": torch.ones(n, 1, 6, dtype=torch.long),
+                    "pixel_values": torch.randn(n, 1, 2, 3, 4, 4, generator=g), "image_sizes": torch.full((n, 1, 2), 336)}
+        out.append((one(), one(), None, None))
+    return out
+
+
+def _worker(rank, ws, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    args = types.SimpleNamespace(is_general_preference=True, value_head_dim=2, general_preference_tau=0.1)
+    res = score_pairwise(_FakeModel(2), args, _batches(3, 5, 0))          # 5 rows over 2 ranks: ragged shards
+    local = torch.arange(4, dtype=torch.float32).reshape(2, 2) + 10 * rank
+    g = gather_rewards(local)
+    q.put((rank, res["probs"], g.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_process_shard_and_gather_equals_single_process():
+    import torch.multiprocessing as mp
+    args = types.SimpleNamespace(is_general_preference=True, value_head_dim=2, general_preference_tau=0.1)
+    single = score_pairwise(_FakeModel(2), args, _batches(3, 5, 0))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, probs, g in got:
+        assert probs == single["probs"]                       # bit-identical on every rank
+        assert g == [[0.0, 1.0], [2.0, 3.0], [10.0, 11.0], [12.0, 13.0]]
+    assert 0.0 <= single["proportion"] <= 1.0 and len(single["probs"]) == 15
+
+
+def test_score_single_metrics():
+    args = types.SimpleNamespace(is_general_preference=False, value_head_dim=1, general_preference_tau=0.1)
+    bs = [(b[0], torch.tensor([1, 0, 1, 1, 0])) for b in _batches(2, 5, 1)]
+    res = score_single(_FakeModel(1), args, bs, cls_based=True)
+    assert len(res["rewards"]) == 10 and 0 <= res["accuracy"] <= 1 and 0 <= res["f1"] <= 1
+    args.is_general_preference = True
+    with pytest.raises(ValueError):
+        score_single(_FakeModel(1), args, bs)
+
+
+def test_reward_model_requires_weights_or_seed():
+    with pytest.raises(ValueError):
+        RewardModel(synth.tiny_config())
+    with pytest.raises(NotImplementedError):
+        RewardModel(synth.tiny_config(), synth_seed=1, mean_hidden_state=True)
