@@ -22,6 +22,9 @@ template <> struct Op<BF16> {
     static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
+    static __device__ __forceinline__ f32x4 mfma16(uint4 a, uint4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
     static __device__ __forceinline__ unsigned short from_f32(float x) {
         return __builtin_bit_cast(unsigned short, (__bf16)x);
     }
@@ -33,6 +36,9 @@ template <> struct Op<F16> {
     typedef f16x8 vec8;
     static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(uint4 a, uint4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ unsigned short from_f32(float x) {
         // saturate instead of overflowing to inf (f16 max 65504); NaN stays NaN

@@ -425,7 +425,7 @@ int lr_set_layer_limits(lr_handle h, int n_clip_layers, int n_layers) {
     return LR_OK;
 }
 int lr_set_gemm_tile(lr_handle h, int tile) {
-    if (!h || tile < -1 || tile > 2) return LR_EINVAL;
+    if (!h || tile < -1 || tile > 6) return LR_EINVAL;
     h->gemm_tile = tile;
     return LR_OK;
 }

@@ -7,6 +7,8 @@ namespace lr {
 
 // gemm.hip
 void launch_gemm_bt(const GemmParams& p, int operand_dtype, int tile, hipStream_t st);
+// gemm8.hip (deep-pipelined 256x256 variant, tile == 3)
+void launch_gemm_bt8(const GemmParams& p, int operand_dtype, int variant, hipStream_t st);
 // attention.hip
 void launch_attention(const AttnParams& p, int batch, int head_dim, bool causal, int operand_dtype, hipStream_t st);
 

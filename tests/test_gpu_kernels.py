@@ -47,7 +47,7 @@ def test_synth_fill_bit_exact(lib):
 
 
 @pytest.mark.parametrize("dt", DTS, ids=[d[0] for d in DTS])
-@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("shape", [(300, 256, 128), (1000, 512, 640), (257, 1024, 1024), (4100, 768, 3072)])
 def test_gemm_f32_out_and_resadd(lib, dt, tile, shape):
     _, code, tdt, _ = dt
@@ -69,7 +69,7 @@ def test_gemm_f32_out_and_resadd(lib, dt, tile, shape):
 
 
 @pytest.mark.parametrize("dt", DTS, ids=[d[0] for d in DTS])
-@pytest.mark.parametrize("tile", [0, 2])
+@pytest.mark.parametrize("tile", [0, 2, 3, 6])
 @pytest.mark.parametrize("act", [L.ACT_NONE, L.ACT_QUICK_GELU, L.ACT_GELU_ERF])
 def test_gemm_operand_out_activations(lib, dt, tile, act):
     _, code, tdt, ulp = dt
@@ -89,7 +89,7 @@ def test_gemm_operand_out_activations(lib, dt, tile, act):
 
 
 @pytest.mark.parametrize("dt", DTS, ids=[d[0] for d in DTS])
-@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 6])
 def test_gemm_swiglu(lib, dt, tile):
     _, code, tdt, ulp = dt
     M, I, K = 515, 512, 384
