@@ -54,6 +54,12 @@ template <typename OT> __device__ __forceinline__ unsigned pack2(float lo, float
     return (unsigned)Op<OT>::from_f32(lo) | ((unsigned)Op<OT>::from_f32(hi) << 16);
 }
 
+// x * sigmoid(a*x) with the hardware exp2/rcp (1 ulp each; the result is rounded to a 16-bit operand anyway)
+__device__ __forceinline__ float x_sigmoid_fast(float x, float a) {
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * a * x);
+    return x * __builtin_amdgcn_rcpf(1.f + e);
+}
+
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short u) {
     return __builtin_bit_cast(float, ((unsigned)u) << 16);
 }

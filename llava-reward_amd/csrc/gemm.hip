@@ -229,7 +229,8 @@ void launch_gemm_bt(const GemmParams& p, int operand_dtype, int tile, hipStream_
     if (p.epi == EPI_SWIGLU_OP && (p.N % 64) != 0) throw std::runtime_error("gemm_bt: SwiGLU needs N % 64 == 0");
     if (tile < 0) {  // heuristic: the deep-pipelined 256x256 kernel once there is enough work to fill the chip with it
         const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-        tile = t256 >= 256 ? 5 : 0;
+        const bool aligned = p.N % 8 == 0 && p.ldc % 8 == 0 && (((uintptr_t)p.C) & 15) == 0 && (!p.bias || (((uintptr_t)p.bias) & 15) == 0);
+        tile = (t256 >= 256 && aligned) ? 6 : 0;
     }
     if (tile >= 3) { launch_gemm_bt8(p, operand_dtype, tile, st); return; }
     if (operand_dtype == DT_F16) launch_dt<F16>(p, tile, st);

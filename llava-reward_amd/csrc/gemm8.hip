@@ -1,14 +1,14 @@
-// Deep-pipelined variant of gemm_bt (same contract and epilogues as gemm.hip): 256x256x64 block tile,
-// 8 waves, LDS-DMA half-tile ring with counted vmcnt, raw barriers, two wave groups staggered by one
-// barrier (cdna_hip_programming.md §5 "256^2 8-phase template", T3+T4+T5; MI355X_MICROARCH.md
-// "Two waves per SIMD").
+// Deep-pipelined, persistent variant of gemm_bt (same contract and epilogues as gemm.hip):
+// 256x256x64 block tile, 8 waves, LDS-DMA half-tile ring with counted vmcnt, raw barriers, two wave
+// groups staggered by one barrier, 16x16x32 MFMAs, LDS-staged coalesced epilogue, one resident
+// workgroup per CU that walks its tiles (cdna_hip_programming.md §5 "256^2 8-phase template",
+// T1/T3/T4/T5; MI355X_MICROARCH.md "Two waves per SIMD").
 //
 // Schedule.  A K-tile (64 deep) is 4 half-tiles of 16 KB: A0, B0, B1, A1 (128 rows x 64 k each, same
 // swizzled image as gemm.hip).  Half-tile g = 4t + j lives in ring slot g % NS.  A K-tile is consumed
 // in 4 phases, one block quadrant (A-half qa, B-half qb) each: (0,0) (0,1) (1,1) (1,0); in a phase every
-// wave multiplies its 64x32 piece of that quadrant over the full K-tile (8 MFMA 32x32x16 or 16 MFMA
-// 16x16x32), so the register fragments of one half are reused by the next phase (ds_read_b128 per
-// phase: 12, 4, 8, 4).
+// wave multiplies its 64x32 piece of that quadrant over the full K-tile (16 MFMA 16x16x32), so the
+// register fragments of one half are reused by the next phase (ds_read_b128 per phase: 12, 4, 8, 4).
 // Phase P (global index):   LOAD(P): ds_reads for P's MFMAs; issue half-tile P+PF by LDS-DMA;
 //                                    s_waitcnt vmcnt(2*(PF-2))  -> everything up to half-tile P+2 landed
 //                           barrier; COMPUTE(P): MFMAs; barrier.
@@ -17,6 +17,9 @@
 // phase <= g+2 of the lagging wave group (WAR) => NS - PF >= 4.  NS = 10 slots = all 160 KB of LDS.
 // Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA segment while
 // its partner issues LDS reads / DMA.
+// Measured (MI355X, random data): main loop 1.16-1.28 PFLOP/s on every shape of the path; direct
+// stores from the C/D layout cost 30 % of all GEMM time and a per-tile relaunch exposes the store
+// acknowledgements, hence the staged epilogue and the persistent tile loop.
 //
 // Column mapping inside a block tile: wave wc owns columns wc*64 + qb*32 + [0,32) for qb = 0,1, so the
 // SwiGLU pair (gate block, up block: weight rows interleaved in 32s) stays in one lane/register.
@@ -27,23 +30,11 @@ namespace lr {
 
 #define LR_BARRIER() do { asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
-template <typename OT>
-__device__ __forceinline__ void epi_store(const GemmParams& p, int row, int col, float v) {
-    const size_t o = (size_t)row * p.ldc + col;
-    if (p.epi == EPI_OUT_OP) {
-        if (p.act == ACT_QUICK_GELU) v = v / (1.f + expf(-1.702f * v));
-        else if (p.act == ACT_GELU_ERF) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-        ((unsigned short*)p.C)[o] = Op<OT>::from_f32(v);
-    } else if (p.epi == EPI_OUT_F32) {
-        ((float*)p.C)[o] = v;
-    } else {
-        ((float*)p.C)[o] += v;
-    }
-}
-
-// M16: 16x16x32 MFMAs (16 per phase) instead of 32x32x16 (8 per phase).
-// DBG: 0 = product; 1 = every K-tile re-reads K-tile 0 (cache-resident operands: LDS+MFMA ceiling; results invalid).
-template <typename OT, int PF, int NS, bool M16, int DBG>
+// DBG: 0 = product; 1 = every K-tile re-reads K-tile 0 (cache-resident operands; results invalid);
+//      2 = no epilogue (results invalid).  Diagnostics for tools/gemm_bench.py only.
+// EPI is a template parameter so that each instantiation carries ONE epilogue: with all of them
+// unrolled in one kernel the code was ~130 KB and every tile's epilogue ran out of the instruction cache.
+template <typename OT, int PF, int NS, int DBG, int EPI>
 __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
     constexpr int BM = 256, BN = 256, BK = 64;
     constexpr int HT = 16384;                      // bytes per half-tile slot
@@ -54,275 +45,322 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, l4 = lane >> 4;
 
-    // ---- XCD-aware tile mapping (as gemm.hip) ----
     const int Mt = (p.M + BM - 1) / BM, Nt = (p.N + BN - 1) / BN;
     const int nwg = Mt * Nt;
-    int L;
-    {
-        const int bid = blockIdx.x;
-        const int xcd = bid & 7, idx = bid >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    constexpr int GM = 8;
-    const int band = L / (GM * Nt);
-    const int within = L - band * (GM * Nt);
-    const int rows_in_band = min(GM, Mt - band * GM);
-    const int mi = band * GM + within % rows_in_band;
-    const int ni = within / rows_in_band;
-    const int m0 = mi * BM, n0 = ni * BN;
-
-    // ---- LDS-DMA source pointers: [half][it]; swizzle on the source side ----
-    const unsigned short* gA[2][2];
-    const unsigned short* gB[2][2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int q = it * 512 + tid;
-        const int R = q >> 4, Cp = q & 15;
-        const int C = Cp ^ (R & 15);
-        const int row = 2 * R + (C >> 3), c = C & 7;            // row of the 128-row half-tile image
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int ga = min(m0 + h * 128 + row, p.M - 1);
-            gA[h][it] = (const unsigned short*)p.A + (size_t)ga * p.lda + c * 8;
-            const int wrow = (row >> 5) * 64 + h * 32 + (row & 31);   // image row -> tile column
-            const int gb = min(n0 + wrow, p.N - 1);
-            gB[h][it] = (const unsigned short*)p.W + (size_t)gb * p.ldw + c * 8;
-        }
-    }
     const int nk = p.K / BK;
     const int Gtot = 4 * nk;
-
-    // half-tile j of a K-tile: 0 = A0, 1 = B0, 2 = B1, 3 = A1.
-    // The LDS-DMA is issued from inline asm on purpose: hipcc's waitcnt pass would otherwise put
-    // `s_waitcnt vmcnt(0)` in front of every ds_read (it cannot prove the pending DMA does not alias)
-    // and drain the ring each phase.  Ordering is ours: counted vmcnt, then a barrier, then the read
-    // (cdna_hip_programming.md §5.7 item 1).  M0 is saved/restored inside the statement.
     typedef __attribute__((address_space(3))) char lds_char;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_char*)smem;
-    auto issue = [&](int j, int kt, int slot) {
-        const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds_base + slot * HT + wave * 1024);
-        const int koff = DBG == 1 ? 0 : kt * BK;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const unsigned short* src = ((j == 0) ? gA[0][it] : (j == 1) ? gB[0][it] : (j == 2) ? gB[1][it] : gA[1][it]) + koff;
-            const unsigned dst = dst0 + it * 8192;
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-        }
-    };
 
     // ---- fragment read offsets inside a half-tile image: 8 A reads + 4 B reads per phase ----
-    // 32x32x16: lane (r = lane&31, h = lane>>5) reads row r, 16-byte chunk 2*ks + h      (ks = 0..3)
-    // 16x16x32: lane (r = lane&15, q = lane>>4) reads row r, 16-byte chunk 4*ks + q      (ks = 0..1)
+    // 16x16x32: lane (r = lane&15, q = lane>>4) reads row r, 16-byte chunk 4*ks + q   (ks = 0..1)
     int aoff[8], boff[4];
     auto img_off = [](int row, int kc) { const int R = row >> 1; return R * 256 + (((((row & 1) << 3) + kc) ^ (R & 15)) << 4); };
-    if constexpr (M16) {
-        const int r16 = lane & 15, q4 = lane >> 4;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) aoff[i * 2 + ks] = img_off(wr * 64 + i * 16 + r16, 4 * ks + q4);
+        for (int i = 0; i < 4; ++i) aoff[i * 2 + ks] = img_off(wr * 64 + i * 16 + l15, 4 * ks + l4);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) boff[j * 2 + ks] = img_off(wc * 32 + j * 16 + r16, 4 * ks + q4);
+        for (int j = 0; j < 2; ++j) boff[j * 2 + ks] = img_off(wc * 32 + j * 16 + l15, 4 * ks + l4);
+    }
+
+    // ---- persistent walk over tiles: virtual block id vb keeps the XCD-aware order of gemm.hip ----
+    for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+        int L;
+        {
+            const int xcd = vb & 7, idx = vb >> 3;
+            const int q = nwg >> 3, r = nwg & 7;
+            L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         }
-    } else {
-        const int r32 = lane & 31, h2 = lane >> 5;
+        constexpr int GM = 8;
+        const int band = L / (GM * Nt);
+        const int within = L - band * (GM * Nt);
+        const int rows_in_band = min(GM, Mt - band * GM);
+        const int mi = band * GM + within % rows_in_band;
+        const int ni = within / rows_in_band;
+        const int m0 = mi * BM, n0 = ni * BN;
+
+        // ---- LDS-DMA source pointers: [half][it]; swizzle on the source side ----
+        const unsigned short* gA[2][2];
+        const unsigned short* gB[2][2];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int it = 0; it < 2; ++it) {
+            const int q = it * 512 + tid;
+            const int R = q >> 4, Cp = q & 15;
+            const int C = Cp ^ (R & 15);
+            const int row = 2 * R + (C >> 3), c = C & 7;            // row of the 128-row half-tile image
 #pragma unroll
-            for (int i = 0; i < 2; ++i) aoff[i * 4 + ks] = img_off(wr * 64 + i * 32 + r32, 2 * ks + h2);
-            boff[ks] = img_off(wc * 32 + r32, 2 * ks + h2);
+            for (int h = 0; h < 2; ++h) {
+                const int ga = min(m0 + h * 128 + row, p.M - 1);
+                gA[h][it] = (const unsigned short*)p.A + (size_t)ga * p.lda + c * 8;
+                const int wrow = (row >> 5) * 64 + h * 32 + (row & 31);   // image row -> tile column
+                const int gb = min(n0 + wrow, p.N - 1);
+                gB[h][it] = (const unsigned short*)p.W + (size_t)gb * p.ldw + c * 8;
+            }
         }
-    }
 
-    f32x16 acc32[4][2];       // [quadrant (0,0) (0,1) (1,1) (1,0)][row tile of 32]
-    f32x4 acc16[4][4][2];     // [quadrant][row tile of 16][col tile of 16]
+        // half-tile j of a K-tile: 0 = A0, 1 = B0, 2 = B1, 3 = A1.
+        // The LDS-DMA is issued from inline asm on purpose: hipcc's waitcnt pass would otherwise put
+        // `s_waitcnt vmcnt(0)` in front of every ds_read (it cannot prove the pending DMA does not alias)
+        // and drain the ring each phase.  Ordering is ours: counted vmcnt, then a barrier, then the read
+        // (cdna_hip_programming.md §5.7 item 1).  M0 is saved/restored inside the statement.
+        auto issue = [&](int j, int kt, int slot) {
+            const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds_base + slot * HT + wave * 1024);
+            const int koff = DBG == 1 ? 0 : kt * BK;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc32[q][i][r] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc16[q][i][j][r] = 0.f;
-    }
-
-    // ---- prologue: PF half-tiles in flight, the first two landed ----
-    int islot = 0;         // ring slot of the next half-tile to issue
-#pragma unroll
-    for (int g = 0; g < PF; ++g) {
-        if (g < Gtot) issue(g & 3, g >> 2, islot);
-        islot = (islot + 1 == NS) ? 0 : islot + 1;
-    }
-    if (Gtot > PF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PF - 2)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    LR_BARRIER();
-    if (wr == 1) LR_BARRIER();                      // stagger the second wave group by one barrier
-
-    uint4 af[8], bf[4];
-    int rslot = 0;         // ring slot of half-tile A0 of the current K-tile
-    int gi = PF;           // index of the next half-tile to issue
-
-    for (int kt = 0; kt < nk; ++kt) {
-        int s1 = rslot + 1; s1 = s1 >= NS ? s1 - NS : s1;
-        int s2 = rslot + 2; s2 = s2 >= NS ? s2 - NS : s2;
-        int s3 = rslot + 3; s3 = s3 >= NS ? s3 - NS : s3;
-        const char* sA0 = smem + rslot * HT;
-        const char* sB0 = smem + s1 * HT;
-        const char* sB1 = smem + s2 * HT;
-        const char* sA1 = smem + s3 * HT;
-#pragma unroll
-        for (int ph = 0; ph < 4; ++ph) {
-            // ---------------- LOAD ----------------
-            if (ph == 0 || ph == 1 || ph == 3) {
-                const char* sb = (ph == 1) ? sB1 : sB0;
-#pragma unroll
-                for (int f = 0; f < 4; ++f) bf[f] = *(const uint4*)(sb + boff[f]);
+            for (int it = 0; it < 2; ++it) {
+                const unsigned short* src = ((j == 0) ? gA[0][it] : (j == 1) ? gB[0][it] : (j == 2) ? gB[1][it] : gA[1][it]) + koff;
+                const unsigned dst = dst0 + it * 8192;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
             }
-            if (ph == 0 || ph == 2) {
-                const char* sa = (ph == 0) ? sA0 : sA1;
+        };
+
+        f32x4 acc[4][4][2];     // [quadrant (0,0) (0,1) (1,1) (1,0)][row tile of 16][col tile of 16]
 #pragma unroll
-                for (int f = 0; f < 8; ++f) af[f] = *(const uint4*)(sa + aoff[f]);
-            }
-            if (gi < Gtot) {
-                issue((ph + PF) & 3, kt + ((ph + PF) >> 2), islot);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PF - 2)) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            ++gi;
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[q][i][j][r] = 0.f;
+
+        // ---- prologue: PF half-tiles in flight, the first two landed.  (Stores of the previous tile's
+        //      epilogue are older than these DMAs in the vmcnt queue: the wait covers them too.) ----
+        int islot = 0;         // ring slot of the next half-tile to issue
+#pragma unroll
+        for (int g = 0; g < PF; ++g) {
+            if (g < Gtot) issue(g & 3, g >> 2, islot);
             islot = (islot + 1 == NS) ? 0 : islot + 1;
-            LR_BARRIER();
-            // ---------------- COMPUTE ----------------
-            __builtin_amdgcn_s_setprio(1);
-            if constexpr (M16) {
+        }
+        if (Gtot > PF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PF - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LR_BARRIER();
+        if (wr == 1) LR_BARRIER();                      // stagger the second wave group by one barrier
+
+        uint4 af[8], bf[4];
+        int rslot = 0;         // ring slot of half-tile A0 of the current K-tile
+        int gi = PF;           // index of the next half-tile to issue
+
+        for (int kt = 0; kt < nk; ++kt) {
+            int s1 = rslot + 1; s1 = s1 >= NS ? s1 - NS : s1;
+            int s2 = rslot + 2; s2 = s2 >= NS ? s2 - NS : s2;
+            int s3 = rslot + 3; s3 = s3 >= NS ? s3 - NS : s3;
+            const char* sA0 = smem + rslot * HT;
+            const char* sB0 = smem + s1 * HT;
+            const char* sB1 = smem + s2 * HT;
+            const char* sA1 = smem + s3 * HT;
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                // ---------------- LOAD ----------------
+                if (ph == 0 || ph == 1 || ph == 3) {
+                    const char* sb = (ph == 1) ? sB1 : sB0;
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) bf[f] = *(const uint4*)(sb + boff[f]);
+                }
+                if (ph == 0 || ph == 2) {
+                    const char* sa = (ph == 0) ? sA0 : sA1;
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) af[f] = *(const uint4*)(sa + aoff[f]);
+                }
+                if (gi < Gtot) {
+                    issue((ph + PF) & 3, kt + ((ph + PF) >> 2), islot);
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PF - 2)) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                ++gi;
+                islot = (islot + 1 == NS) ? 0 : islot + 1;
+                LR_BARRIER();
+                // ---------------- COMPUTE ----------------
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
-                            acc16[ph][i][j] = Op<OT>::mfma16(af[i * 2 + ks], bf[j * 2 + ks], acc16[ph][i][j]);
-            } else {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) acc32[ph][i] = Op<OT>::mfma32(af[i * 4 + ks], bf[ks], acc32[ph][i]);
+                            acc[ph][i][j] = Op<OT>::mfma16(af[i * 2 + ks], bf[j * 2 + ks], acc[ph][i][j]);
+                __builtin_amdgcn_s_setprio(0);
+                LR_BARRIER();
             }
-            __builtin_amdgcn_s_setprio(0);
-            LR_BARRIER();
+            rslot += 4;
+            rslot = rslot >= NS ? rslot - NS : rslot;
         }
-        rslot += 4;
-        rslot = rslot >= NS ? rslot - NS : rslot;
-    }
-    if (wr == 0) LR_BARRIER();                      // balance the stagger barrier
+        if (wr == 0) LR_BARRIER();                      // balance the stagger barrier
 
-    // ---- epilogue ----  quadrant q -> (qa, qb): 0:(0,0) 1:(0,1) 2:(1,1) 3:(1,0)
-    // 32x32 C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5);  16x16: col = lane&15, row = 4*(lane>>4) + r
-    const int rbase = m0 + wr * 64, cbase = n0 + wc * 64;
-    if (p.epi == EPI_SWIGLU_OP) {
-        unsigned short* C = (unsigned short*)p.C;
-        if (cbase + 64 <= p.N) {
+        if constexpr (DBG == 2) {   // diagnostic: no epilogue (keep the accumulators live)
 #pragma unroll
-            for (int qa = 0; qa < 2; ++qa) {
-                const int qg = qa == 0 ? 0 : 3, qu = qa == 0 ? 1 : 2;
-                if constexpr (M16) {
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = rbase + qa * 128 + i * 16 + 4 * (lane >> 4) + r;
-                                const int col = (cbase >> 1) + j * 16 + (lane & 15);
-                                if (row < p.M) {
-                                    const float g = acc16[qg][i][j][r], u = acc16[qu][i][j][r];
-                                    C[(size_t)row * p.ldc + col] = Op<OT>::from_f32(u * (g / (1.f + expf(-g))));
-                                }
-                            }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int row = rbase + qa * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                            const int col = (cbase >> 1) + (lane & 31);
-                            if (row < p.M) {
-                                const float g = acc32[qg][i][r], u = acc32[qu][i][r];
-                                C[(size_t)row * p.ldc + col] = Op<OT>::from_f32(u * (g / (1.f + expf(-g))));
-                            }
-                        }
-                }
-            }
+                for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(acc[q][i][0]), "v"(acc[q][i][1])); }
+            continue;
         }
-        return;
-    }
+
+        // ---- epilogue ----  quadrant index q -> (qa, qb): 0:(0,0) 1:(0,1) 2:(1,1) 3:(1,0)
+        // The ring is idle (every DMA was retired by the vmcnt(0) of the tail phases), so the tile is staged
+        // through LDS, 128 rows at a time, and leaves the CU as whole rows with 16 bytes per lane.
+        // C/D map of 16x16x32: col = lane&15, row = 4*(lane>>4) + r.  Row stride 260 floats: 4 rows = 1040
+        // floats = 16 banks (mod 32), so the row groups of one ds_write_b32 half-wave use disjoint banks.
+        constexpr int SLD = 260;
+        float* stg = (float*)smem;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int qa = (q >= 2) ? 1 : 0, qb = (q == 1 || q == 2) ? 1 : 0;
-        if constexpr (M16) {
+        for (int qa = 0; qa < 2; ++qa) {
+            const int rowq = m0 + qa * 128;
+            // residual rows are fetched around the staging pass so their latency hides behind it: 8 rows
+            // before it, 8 right after the staging writes (when 64 accumulator registers have been freed)
+            float4 ca[8], cb[8];
+            const int fcol = n0 + lane * 4;
+            auto cload = [&](int it) {
+                const int row = rowq + it * 8 + wave;
+                return (row < p.M && fcol < p.N) ? *(const float4*)((const float*)p.C + (size_t)row * p.ldc + fcol)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+            };
+            if constexpr (EPI == EPI_RESADD_F32) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = cbase + qb * 32 + j * 16 + (lane & 15);
-                if (col >= p.N) continue;
-                const float bv = p.bias ? p.bias[col] : 0.f;
+                for (int it = 0; it < 8; ++it) ca[it] = cload(it);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const int q = qa == 0 ? qb : 3 - qb;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = rbase + qa * 128 + i * 16 + 4 * (lane >> 4) + r;
-                        if (row < p.M) epi_store<OT>(p, row, col, acc16[q][i][j][r] + bv);
-                    }
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            stg[(wr * 64 + i * 16 + 4 * l4 + r) * SLD + wc * 64 + qb * 32 + j * 16 + l15] = acc[q][i][j][r];
             }
-        } else {
-            const int col = cbase + qb * 32 + (lane & 31);
-            if (col >= p.N) continue;
-            const float bv = p.bias ? p.bias[col] : 0.f;
+            if constexpr (EPI == EPI_RESADD_F32) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + qa * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (row < p.M) epi_store<OT>(p, row, col, acc32[q][i][r] + bv);
+                for (int it = 0; it < 8; ++it) cb[it] = cload(8 + it);
+            }
+            __syncthreads();
+            if constexpr (EPI == EPI_SWIGLU_OP) {
+                // 128 output columns per row = 16 chunks of 8: 16 lanes per row, 4 rows per wave-iteration
+                const int c8 = lane & 15, wcc = c8 >> 2, cc = c8 & 3;
+                const int ocol = (n0 >> 1) + c8 * 8;
+#pragma unroll 2
+                for (int it = 0; it < 4; ++it) {
+                    const int rl = it * 32 + wave * 4 + (lane >> 4);
+                    const int row = rowq + rl;
+                    const float* g = stg + rl * SLD + wcc * 64 + cc * 8;
+                    const float4 g0 = *(const float4*)g, g1 = *(const float4*)(g + 4);
+                    const float4 u0 = *(const float4*)(g + 32), u1 = *(const float4*)(g + 36);
+                    if (row < p.M && n0 + wcc * 64 + 64 <= p.N) {
+                        auto sw = [](float gg, float uu) { return uu * x_sigmoid_fast(gg, 1.f); };
+                        uint4 w;
+                        w.x = pack2<OT>(sw(g0.x, u0.x), sw(g0.y, u0.y));
+                        w.y = pack2<OT>(sw(g0.z, u0.z), sw(g0.w, u0.w));
+                        w.z = pack2<OT>(sw(g1.x, u1.x), sw(g1.y, u1.y));
+                        w.w = pack2<OT>(sw(g1.z, u1.z), sw(g1.w, u1.w));
+                        *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + ocol) = w;
+                    }
                 }
+            } else if constexpr (EPI == EPI_OUT_OP) {
+                // 256 columns = 32 chunks of 8: 32 lanes per row, 2 rows per wave-iteration
+                const int c8 = lane & 31;
+                const int col = n0 + c8 * 8;
+                float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+                if (p.bias && col < p.N) { b0 = *(const float4*)(p.bias + col); b1 = *(const float4*)(p.bias + col + 4); }
+#pragma unroll 2
+                for (int it = 0; it < 8; ++it) {
+                    const int rl = it * 16 + wave * 2 + (lane >> 5);
+                    const int row = rowq + rl;
+                    const float* sp = stg + rl * SLD + c8 * 8;
+                    float4 v0 = *(const float4*)sp, v1 = *(const float4*)(sp + 4);
+                    if (row < p.M && col < p.N) {
+                        float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            if (p.act == ACT_QUICK_GELU) v[e] = x_sigmoid_fast(v[e], 1.702f);
+                            else if (p.act == ACT_GELU_ERF) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752440f));
+                        }
+                        uint4 w;
+                        w.x = pack2<OT>(v[0], v[1]); w.y = pack2<OT>(v[2], v[3]);
+                        w.z = pack2<OT>(v[4], v[5]); w.w = pack2<OT>(v[6], v[7]);
+                        *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + col) = w;
+                    }
+                }
+            } else {
+                // fp32 out / residual add: 64 float4 per row, one row per wave-iteration (1 KB contiguous)
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.bias && fcol < p.N) bv = *(const float4*)(p.bias + fcol);
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const int rl = it * 8 + wave;
+                    const int row = rowq + rl;
+                    float4 v = *(const float4*)(stg + rl * SLD + lane * 4);
+                    if (row < p.M && fcol < p.N) {
+                        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                        if constexpr (EPI == EPI_RESADD_F32) { const float4 c = it < 8 ? ca[it & 7] : cb[it & 7]; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+                        *(float4*)((float*)p.C + (size_t)row * p.ldc + fcol) = v;
+                    }
+                }
+            }
         }
+        __syncthreads();      // staging reads done before the next tile's DMA reuses the ring
     }
 }
 
-template <typename OT, int PF, bool M16, int DBG>
-static void launch8(const GemmParams& p, hipStream_t st) {
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        LR_HIP_CHECK(hipGetDevice(&dev));
+        LR_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
+
+template <typename OT, int PF, int DBG, int EPI>
+static void launch8(const GemmParams& p, bool persistent, hipStream_t st) {
     constexpr int NS = 10;
     constexpr int smem = NS * 16384;
     static bool attr_set = false;
-    auto kfn = gemm_bt8_kernel<OT, PF, NS, M16, DBG>;
+    auto kfn = gemm_bt8_kernel<OT, PF, NS, DBG, EPI>;
     if (!attr_set) {
         LR_HIP_CHECK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
     const int Mt = (p.M + 255) / 256, Nt = (p.N + 255) / 256;
-    hipLaunchKernelGGL(kfn, dim3(Mt * Nt), dim3(512), smem, st, p);
+    // persistent: one resident workgroup per CU (160 KB LDS each) walking its tiles; else one workgroup per tile
+    const int grid = persistent ? std::min(Mt * Nt, num_cus()) : Mt * Nt;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), smem, st, p);
+}
+
+template <typename OT, int PF, int DBG>
+static void launch8_epi(const GemmParams& p, bool persistent, hipStream_t st) {
+    switch (p.epi) {
+        case EPI_OUT_OP: launch8<OT, PF, DBG, EPI_OUT_OP>(p, persistent, st); break;
+        case EPI_OUT_F32: launch8<OT, PF, DBG, EPI_OUT_F32>(p, persistent, st); break;
+        case EPI_RESADD_F32: launch8<OT, PF, DBG, EPI_RESADD_F32>(p, persistent, st); break;
+        case EPI_SWIGLU_OP: launch8<OT, PF, DBG, EPI_SWIGLU_OP>(p, persistent, st); break;
+        default: throw std::runtime_error("gemm_bt8: unknown epilogue");
+    }
 }
 
 template <typename OT>
 static void launch8_variant(const GemmParams& p, int variant, hipStream_t st) {
     switch (variant) {
-        case 3: launch8<OT, 5, false, 0>(p, st); break;
-        case 4: launch8<OT, 6, false, 0>(p, st); break;
-        case 5: launch8<OT, 5, true, 0>(p, st); break;
-        case 6: launch8<OT, 6, true, 0>(p, st); break;
-        case 7: launch8<OT, 6, true, 1>(p, st); break;      // diagnostic only
+        case 3: case 5: launch8_epi<OT, 5, 0>(p, false, st); break;
+        case 4: case 6: launch8_epi<OT, 5, 0>(p, true, st); break;       // persistent walk (A/B)
+        case 7: launch8<OT, 5, 1, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: cache-resident operands
+        case 8: launch8<OT, 5, 2, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: no epilogue
         default: throw std::runtime_error("gemm_bt8: unknown variant");
     }
 }
 
 void launch_gemm_bt8(const GemmParams& p, int operand_dtype, int variant, hipStream_t st) {
+    if (p.N % 8 || p.ldc % 8 || ((uintptr_t)p.C & 15) || (p.bias && ((uintptr_t)p.bias & 15)))
+        throw std::runtime_error("gemm_bt8: N and ldc must be multiples of 8 and C/bias 16-byte aligned");
     if (operand_dtype == DT_F16) launch8_variant<F16>(p, variant, st);
     else launch8_variant<BF16>(p, variant, st);
 }
