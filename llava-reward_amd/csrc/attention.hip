@@ -7,40 +7,67 @@
 // leaves registers: online softmax in fp32, operands in the 2-byte MFMA type.
 //
 // Work split: one workgroup = 4 waves = 128 query rows of one (sequence, head); each wave owns 32
-// query rows and walks the key/value tiles (64 keys) staged once per workgroup in LDS.
-//   S^T = K Q^T   : A = K rows from LDS (ds_read_b128, rows padded by 16 B: conflict-free),
-//                   B = Q^T from registers (each lane loaded its own query row from HBM once).
-//                   The 32x32 result has the QUERY on the lane and 16 keys in registers, so
-//                   row max / row sum are 16 register ops + one exchange with lane^32.
-//   O^T = V^T P^T : the score accumulators, converted pairwise to the operand type, ARE the B
-//                   operand (cdna_hip_programming.md §3 "accumulator tile as the next MFMA's
-//                   operand": k index of element j of lane half h = 16s + 8(j>>2) + 4h + (j&3));
-//                   A = V^T from an LDS image transposed while staging (2 x ds_read_b64 per step).
-//                   O^T again has the query on the lane, so the online-softmax rescale is lane-local.
-// Global loads of the next K/V tile are issued before the current tile's MFMAs and written to LDS
-// after them (issue-early / write-late, T14).
+// query rows and walks 64-key K/V tiles shared by the workgroup through LDS.
+//   S^T = K Q^T   : A = K rows from LDS (ds_read_b128), B = Q^T from registers (each lane loaded its own
+//                   query row once).  The 32x32 result has the QUERY on the lane and 16 keys in
+//                   registers: row max / row sum are register ops + one exchange with lane^32.
+//   O^T = V^T P^T : the score accumulators, converted pairwise to the operand type, ARE the B operand
+//                   (cdna_hip_programming.md §3 "accumulator tile as the next MFMA's operand": k index
+//                   of element j of lane half h = 16s + 8(j>>2) + 4h + (j&3)); A = V^T read straight
+//                   from the row-major V image with ds_read_b64_tr_b16 (T10): per 16-lane group a
+//                   4-key x 16-d block, lane i receives d-column i of 4 consecutive keys = elements
+//                   j..j+3 of that fragment.  O^T has the query on the lane: rescale is lane-local.
+// Data movement (the part that mattered): with register staging one tile per workgroup was in
+// flight and each 64-key step cost ~5.8 us against ~0.4 us of MFMA work (latency-bound, 13 % MFMA
+// utilisation).  K/V tiles now go HBM/L2 -> LDS by LDS-DMA into a 3-slot ring, two tiles ahead,
+// retired with counted vmcnt + barrier (same discipline as gemm8.hip; the DMA is inline asm so hipcc
+// does not drain it in front of every ds_read).  No ordinary global load lives in the loop: the key
+// mask is turned into an LDS bitmask up front.  LDS-DMA writes lane-linear, so the images are
+// unpadded and bank conflicts are removed by XOR-ing the 16-byte chunk index on the SOURCE side:
+//   K (ds_read_b128, 16 rows per lane group):  HD 96: chunk ^ ((row>>2)&3);  HD 64: chunk ^ ((row>>1)&7)
+//   V (tr reads, 4 rows x 64 B per half-wave):  HD 96: none (192-B rows);     HD 64: chunk ^ (((row>>1)&1)<<2)
+// Softmax diet: masks only on tiles that need them (wave-uniform), raw v_exp_f32 on log2-domain
+// scores, packed conversions, O rescale only when a row maximum moved, dead diagonal sub-tiles skipped.
 #include "common.h"
 #include "kernels.h"
 
 namespace lr {
 
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+template <typename OT> __device__ __forceinline__ unsigned pack2_fast(float lo, float hi);
+template <> __device__ __forceinline__ unsigned pack2_fast<F16>(float lo, float hi) {      // values in [0,1]: no saturation needed
+    const f32x2 x = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));
+}
+template <> __device__ __forceinline__ unsigned pack2_fast<BF16>(float lo, float hi) {
+    const f32x2 x = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+}
+
+constexpr int ATT_MAX_S = 8192;        // keys covered by the LDS bitmask
+
 template <typename OT, int HD, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 waves/SIMD: <= 256 unified registers, MFMA results stay in VGPRs
     constexpr int KT = 64;                 // keys per tile
     constexpr int KSTEPS = HD / 16;        // MFMA k-steps over the head dim
     constexpr int DT = HD / 32;            // 32-wide output tiles over the head dim
-    constexpr int KROW = HD * 2 + 16;      // K image row stride (bytes)
-    constexpr int VROW = KT * 2 + 8;       // V^T image row stride (bytes)
+    constexpr int ROW = HD * 2;            // image row stride (bytes), unpadded (LDS-DMA is lane-linear)
     constexpr int CH = HD / 8;             // 16-byte chunks per row
-    constexpr int LD_PER_T = KT * CH / 256;  // 16-byte loads per thread per operand tile (2 or 3)
+    constexpr int NPO = KT * CH / 256;     // DMA instructions per thread per operand tile (3 or 2)
+    constexpr int NPT = 2 * NPO;           // ... per K+V tile
+    constexpr int TILE = KT * ROW;         // bytes of one operand tile
+    constexpr int NSLOT = 3;
     static_assert(KT * CH % 256 == 0, "tile/threads mismatch");
 
-    __shared__ __attribute__((aligned(16))) char smem[KT * KROW + HD * VROW + KT * 4];
-    char* sK = smem;
-    char* sV = smem + KT * KROW;
-    float* sM = (float*)(smem + KT * KROW + HD * VROW);   // additive key mask (0 or -inf)
+    __shared__ __attribute__((aligned(16))) char smem[NSLOT * 2 * TILE + ATT_MAX_S / 8];
+    unsigned* sBits = (unsigned*)(smem + NSLOT * 2 * TILE);     // bit k = key k visible (before the causal rule)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lc = lane & 31, lh = lane >> 5;
     const int nqt = (p.S + 127) / 128;
     const int qt = nqt - 1 - (int)blockIdx.x;      // heavy (late) causal tiles first
@@ -52,135 +79,197 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     const unsigned short* Kp = (const unsigned short*)p.K + p.koff + head * HD;
     const unsigned short* Vp = (const unsigned short*)p.V + p.voff + head * HD;
 
-    // ---- Q fragments: lane (c,h) holds Q[q0+c][16*ks + 8h .. +7] ----
-    uint4 qf[KSTEPS];
-    {
-        const int qrow = min(q0 + lc, p.S - 1);
-        const unsigned short* src = Qp + (rowbase + qrow) * p.ldq + 8 * lh;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = *(const uint4*)(src + 16 * ks);
-    }
-
     // ---- key range of this workgroup ----
     int kbeg = 0, kend = p.S;
     if (CAUSAL) {
         kend = min(p.S, qt * 128 + 128);
         if (p.kmin) kbeg = (min(p.kmin[b * p.kmin_stride], p.S) / KT) * KT;
     }
+    const int ntiles = kbeg < kend ? (kend - kbeg + KT - 1) / KT : 0;
+
+    // ---- LDS-DMA: per-thread (row, swizzled chunk) of each piece; destination is lane-linear ----
+    typedef __attribute__((address_space(3))) char lds_char;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_char*)smem;
+    int drow[NPO], dkc[NPO], dvc[NPO];
+#pragma unroll
+    for (int it = 0; it < NPO; ++it) {
+        const int q = it * 256 + tid;
+        const int r = q / CH, c = q - r * CH;
+        drow[it] = r;
+        dkc[it] = (HD == 96 ? (c ^ ((r >> 2) & 3)) : (c ^ ((r >> 1) & 7))) * 8;
+        dvc[it] = (HD == 96 ? c : (c ^ (((r >> 1) & 1) << 2))) * 8;
+    }
+    auto issue = [&](int t) {            // tile t (keys kbeg + 64 t ..) -> slot t % 3
+        const int slot = t % NSLOT;
+        const int k0 = kbeg + t * KT;
+        const unsigned dstK = __builtin_amdgcn_readfirstlane(lds_base + slot * 2 * TILE + wave * 1024);
+#pragma unroll
+        for (int it = 0; it < NPO; ++it) {
+            const size_t key = rowbase + min(k0 + drow[it], p.S - 1);
+            const unsigned short* sk = Kp + key * p.ldq + dkc[it];
+            const unsigned short* sv = Vp + key * p.ldq + dvc[it];
+            const unsigned dk = dstK + it * 4096, dv = dk + TILE;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(sk), "s"(dk) : "memory");
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(sv), "s"(dv) : "memory");
+        }
+    };
+
+    // ---- prologue: first two tiles in flight, then the key bitmask and the Q fragments ----
+    if (ntiles > 0) issue(0);
+    if (ntiles > 1) issue(1);
+    {
+        const int w0 = kbeg / KT, w1 = (kend + KT - 1) / KT;
+        for (int w = w0 + wave; w < w1; w += 4) {
+            const int kk = w * KT + lane;
+            bool ok = kk < p.S;
+            if (ok && p.mask) ok = p.mask[(size_t)b * p.S + kk] != 0;
+            const unsigned long long bits = __ballot(ok);
+            if (lane == 0) { sBits[2 * w] = (unsigned)bits; sBits[2 * w + 1] = (unsigned)(bits >> 32); }
+        }
+    }
+    uint4 qf[KSTEPS];       // lane (c,h) holds Q[q0+c][16*ks + 8h .. +7]
+    {
+        const int qrow = min(q0 + lc, p.S - 1);
+        const unsigned short* src = Qp + (rowbase + qrow) * p.ldq + 8 * lh;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = *(const uint4*)(src + 16 * ks);
+    }
+    // Retire the ordinary loads HERE (vmcnt(0), expcnt/lgkmcnt untouched).  Otherwise hipcc puts its waits
+    // for the Q loads at their first use inside the loop, where a vmcnt(0) would drain the DMA ring on
+    // every iteration.  Tiles 0 and 1 are needed before the first MFMA anyway.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
 
     f32x16 o[DT];
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
-    const float sc = p.scale * 1.4426950408889634f;   // scores kept in log2 units
+    float m_run = -1e30f, l_run = 0.f;                // running max in log2 units, running denominator
+    const float sc = p.scale * 1.4426950408889634f;
     const int qpos = q0 + lc;
 
-    // staging assignment: thread -> (key = tid & 63, chunk = (tid >> 6) + 4*i)
-    const int skey = tid & 63;
-    uint4 kreg[LD_PER_T], vreg[LD_PER_T];
-    float mreg = 0.f;
-    auto gload = [&](int k0) {
-        const int key = min(k0 + skey, p.S - 1);
-        const unsigned short* ks_ = Kp + (rowbase + key) * p.ldq;
-        const unsigned short* vs_ = Vp + (rowbase + key) * p.ldq;
+    // fragment read offsets (bytes inside an operand tile)
+    int koff[2][KSTEPS];
 #pragma unroll
-        for (int i = 0; i < LD_PER_T; ++i) {
-            const int ch = (tid >> 6) + 4 * i;
-            kreg[i] = *(const uint4*)(ks_ + ch * 8);
-            vreg[i] = *(const uint4*)(vs_ + ch * 8);
-        }
-        if (tid < KT) {
-            const int kk = k0 + tid;
-            bool ok = kk < p.S;
-            if (ok && p.mask) ok = p.mask[(size_t)b * p.S + kk] != 0;
-            mreg = ok ? 0.f : -INFINITY;
-        }
-    };
-    auto lwrite = [&]() {
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int i = 0; i < LD_PER_T; ++i) {
-            const int ch = (tid >> 6) + 4 * i;
-            *(uint4*)(sK + skey * KROW + ch * 16) = kreg[i];
-            const unsigned short* e = (const unsigned short*)&vreg[i];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) *(unsigned short*)(sV + (ch * 8 + j) * VROW + skey * 2) = e[j];
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int row = kt * 32 + lc, c = 2 * ks + lh;
+            const int cs = HD == 96 ? (c ^ ((row >> 2) & 3)) : (c ^ ((row >> 1) & 7));
+            koff[kt][ks] = row * ROW + cs * 16;
         }
-        if (tid < KT) sM[tid] = mreg;
-    };
+    // transposed V read: group g = lane>>4 covers keys 4h + q (q = (lane&15)>>2) and d columns
+    // 16*(g&1) + 4*(lane&3) .. +3 of a 4-key x 16-d block; for HD 64 the 64-B window of rows 2,3 (mod 4) is swapped
+    const int vq = (lane & 15) >> 2;
+    int voff[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+        const int row = 4 * lh + vq;                                  // + multiples of 8 keys: (row>>1)&1 unchanged
+        const int win = HD == 96 ? d : (d ^ ((row >> 1) & 1));
+        voff[d] = row * ROW + win * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    }
 
-    if (kbeg < kend) gload(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += KT) {
-        lwrite();
-        __syncthreads();
-        if (k0 + KT < kend) gload(k0 + KT);
-
-        // ---- S^T tiles: keys kt*32 + [(r&3) + 8(r>>2) + 4h], query lc ----
-        f32x16 s[2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                const uint4 kf = *(const uint4*)(sK + (kt * 32 + lc) * KROW + (2 * ks + lh) * 16);
-                s[kt] = Op<OT>::mfma32(kf, qf[ks], s[kt]);
-            }
+    for (int t = 0; t < ntiles; ++t) {
+        const int k0 = kbeg + t * KT;
+        if (t + 2 < ntiles) {
+            issue(t + 2);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPT) : "memory");
+        } else if (t + 1 < ntiles) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPT) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        // ---- mask + online softmax (lane-local: this lane's query is lc) ----
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kl = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float t = s[kt][r] * sc + sM[kl];
-                if (CAUSAL && (k0 + kl > qpos)) t = -INFINITY;
-                s[kt][r] = t;
-                mx = fmaxf(mx, t);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
-        float rs = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = exp2f(s[kt][r] - m_new);
-                s[kt][r] = e;
-                rs += e;
-            }
-        rs += __shfl_xor(rs, 32, 64);
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
-#pragma unroll
-        for (int d = 0; d < DT; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        __syncthreads();                                  // tile t landed for every wave (and sBits on the first pass)
+        const char* sK = smem + (t % NSLOT) * 2 * TILE;
+        const char* sV = sK + TILE;
 
-        // ---- O^T += V^T P^T ----
+        // waves whose 32 queries all precede this tile have nothing to do (diagonal workgroup tiles)
+        const bool active = !CAUSAL || (k0 <= q0 + 31);
+        if (active) {
+            // ---- S^T tiles: keys kt*32 + [(r&3) + 8(r>>2) + 4h], query lc ----
+            f32x16 s[2];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                uint4 pf;
-                pf.x = pack2<OT>(s[kt][8 * st + 0], s[kt][8 * st + 1]);
-                pf.y = pack2<OT>(s[kt][8 * st + 2], s[kt][8 * st + 3]);
-                pf.z = pack2<OT>(s[kt][8 * st + 4], s[kt][8 * st + 5]);
-                pf.w = pack2<OT>(s[kt][8 * st + 6], s[kt][8 * st + 7]);
+                for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
 #pragma unroll
-                for (int d = 0; d < DT; ++d) {
-                    const char* vrow = sV + (d * 32 + lc) * VROW + (kt * 32 + 16 * st + 4 * lh) * 2;
-                    const uint2 v0 = *(const uint2*)(vrow);
-                    const uint2 v1 = *(const uint2*)(vrow + 16);
-                    uint4 vf;
-                    vf.x = v0.x; vf.y = v0.y; vf.z = v1.x; vf.w = v1.y;
-                    o[d] = Op<OT>::mfma32(vf, pf, o[d]);
+                for (int ks = 0; ks < KSTEPS; ++ks) {
+                    const uint4 kf = *(const uint4*)(sK + koff[kt][ks]);
+                    s[kt] = Op<OT>::mfma32(kf, qf[ks], s[kt]);
                 }
             }
-        __syncthreads();
+            // ---- masks only where a tile needs them (wave-uniform) ----
+            const unsigned blo = __builtin_amdgcn_readfirstlane(sBits[2 * (k0 / KT)]);
+            const unsigned bhi = __builtin_amdgcn_readfirstlane(sBits[2 * (k0 / KT) + 1]);
+            const bool need_causal = CAUSAL && (k0 + KT - 1 > q0);
+            if (need_causal || (blo & bhi) != 0xFFFFFFFFu) {
+                const unsigned wl = blo >> (4 * lh), wh = bhi >> (4 * lh);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kb = (r & 3) + 8 * (r >> 2);            // + 4*lh = key index inside the 32-key sub-tile
+                        bool ok = (((kt ? wh : wl) >> kb) & 1u) != 0;
+                        if (CAUSAL) ok = ok && (k0 + kt * 32 + kb + 4 * lh <= qpos);
+                        s[kt][r] = ok ? s[kt][r] : -INFINITY;
+                    }
+            }
+            // ---- online softmax in log2 units; this lane's query is lc ----
+            float mx = s[0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx * sc);
+            if (!__all(m_new == m_run)) {          // some row maximum moved: rescale (alpha == 1 on unchanged rows)
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int d = 0; d < DT; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            }
+            float rs = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -m_run));
+                    s[kt][r] = e;
+                    rs += e;
+                }
+            rs += __shfl_xor(rs, 32, 64);
+            l_run += rs;
+
+            // ---- O^T += V^T P^T ----
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    uint4 pf;
+                    pf.x = pack2_fast<OT>(s[kt][8 * st + 0], s[kt][8 * st + 1]);
+                    pf.y = pack2_fast<OT>(s[kt][8 * st + 2], s[kt][8 * st + 3]);
+                    pf.z = pack2_fast<OT>(s[kt][8 * st + 4], s[kt][8 * st + 5]);
+                    pf.w = pack2_fast<OT>(s[kt][8 * st + 6], s[kt][8 * st + 7]);
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) {
+                        // keys kt*32 + 16*st + 4h + {0..3} and +8, d columns d*32 + (lane&31)
+                        const char* vb = sV + (kt * 32 + 16 * st) * ROW + voff[d];
+                        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb));
+                        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * ROW));
+                        uint4 vf;
+                        const uint2 a = __builtin_bit_cast(uint2, v0), c = __builtin_bit_cast(uint2, v1);
+                        vf.x = a.x; vf.y = a.y; vf.z = c.x; vf.w = c.y;
+                        o[d] = Op<OT>::mfma32(vf, pf, o[d]);
+                    }
+                }
+        }
+        __syncthreads();                                  // every wave is done with slot t%3 before tile t+3 is issued into it
     }
 
     // ---- epilogue: O[q][d], d = dt*32 + (r&3) + 8(r>>2) + 4h : 4 consecutive d per register quad ----
@@ -209,6 +298,7 @@ void launch_attention(const AttnParams& p, int batch, int head_dim, bool causal,
     if (batch <= 0) return;
     if (p.ldq % 8 || p.qoff % 8 || p.koff % 8 || p.voff % 8 || p.ldo % 4)
         throw std::runtime_error("attention: operand rows must be 16-byte aligned");
+    if (p.S > ATT_MAX_S) throw std::runtime_error("attention: sequence length above 8192 is not supported");
     const bool f16 = operand_dtype == DT_F16;
     if (head_dim == 96 && causal) { f16 ? launch_one<F16, 96, true>(p, batch, st) : launch_one<BF16, 96, true>(p, batch, st); }
     else if (head_dim == 64 && !causal) { f16 ? launch_one<F16, 64, false>(p, batch, st) : launch_one<BF16, 64, false>(p, batch, st); }
