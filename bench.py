@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="MFMA operand type")
     ap.add_argument("--tile", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests)")
+    ap.add_argument("--all-ranks-on-device", type=int, default=-1, help="smoke test: put every rank on this one GPU")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,11 +115,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if a.all_ranks_on_device >= 0:
+        local = a.all_ranks_on_device
     torch.cuda.set_device(local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(a.backend)
 
     from llava_reward_amd import synth, _lib as L
     from llava_reward_amd.model import RewardModel
@@ -140,7 +147,11 @@ def main():
 
     def step():
         r = model.engine.forward(ids, mask, pix, sizes)
-        return gather_rewards(r) if world > 1 else r
+        if world == 1:
+            return r
+        if a.backend != "nccl":               # gloo smoke path: collectives on host tensors
+            return gather_rewards(r.cpu())
+        return gather_rewards(r)
 
     for _ in range(a.warmup):
         out = step()
@@ -157,7 +168,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if a.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(out).all(), "non-finite rewards"

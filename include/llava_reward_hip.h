@@ -101,6 +101,10 @@ int lr_set_gemm_tile(lr_handle h, int tile);
 /* ---- single-kernel entry points (per-kernel parity tests and microbenchmarks) ---- */
 int lr_op_gemm_bt(const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int lda, int ldw,
                   int ldc, int epi, int act, int operand_dtype, int tile, void* hip_stream);
+/* QKV projection with the fused RoPE epilogue: C_op[m][n] = rotate(A W^T) for n < rope_cols, pairs (2i, 2i+1) of each
+ * rope_hd-wide head rotated by cs[m][i] = (cos, sin); weight rows must already be pair-interleaved. */
+int lr_op_gemm_rope(const void* A, const void* W, void* C, const float* cs, int M, int N, int K, int rope_cols, int rope_hd,
+                    int operand_dtype, int tile, void* hip_stream);
 int lr_op_attention(const void* Q, const void* K, const void* V, void* O, const int64_t* mask, const int* kmin, int ldq,
                     int ldo, int qoff, int koff, int voff, int batch, int S, int heads, int head_dim, int causal,
                     float scale, int operand_dtype, void* hip_stream);

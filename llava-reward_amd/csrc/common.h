@@ -81,6 +81,7 @@ enum : int {
     EPI_OUT_F32 = 1,     // C_f32[m][n]  = acc + bias
     EPI_RESADD_F32 = 2,  // C_f32[m][n] += acc + bias
     EPI_SWIGLU_OP = 3,   // C_op[m][n/2] = silu(gate) * up, weight rows interleaved in blocks of 32
+    EPI_ROPE_OP = 4,     // C_op[m][n]   = RoPE(acc) for n < rope_cols (pair-interleaved head dims), acc elsewhere
 };
 enum : int { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU_ERF = 2 };
 enum : int { DT_BF16 = 0, DT_F16 = 1, DT_F32 = 2 };
@@ -93,6 +94,9 @@ struct GemmParams {
     int M, N, K;        // K multiple of 64, N multiple of the block's BN
     int lda, ldw, ldc;  // in elements
     int epi, act;
+    // EPI_ROPE_OP: cos/sin table [M][rope_hd/2][2] and the number of leading columns (q and k sections) to rotate
+    const float* rope_cs;
+    int rope_cols, rope_hd;
 };
 
 struct AttnParams {

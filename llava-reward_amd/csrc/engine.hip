@@ -199,7 +199,7 @@ void build_weight_table(lr_engine* e) {
         L.qkv_w = oalloc(e, (size_t)3 * D * D); L.o_w = oalloc(e, (size_t)D * D);
         L.gu_w = oalloc(e, (size_t)2 * I * D); L.down_w = oalloc(e, (size_t)D * I);
         vec_slot(e, p + "input_layernorm.weight", {D}, L.ln1, 0.05, 1.0);
-        add_slot(e, p + "self_attn.qkv_proj.weight", {3 * D, D}, L.qkv_w, D, D, od, PACK_PLAIN, 0.02, 0);
+        add_slot(e, p + "self_attn.qkv_proj.weight", {3 * D, D}, L.qkv_w, D, D, od, PACK_ROPE_QKV, 0.02, 0);
         add_slot(e, p + "self_attn.o_proj.weight", {D, D}, L.o_w, D, D, od, PACK_PLAIN, 0.02, 0);
         vec_slot(e, p + "post_attention_layernorm.weight", {D}, L.ln2, 0.05, 1.0);
         add_slot(e, p + "mlp.gate_up_proj.weight", {2 * I, D}, L.gu_w, D, D, od, PACK_SWIGLU, 0.02, 0);
@@ -239,7 +239,8 @@ void ensure_stage(lr_engine* e, size_t raw_bytes, size_t n_f32) {
 }
 
 void pack_slot(lr_engine* e, Slot& s, const float* src_f32) {
-    launch_pack(src_f32, s.dst, s.rows, s.cols, s.ld_dst, s.mode == PACK_TRANSPOSE ? s.cols : s.cols_dst, s.dst_dtype, s.mode, 0);
+    launch_pack(src_f32, s.dst, s.rows, s.cols, s.ld_dst, s.mode == PACK_TRANSPOSE ? s.cols : s.cols_dst, s.dst_dtype, s.mode, 0,
+                e->d.hidden, e->hd);
     s.provided = true;
 }
 
@@ -278,7 +279,7 @@ template <typename F> int guarded(lr_engine* e, F&& f) {
 
 void gemm(lr_engine* e, hipStream_t st, const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int lda,
           int ldw, int ldc, int epi, int act) {
-    GemmParams p{A, W, C, bias, M, N, K, lda, ldw, ldc, epi, act};
+    GemmParams p{A, W, C, bias, M, N, K, lda, ldw, ldc, epi, act, nullptr, 0, 0};
     launch_gemm_bt(p, e->op_dt, e->gemm_tile, st);
 }
 
@@ -509,8 +510,15 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
         for (int l = 0; l < nl; ++l) {
             const DecLayer& L = h->dl[l];
             launch_norm_rows(h->x, L.ln1, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st);
-            gemm(h, st, h->h, L.qkv_w, h->qkv32, nullptr, Rl, 3 * D, D, D, D, 3 * D, EPI_OUT_F32, ACT_NONE);
-            launch_rope_split(h->qkv32, h->cs, h->qkv, Rl, D, d.heads, h->op_dt, st);
+            {   // qkv projection with RoPE on q,k: fused in the GEMM epilogue when the deep-pipelined kernel runs
+                GemmParams gp{h->h, L.qkv_w, h->qkv, nullptr, Rl, 3 * D, D, D, D, 3 * D, EPI_ROPE_OP, ACT_NONE, h->cs, 2 * D, h->hd};
+                if (gemm_bt_is_deep(gp, h->gemm_tile)) {
+                    launch_gemm_bt(gp, h->op_dt, h->gemm_tile, st);
+                } else {
+                    gemm(h, st, h->h, L.qkv_w, h->qkv32, nullptr, Rl, 3 * D, D, D, D, 3 * D, EPI_OUT_F32, ACT_NONE);
+                    launch_rope_split(h->qkv32, h->cs, h->qkv, Rl, D, d.heads, h->op_dt, st);
+                }
+            }
             AttnParams ap{h->qkv, h->qkv, h->qkv, h->att, attention_mask, h->tstat + 1, 4, 3 * D, D, 0, D, 2 * D, S, d.heads, ascale};
             launch_attention(ap, B, h->hd, true, h->op_dt, st);
             gemm(h, st, h->att, L.o_w, h->x, nullptr, Rl, D, D, D, D, D, EPI_RESADD_F32, ACT_NONE);
@@ -561,7 +569,15 @@ static int op_guard(const std::function<void()>& f) {
 int lr_op_gemm_bt(const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int lda, int ldw, int ldc,
                   int epi, int act, int operand_dtype, int tile, void* hip_stream) {
     return op_guard([&] {
-        GemmParams p{A, W, C, bias, M, N, K, lda, ldw, ldc, epi, act};
+        GemmParams p{A, W, C, bias, M, N, K, lda, ldw, ldc, epi, act, nullptr, 0, 0};
+        launch_gemm_bt(p, operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16, tile, (hipStream_t)hip_stream);
+    });
+}
+
+int lr_op_gemm_rope(const void* A, const void* W, void* C, const float* cs, int M, int N, int K, int rope_cols, int rope_hd,
+                    int operand_dtype, int tile, void* hip_stream) {
+    return op_guard([&] {
+        GemmParams p{A, W, C, nullptr, M, N, K, K, K, N, EPI_ROPE_OP, ACT_NONE, cs, rope_cols, rope_hd};
         launch_gemm_bt(p, operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16, tile, (hipStream_t)hip_stream);
     });
 }

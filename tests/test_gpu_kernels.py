@@ -109,6 +109,27 @@ def test_gemm_swiglu(lib, dt, tile):
     assert (err <= ulp * ref.abs() + 1e-4).all(), err.max().item()
 
 
+@pytest.mark.parametrize("dt", DTS, ids=[d[0] for d in DTS])
+def test_gemm_fused_rope_epilogue(lib, dt):
+    """QKV projection + RoPE in the epilogue; q/k head dims pair-interleaved (reference dims i, i+hd/2 at 2i, 2i+1)."""
+    _, code, tdt, ulp = dt
+    M, D, hd, K = 700, 384, 96, 256          # rope_cols = 2D = 768: multiple of the 256-wide tile and of the head
+    N, half = 3 * D, hd // 2
+    A = rnd((M, K), 31).to(tdt)
+    W = rnd((N, K), 32, 0.1).to(tdt)
+    ang = rnd((M, half), 33, 3.0)
+    cs = torch.stack([torch.cos(ang) * 1.19, torch.sin(ang) * 1.19], dim=-1).contiguous()      # [M, half, 2]
+    y = (A.float() @ W.float().t())
+    ref = y.clone()
+    qk = y[:, :2 * D].view(M, 2 * D // hd, half, 2)
+    c, s_ = cs[:, None, :, 0], cs[:, None, :, 1]
+    ref[:, :2 * D] = torch.stack([qk[..., 0] * c - qk[..., 1] * s_, qk[..., 1] * c + qk[..., 0] * s_], dim=-1).reshape(M, 2 * D)
+    out = torch.zeros(M, N, device="cuda", dtype=tdt)
+    assert lib.lr_op_gemm_rope(P(A), P(W), P(out), P(cs), M, N, K, 2 * D, hd, code, 5, stream()) == 0
+    err = (out.float() - ref).abs()
+    assert (err <= ulp * ref.abs() + 2e-4).all(), err.max().item()
+
+
 def _attn_ref(q, k, v, mask, causal, scale):
     # q,k,v [B,H,S,hd] fp32; mask [B,S] or None
     B, H, S, _ = q.shape
