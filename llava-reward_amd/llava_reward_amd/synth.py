@@ -352,3 +352,179 @@ def synth_batch(cfg: RewardConfig, seed: int, caption_lens: List[int], grids, ma
             pix[b, :ncrops[b]] = synth_pixels(seed, f"pixel_values.{b}", (ncrops[b], 3, 336, 336))
     sizes = np.array([[336 * hc, 336 * wc] for hc, wc in grids], dtype=np.int64)
     return dict(input_ids=ids, attention_mask=mask, pixel_values=pix, image_sizes=sizes)
+
+
+# ----------------------------------------------------------------------------------------------
+# LLaVA-1.6 (LlavaNext + Mistral) reward model: rw_model_general_preference.py:372-375 branch
+# ----------------------------------------------------------------------------------------------
+LLAVA_PINPOINTS = ((336, 672), (672, 336), (672, 672), (1008, 336), (336, 1008))
+
+
+@dataclasses.dataclass
+class LlavaConfig:
+    """llava-hf/llava-v1.6-mistral-7b-hf geometry (public config.json; not in the reference tree)."""
+    vocab_size: int = 32064
+    hidden: int = 4096
+    intermediate: int = 14336
+    layers: int = 32
+    heads: int = 32
+    kv_heads: int = 8
+    head_dim: int = 128
+    rms_eps: float = 1e-5
+    rope_theta: float = 1000000.0
+    clip: ClipConfig = dataclasses.field(default_factory=ClipConfig)
+    image_token_id: int = 32000
+    pad_token_id: int = 32001
+    pinpoints: Tuple[Tuple[int, int], ...] = LLAVA_PINPOINTS
+    is_general_preference: bool = False
+    add_cross_attention: bool = False          # the llava branch has no SkipCA (rw_model:376-397)
+    value_head_dim: int = 1
+    general_preference_tau: float = 0.1
+
+    def __post_init__(self):
+        if not self.is_general_preference:
+            self.value_head_dim = 1
+        if self.add_cross_attention:
+            raise ValueError("add_cross_attention=True raises in the reference for llava (rw_model:315: no config.hidden_size)")
+
+    def to_json(self) -> dict:
+        d = dataclasses.asdict(self)
+        d["pinpoints"] = [list(p) for p in self.pinpoints]
+        d["backbone"] = "llava"
+        return d
+
+    @staticmethod
+    def from_json(d: dict) -> "LlavaConfig":
+        d = dict(d)
+        d.pop("backbone", None)
+        clip = ClipConfig(**d.pop("clip"))
+        d["pinpoints"] = tuple(tuple(p) for p in d["pinpoints"])
+        return LlavaConfig(clip=clip, **d)
+
+
+def llava_full_config(**kw) -> LlavaConfig:
+    return LlavaConfig(**kw)
+
+
+def llava_tiny_config(**kw) -> LlavaConfig:
+    base = dict(vocab_size=1024, hidden=512, intermediate=768, layers=2, heads=4, kv_heads=2, head_dim=128,
+                image_token_id=1000, pad_token_id=1001, clip=ClipConfig(hidden=128, heads=2, mlp=512, layers_used=2))
+    base.update(kw)
+    return LlavaConfig(**base)
+
+
+def select_best_resolution(original_size, possible_resolutions):
+    """transformers.image_processing_utils.select_best_resolution (third party, restated)."""
+    oh, ow = original_size
+    best, max_eff, min_waste = None, 0, float("inf")
+    for h, w in possible_resolutions:
+        scale = min(w / ow, h / oh)
+        dw, dh = int(ow * scale), int(oh * scale)
+        eff = min(dw * dh, ow * oh)
+        waste = w * h - eff
+        if eff > max_eff or (eff == max_eff and waste < min_waste):
+            max_eff, min_waste, best = eff, waste, (h, w)
+    return best
+
+
+def llava_geometry(h: int, w: int, pinpoints=LLAVA_PINPOINTS, crop: int = 336, g: int = 24):
+    """(grid_h, grid_w, r0, r1, c0, c1, n_tokens) of one image of original size (h, w): the anyres grid picked by
+    select_best_resolution, the rows/cols of the (grid_h*g) x (grid_w*g) feature map that survive unpad_image
+    (modeling_llava_next.py:109-146) and the packed token count = g*g + rows*(cols+1)."""
+    bh, bw = select_best_resolution((h, w), pinpoints)
+    gh, gw = bh // crop, bw // crop
+    ch, cw = gh * g, gw * g
+    r0, r1, c0, c1 = 0, ch, 0, cw
+    if w / h > cw / ch:
+        nh = int(round(h * (cw / w), 7))
+        pad = (ch - nh) // 2
+        r0, r1 = pad, ch - pad
+    else:
+        nw = int(round(w * (ch / h), 7))
+        pad = (cw - nw) // 2
+        c0, c1 = pad, cw - pad
+    return gh, gw, r0, r1, c0, c1, g * g + (r1 - r0) * (c1 - c0 + 1)
+
+
+LLAVA_CLIP_PREFIX = "vision_tower.vision_model."
+
+
+def llava_weight_specs(cfg: LlavaConfig) -> List[Tuple[str, Tuple[int, ...], float, float]]:
+    """Checkpoint (transformers 4.50 era) names of llava-v1.6-mistral-7b-hf + the reward head."""
+    c = cfg.clip
+    D, I, hd = cfg.hidden, cfg.intermediate, cfg.head_dim
+    s: List[Tuple[str, Tuple[int, ...], float, float]] = []
+    s.append(("language_model.model.embed_tokens.weight", (cfg.vocab_size, D), 0.02, 0.0))
+    p = LLAVA_CLIP_PREFIX
+    s.append((p + "embeddings.class_embedding", (c.hidden,), 0.02, 0.0))
+    s.append((p + "embeddings.patch_embedding.weight", (c.hidden, 3, c.patch, c.patch), 0.02, 0.0))
+    s.append((p + "embeddings.position_embedding.weight", (c.tokens, c.hidden), 0.02, 0.0))
+    s.append((p + "pre_layrnorm.weight", (c.hidden,), 0.05, 1.0))
+    s.append((p + "pre_layrnorm.bias", (c.hidden,), 0.02, 0.0))
+    for l in range(c.layers_used):
+        q = f"{p}encoder.layers.{l}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s.append((q + f"self_attn.{nm}.weight", (c.hidden, c.hidden), 0.02, 0.0))
+            s.append((q + f"self_attn.{nm}.bias", (c.hidden,), 0.02, 0.0))
+        s.append((q + "layer_norm1.weight", (c.hidden,), 0.05, 1.0))
+        s.append((q + "layer_norm1.bias", (c.hidden,), 0.02, 0.0))
+        s.append((q + "mlp.fc1.weight", (c.mlp, c.hidden), 0.02, 0.0))
+        s.append((q + "mlp.fc1.bias", (c.mlp,), 0.02, 0.0))
+        s.append((q + "mlp.fc2.weight", (c.hidden, c.mlp), 0.02, 0.0))
+        s.append((q + "mlp.fc2.bias", (c.hidden,), 0.02, 0.0))
+        s.append((q + "layer_norm2.weight", (c.hidden,), 0.05, 1.0))
+        s.append((q + "layer_norm2.bias", (c.hidden,), 0.02, 0.0))
+    s.append(("multi_modal_projector.linear_1.weight", (D, c.hidden), 0.02, 0.0))
+    s.append(("multi_modal_projector.linear_1.bias", (D,), 0.02, 0.0))
+    s.append(("multi_modal_projector.linear_2.weight", (D, D), 0.02, 0.0))
+    s.append(("multi_modal_projector.linear_2.bias", (D,), 0.02, 0.0))
+    s.append(("image_newline", (D,), 0.02, 0.0))
+    for l in range(cfg.layers):
+        q = f"language_model.model.layers.{l}."
+        s.append((q + "input_layernorm.weight", (D,), 0.05, 1.0))
+        s.append((q + "self_attn.q_proj.weight", (cfg.heads * hd, D), 0.02, 0.0))
+        s.append((q + "self_attn.k_proj.weight", (cfg.kv_heads * hd, D), 0.02, 0.0))
+        s.append((q + "self_attn.v_proj.weight", (cfg.kv_heads * hd, D), 0.02, 0.0))
+        s.append((q + "self_attn.o_proj.weight", (D, cfg.heads * hd), 0.02, 0.0))
+        s.append((q + "post_attention_layernorm.weight", (D,), 0.05, 1.0))
+        s.append((q + "mlp.gate_proj.weight", (I, D), 0.02, 0.0))
+        s.append((q + "mlp.up_proj.weight", (I, D), 0.02, 0.0))
+        s.append((q + "mlp.down_proj.weight", (D, I), 0.02, 0.0))
+    s.append(("language_model.model.norm.weight", (D,), 0.05, 1.0))
+    s.append(("value_head.weight", (cfg.value_head_dim, D), 1.0 / math.sqrt(D), 0.0))
+    return s
+
+
+def llava_make_weights(cfg: LlavaConfig, seed: int) -> Dict[str, np.ndarray]:
+    return {n: gen_tensor(seed, n, sh, std, off) for n, sh, std, off in llava_weight_specs(cfg)}
+
+
+def llava_synth_batch(cfg: LlavaConfig, seed: int, caption_lens: List[int], image_sizes, max_crops: int = None,
+                      with_pixels: bool = True):
+    """inputs_batch of the llava branch: input_ids (image slots = image_token_id, already expanded by the
+    processor), attention_mask (left padded), pixel_values [B, P, 3, 336, 336] (crop 0 = base, zero-padded to P),
+    image_sizes [B, 2] = ORIGINAL (h, w)."""
+    batch = len(caption_lens)
+    geo = [llava_geometry(int(h), int(w), cfg.pinpoints) for h, w in image_sizes]
+    ncrops = [1 + g[0] * g[1] for g in geo]
+    P = max_crops if max_crops is not None else max(ncrops)
+    lo, hi = 3, min(cfg.image_token_id, cfg.pad_token_id) - 1
+    rows = []
+    for b, n in enumerate(caption_lens):
+        t = tensor_seed(seed, f"caption.{b}")
+        cap = np.array([lo + splitmix64_scalar((t + i) & MASK64) % (hi - lo) for i in range(n)], dtype=np.int64)
+        rows.append(np.concatenate([np.array([1, 5, 6], dtype=np.int64), np.full(geo[b][6], cfg.image_token_id, dtype=np.int64),
+                                    np.array([13], dtype=np.int64), cap, np.array([2], dtype=np.int64)]))
+    S = max(len(r) for r in rows)
+    ids = np.full((batch, S), cfg.pad_token_id, dtype=np.int64)
+    mask = np.zeros((batch, S), dtype=np.int64)
+    for b, row in enumerate(rows):
+        ids[b, S - len(row):] = row
+        mask[b, S - len(row):] = 1
+    pix = None
+    if with_pixels:
+        pix = np.zeros((batch, P, 3, 336, 336), dtype=np.float32)
+        for b in range(batch):
+            pix[b, :ncrops[b]] = synth_pixels(seed, f"pixel_values.{b}", (ncrops[b], 3, 336, 336))
+    sizes = np.array([[int(h), int(w)] for h, w in image_sizes], dtype=np.int64)
+    return dict(input_ids=ids, attention_mask=mask, pixel_values=pix, image_sizes=sizes)

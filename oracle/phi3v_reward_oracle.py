@@ -38,7 +38,7 @@ def _lin(x, w, b=None, opr=Ident):
 
 
 # ---------------------------------------------------------------------------------- CLIP tower
-def clip_tower(W: Dict[str, torch.Tensor], pixels: torch.Tensor, ccfg, opr=Ident) -> torch.Tensor:
+def clip_tower(W: Dict[str, torch.Tensor], pixels: torch.Tensor, ccfg, opr=Ident, prefix: str = CLIP_PREFIX) -> torch.Tensor:
     """CLIP-ViT patch features of `pixels [N,3,336,336]` -> [N, 576, hidden].
 
     Restates UT:266-273 (patched get_img_features == hidden_states[-2][:,1:] of PHI:208-219):
@@ -46,7 +46,7 @@ def clip_tower(W: Dict[str, torch.Tensor], pixels: torch.Tensor, ccfg, opr=Ident
     CLIP embeddings: Conv2d(3,H,k=14,s=14,bias=False) patches, class token first, learned
     position embedding added; encoder layer: x += out_proj(MHA(LN1 x)); x += fc2(quick_gelu(fc1(LN2 x)))
     with attention scale head_dim**-0.5 and quick_gelu(x) = x*sigmoid(1.702x) (PHI:68-83 config)."""
-    p = CLIP_PREFIX
+    p = prefix
     N = pixels.shape[0]
     H, nh, hd = ccfg.hidden, ccfg.heads, ccfg.head_dim
     wpe = W[p + "embeddings.patch_embedding.weight"]

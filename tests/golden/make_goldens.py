@@ -136,6 +136,69 @@ def run_case(ref, name, cfg, seed, caption_lens, grids, max_crops, taps=True):
     return out
 
 
+def canon_llava_name(name: str) -> str:
+    """transformers 5.x module tree -> checkpoint (4.50 era) tensor names of llava-v1.6-*-hf."""
+    n = name
+    if n.startswith("model."):
+        n = n[len("model."):]
+    n = n.replace("language_model.layers.", "language_model.model.layers.")
+    n = n.replace("language_model.embed_tokens.", "language_model.model.embed_tokens.")
+    n = n.replace("language_model.norm.", "language_model.model.norm.")
+    if n.startswith("vision_tower.") and not n.startswith("vision_tower.vision_model."):
+        n = n.replace("vision_tower.", "vision_tower.vision_model.", 1)
+    return n
+
+
+def run_llava_case(name, cfg, seed, caption_lens, image_sizes, max_crops):
+    """Reference custom_forward, model_type='llava' (rw_model_general_preference.py:372-375,407-448)."""
+    import transformers
+    from transformers import CLIPVisionConfig, LlavaNextConfig, LlavaNextForConditionalGeneration, MistralConfig
+    sys.path.insert(0, "/root/reference")
+    from llava_reward.models.rw_model_general_preference import _get_reward_model, LlamaRMSNorm
+    c = cfg.clip
+    vcfg = CLIPVisionConfig(hidden_size=c.hidden, intermediate_size=c.mlp, num_hidden_layers=c.layers_used + 1,
+                            num_attention_heads=c.heads, image_size=c.image, patch_size=c.patch, hidden_act="quick_gelu",
+                            layer_norm_eps=c.ln_eps, projection_dim=64)
+    tcfg = MistralConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden, intermediate_size=cfg.intermediate,
+                         num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads, num_key_value_heads=cfg.kv_heads,
+                         head_dim=cfg.head_dim, rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta, sliding_window=None,
+                         max_position_embeddings=32768, use_cache=False, pad_token_id=cfg.pad_token_id)
+    hcfg = LlavaNextConfig(vision_config=vcfg, text_config=tcfg, image_grid_pinpoints=[list(p) for p in cfg.pinpoints],
+                           image_token_index=cfg.image_token_id, vision_feature_layer=-2,
+                           vision_feature_select_strategy="default", projector_hidden_act="gelu")
+    hcfg._attn_implementation = "eager"
+    cls = _get_reward_model(LlavaNextForConditionalGeneration, LlavaNextForConditionalGeneration, RMSNorm_class=LlamaRMSNorm,
+                            RMSNorm_class_eps=1e-5, is_general_preference=cfg.is_general_preference,
+                            add_cross_attention=False, value_head_dim=cfg.value_head_dim, model_type="llava")
+    model = cls(hcfg)
+    model.eval()
+    specs = {n: (sh, std, off) for n, sh, std, off in synth.llava_weight_specs(cfg)}
+    used = set()
+    with torch.no_grad():
+        for pname, p in model.named_parameters():
+            cn = canon_llava_name(pname)
+            if cn in specs:
+                sh, std, off = specs[cn]
+                assert tuple(p.shape) == tuple(sh), (pname, p.shape, sh)
+                p.copy_(torch.from_numpy(synth.gen_tensor(seed, cn, sh, std, off)))
+                used.add(cn)
+    missing = set(specs) - used
+    assert not missing, f"weights not consumed by the reference: {sorted(missing)[:6]}"
+    batch = synth.llava_synth_batch(cfg, seed, caption_lens, image_sizes, max_crops=max_crops)
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    t0 = time.time()
+    with torch.no_grad():
+        reward, _ = model.custom_forward(inputs_batch=tb)
+    dt = time.time() - t0
+    print(f"[{name}] reference llava custom_forward {dt:.1f}s reward={reward.flatten().tolist()}", flush=True)
+    out = {"name": name, "backbone": "llava", "config": cfg.to_json(), "seed": seed, "caption_lens": caption_lens,
+           "image_sizes": [list(x) for x in image_sizes], "max_crops": max_crops, "reward": reward.float().tolist(),
+           "transformers": transformers.__version__, "torch": torch.__version__, "dtype": "float32"}
+    with open(os.path.join(HERE, f"{name}.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    return out
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "small"
     torch.manual_seed(0)
@@ -147,6 +210,12 @@ def main():
         run_case(ref, "ref_small_bt_noca", C(add_cross_attention=False), 4321, [4], (1, 1), None)
         run_case(ref, "ref_small_bt_ca_ragged", C(), 99, [5, 9], [(1, 1), (1, 2)], 3)
         run_case(ref, "ref_small_gpm4_ca", C(is_general_preference=True, value_head_dim=4), 7, [2], (1, 1), None)
+    elif which == "llava":
+        C = synth.llava_tiny_config
+        run_llava_case("ref_llava_tiny_bt", C(), 11, [6, 3], [(336, 336), (336, 336)], None)
+        run_llava_case("ref_llava_tiny_gpm2", C(is_general_preference=True, value_head_dim=2), 12, [5, 9], [(512, 640), (336, 336)], 5)
+        run_llava_case("ref_llava_tiny_wide", C(), 13, [4], [(300, 900)], None)
+        run_llava_case("ref_llava_tiny_tall", C(layers=3), 14, [2, 7], [(400, 300), (672, 672)], 5)
     elif which == "full":
         run_case(ref, "ref_full_bt_ca", synth.full_config(), 1234, [128], (4, 4), None)
     elif which == "full_gpm":

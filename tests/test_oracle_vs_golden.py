@@ -74,3 +74,26 @@ def test_token_count_kats():
     h, w, _ = synth.hd_target_size(336, 336, 4)
     assert synth.num_img_tokens(h, w) == 757
     assert synth.num_img_tokens(336, 336) == 313 and synth.num_img_tokens(336, 672) == 457
+
+
+LLAVA_CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref_llava_*.json")))
+
+
+@pytest.mark.parametrize("path", LLAVA_CASES, ids=[os.path.basename(p)[:-5] for p in LLAVA_CASES])
+def test_llava_oracle_matches_reference(path):
+    """oracle/llava_next_reward_oracle.py vs the reference's custom_forward (model_type='llava') run on the
+    container's transformers LlavaNext/Mistral/CLIP (tests/golden/make_goldens.py llava)."""
+    from oracle import llava_next_reward_oracle as lorc
+    g = json.load(open(path))
+    cfg = synth.LlavaConfig.from_json(g["config"])
+    W = orc.weights_to_torch(synth.llava_make_weights(cfg, g["seed"]))
+    batch = synth.llava_synth_batch(cfg, g["seed"], g["caption_lens"], [tuple(x) for x in g["image_sizes"]], max_crops=g["max_crops"])
+    r = lorc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"])
+    ref = np.array(g["reward"], dtype=np.float32).reshape(r.shape)
+    assert np.abs(r.numpy() - ref).max() < TOL, (r, ref)
+
+
+def test_llava_geometry_kats():
+    # 336x336 -> 1x2 grid, 3 crops, 1176 tokens (SURVEY.md §8c probe of the reference's llava branch)
+    assert synth.llava_geometry(336, 336) == (1, 2, 0, 24, 12, 36, 1176)
+    assert synth.select_best_resolution((512, 640), synth.LLAVA_PINPOINTS) == (672, 672)
