@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LR_ABI_VERSION 1
+#define LR_ABI_VERSION 2
 
 enum { LR_OK = 0, LR_EINVAL = 1, LR_EHIP = 2, LR_ESTATE = 3, LR_ENOTFOUND = 4, LR_ENOMEM = 5 };
 enum { LR_DT_BF16 = 0, LR_DT_F16 = 1, LR_DT_F32 = 2 };
@@ -39,6 +39,8 @@ enum { LR_DT_BF16 = 0, LR_DT_F16 = 1, LR_DT_F32 = 2 };
 enum { LR_FWD_TRAINING_LAST_TOKEN = 1 };   /* self.training reward selection (rw_model:410-415,429-434) */
 
 #define LR_MAX_HALF_HEAD 64
+#define LR_MAX_PINPOINTS 8
+enum { LR_BACKBONE_PHI3V = 0, LR_BACKBONE_LLAVA_NEXT = 1 };
 
 typedef struct lr_engine* lr_handle;
 
@@ -60,6 +62,12 @@ typedef struct lr_model_desc {
     /* capacity: workspace is sized for these at lr_finalize */
     int32_t max_batch, max_seq, max_crops;    /* max_crops counts the global crop */
     int32_t operand_dtype;        /* LR_DT_BF16 or LR_DT_F16: element type of MFMA operands */
+    /* backbone (ABI 2).  LR_BACKBONE_PHI3V: fields above as in Phi3VConfig, kv_heads = heads, head_dim = hidden/heads.
+     * LR_BACKBONE_LLAVA_NEXT (rw_model_general_preference.py:372-375; transformers LlavaNext + Mistral): GQA decoder
+     * with explicit head_dim, image slots marked by image_token_id, positions = arange(S), anyres grid pinpoints
+     * (h, w) pairs, no SkipCA.  Weight names are those of the llava-v1.6-*-hf checkpoints. */
+    int32_t backbone, kv_heads, head_dim, image_token_id, n_pinpoints;
+    int32_t pinpoints[2 * LR_MAX_PINPOINTS];
 } lr_model_desc;
 
 int lr_abi_version(void);
@@ -84,7 +92,7 @@ size_t lr_workspace_bytes(lr_handle h);
 
 /* One scoring pass.  input_ids/attention_mask: device int64 [B,S] (image slots are negative ids);
  * pixel_values: device [B, n_crops, 3, img, img] of pix_dtype (F32 or BF16); image_sizes: HOST int64
- * [B,2] = HD-transformed (h, w); rewards_out: device fp32 [B, value_head_dim]. */
+ * [B,2] = HD-transformed (h, w) for Phi-3-V, ORIGINAL (h, w) for LLaVA; rewards_out: device fp32 [B, value_head_dim]. */
 int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_mask, const void* pixel_values,
                int pix_dtype, const int64_t* image_sizes_host, int B, int S, int n_crops, int flags, float* rewards_out,
                void* hip_stream);
@@ -107,7 +115,7 @@ int lr_op_gemm_rope(const void* A, const void* W, void* C, const float* cs, int 
                     int operand_dtype, int tile, void* hip_stream);
 int lr_op_attention(const void* Q, const void* K, const void* V, void* O, const int64_t* mask, const int* kmin, int ldq,
                     int ldo, int qoff, int koff, int voff, int batch, int S, int heads, int head_dim, int causal,
-                    float scale, int operand_dtype, void* hip_stream);
+                    int kv_group, float scale, int operand_dtype, void* hip_stream);   /* kv_group = query heads per K/V head */
 int lr_op_norm_rows(const float* x, const float* w, const float* b, void* y, int rows, int H, float eps,
                     int operand_dtype, void* hip_stream);
 int lr_op_synth_fill(float* out, size_t n, uint64_t seed, const char* name, float std, float offset, int bf16_round,

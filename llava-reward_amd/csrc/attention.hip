@@ -24,8 +24,8 @@
 // does not drain it in front of every ds_read).  No ordinary global load lives in the loop: the key
 // mask is turned into an LDS bitmask up front.  LDS-DMA writes lane-linear, so the images are
 // unpadded and bank conflicts are removed by XOR-ing the 16-byte chunk index on the SOURCE side:
-//   K (ds_read_b128, 16 rows per lane group):  HD 96: chunk ^ ((row>>2)&3);  HD 64: chunk ^ ((row>>1)&7)
-//   V (tr reads, 4 rows x 64 B per half-wave):  HD 96: none (192-B rows);     HD 64: chunk ^ (((row>>1)&1)<<2)
+//   K (ds_read_b128, 16 rows per lane group):  HD 96: chunk ^ ((row>>2)&3);  HD 64: chunk ^ ((row>>1)&7);       HD 128: chunk ^ (row&15)
+//   V (tr reads, 4 rows x 64 B per half-wave):  HD 96: none (192-B rows);     HD 64: chunk ^ (((row>>1)&1)<<2);  HD 128: chunk ^ ((row&3)<<2)
 // Softmax diet: masks only on tiles that need them (wave-uniform), raw v_exp_f32 on log2-domain
 // scores, packed conversions, O rescale only when a row maximum moved, dead diagonal sub-tiles skipped.
 #include "common.h"
@@ -76,8 +76,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
     const size_t rowbase = (size_t)b * p.S;
 
     const unsigned short* Qp = (const unsigned short*)p.Q + p.qoff + head * HD;
-    const unsigned short* Kp = (const unsigned short*)p.K + p.koff + head * HD;
-    const unsigned short* Vp = (const unsigned short*)p.V + p.voff + head * HD;
+    const int kvh = head / p.kv_group;                 // GQA: several query heads share one key/value head
+    const unsigned short* Kp = (const unsigned short*)p.K + p.koff + kvh * HD;
+    const unsigned short* Vp = (const unsigned short*)p.V + p.voff + kvh * HD;
 
     // ---- key range of this workgroup ----
     int kbeg = 0, kend = p.S;
@@ -96,8 +97,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
         const int q = it * 256 + tid;
         const int r = q / CH, c = q - r * CH;
         drow[it] = r;
-        dkc[it] = (HD == 96 ? (c ^ ((r >> 2) & 3)) : (c ^ ((r >> 1) & 7))) * 8;
-        dvc[it] = (HD == 96 ? c : (c ^ (((r >> 1) & 1) << 2))) * 8;
+        dkc[it] = (HD == 96 ? (c ^ ((r >> 2) & 3)) : HD == 64 ? (c ^ ((r >> 1) & 7)) : (c ^ (r & 15))) * 8;
+        dvc[it] = (HD == 96 ? c : HD == 64 ? (c ^ (((r >> 1) & 1) << 2)) : (c ^ ((r & 3) << 2))) * 8;
     }
     auto issue = [&](int t) {            // tile t (keys kbeg + 64 t ..) -> slot t % 3
         const int slot = t % NSLOT;
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const int row = kt * 32 + lc, c = 2 * ks + lh;
-            const int cs = HD == 96 ? (c ^ ((row >> 2) & 3)) : (c ^ ((row >> 1) & 7));
+            const int cs = HD == 96 ? (c ^ ((row >> 2) & 3)) : HD == 64 ? (c ^ ((row >> 1) & 7)) : (c ^ (row & 15));
             koff[kt][ks] = row * ROW + cs * 16;
         }
     // transposed V read: group g = lane>>4 covers keys 4h + q (q = (lane&15)>>2) and d columns
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
         const int row = 4 * lh + vq;                                  // + multiples of 8 keys: (row>>1)&1 unchanged
-        const int win = HD == 96 ? d : (d ^ ((row >> 1) & 1));
+        const int win = HD == 96 ? d : HD == 64 ? (d ^ ((row >> 1) & 1)) : (d ^ (row & 3));
         voff[d] = row * ROW + win * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
     }
 
@@ -299,12 +300,14 @@ void launch_attention(const AttnParams& p, int batch, int head_dim, bool causal,
     if (p.ldq % 8 || p.qoff % 8 || p.koff % 8 || p.voff % 8 || p.ldo % 4)
         throw std::runtime_error("attention: operand rows must be 16-byte aligned");
     if (p.S > ATT_MAX_S) throw std::runtime_error("attention: sequence length above 8192 is not supported");
+    if (p.kv_group < 1 || p.heads % p.kv_group) throw std::runtime_error("attention: heads must be a multiple of kv_group");
     const bool f16 = operand_dtype == DT_F16;
     if (head_dim == 96 && causal) { f16 ? launch_one<F16, 96, true>(p, batch, st) : launch_one<BF16, 96, true>(p, batch, st); }
     else if (head_dim == 64 && !causal) { f16 ? launch_one<F16, 64, false>(p, batch, st) : launch_one<BF16, 64, false>(p, batch, st); }
     else if (head_dim == 64 && causal) { f16 ? launch_one<F16, 64, true>(p, batch, st) : launch_one<BF16, 64, true>(p, batch, st); }
     else if (head_dim == 96 && !causal) { f16 ? launch_one<F16, 96, false>(p, batch, st) : launch_one<BF16, 96, false>(p, batch, st); }
-    else throw std::runtime_error("attention: head_dim must be 64 or 96");
+    else if (head_dim == 128 && causal) { f16 ? launch_one<F16, 128, true>(p, batch, st) : launch_one<BF16, 128, true>(p, batch, st); }
+    else throw std::runtime_error("attention: head_dim must be 64, 96 or 128 (128: causal only)");
 }
 
 }  // namespace lr

@@ -112,6 +112,7 @@ struct AttnParams {
     int S;          // tokens per sequence
     int heads;
     float scale;    // 1/sqrt(HD)
+    int kv_group;   // query heads per key/value head (GQA); 1 = MHA
 };
 
 }  // namespace lr

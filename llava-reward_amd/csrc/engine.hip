@@ -39,6 +39,7 @@ struct Slot {
     void* dst;                 // destination (already offset for concatenated tensors)
     int ld_dst, cols_dst, dst_dtype, mode;
     double std_, offset;       // synthetic init (llava_reward_amd.synth.weight_specs)
+    int aux_d = 0, aux_hd = 0; // PACK_ROPE_QKV: width of a rotated section, head width
     bool provided = false;
 };
 
@@ -66,13 +67,15 @@ struct lr_engine {
 
     // derived
     int T = 0, G = 0, Kpatch = 0, Kpad = 0, hd = 0, half = 0, Vcap = 0;
+    int Hq = 0, Hkv = 0, Nqkv = 0;      // decoder projection widths: heads*hd, kv_heads*hd, Hq + 2*Hkv
+    bool llava = false;
     int op_dt = DT_BF16;
 
     // weights
     float *cls = nullptr, *pos = nullptr, *pre_w = nullptr, *pre_b = nullptr;
     void* patch_w = nullptr;
     std::vector<ClipLayer> cl;
-    float *sub_gn = nullptr, *glb_gn = nullptr, *p0_b = nullptr, *p2_b = nullptr;
+    float *sub_gn = nullptr, *glb_gn = nullptr, *p0_b = nullptr, *p2_b = nullptr, *newline = nullptr;
     void *p0_w = nullptr, *p2_w = nullptr;
     unsigned short* wte = nullptr;
     std::vector<DecLayer> dl;
@@ -89,7 +92,7 @@ struct lr_engine {
     void *patchA = nullptr, *clip_h = nullptr, *clip_qkv = nullptr, *clip_att = nullptr, *clip_ff = nullptr;
     float *patch_out = nullptr, *clip_x = nullptr;
     void *hdA = nullptr, *proj1 = nullptr;
-    float* ev = nullptr;
+    float *ev = nullptr, *pf32 = nullptr;
     float *x = nullptr, *qkv32 = nullptr, *cs = nullptr;
     void *h = nullptr, *qkv = nullptr, *att = nullptr, *ff = nullptr;
     int *pos_ids = nullptr, *img_row = nullptr, *tstat = nullptr;
@@ -138,14 +141,10 @@ void vec_slot(lr_engine* e, const std::string& name, std::vector<int64_t> shape,
     e->slots.back().rows = 1; e->slots.back().cols = (int)n;
 }
 
-void build_weight_table(lr_engine* e) {
+void register_clip(lr_engine* e, const std::string& cp) {
     const lr_model_desc& d = e->d;
-    const int Hc = d.clip_hidden, Mc = d.clip_mlp, D = d.hidden, I = d.intermediate;
+    const int Hc = d.clip_hidden, Mc = d.clip_mlp;
     const int od = e->op_dt;
-    const std::string cp = "model.vision_embed_tokens.img_processor.vision_model.";
-    const std::string ep = "model.vision_embed_tokens.";
-    e->wte = (unsigned short*)oalloc(e, (size_t)d.vocab_size * D);
-    add_slot(e, "model.embed_tokens.weight", {d.vocab_size, D}, e->wte, D, D, DT_BF16, PACK_PLAIN, 0.02, 0);
     e->cls = falloc(e, Hc);
     vec_slot(e, cp + "embeddings.class_embedding", {Hc}, e->cls, 0.02, 0);
     e->patch_w = oalloc(e, (size_t)Hc * e->Kpad);
@@ -182,6 +181,23 @@ void build_weight_table(lr_engine* e) {
         vec_slot(e, p + "layer_norm2.weight", {Hc}, c.ln2_w, 0.05, 1.0);
         vec_slot(e, p + "layer_norm2.bias", {Hc}, c.ln2_b, 0.02, 0);
     }
+}
+
+void upload_rope_tables(lr_engine* e) {
+    e->inv_s = falloc(e, LR_MAX_HALF_HEAD); e->inv_l = falloc(e, LR_MAX_HALF_HEAD);
+    LR_HIP_CHECK(hipMemcpy(e->inv_s, e->d.inv_freq_short, sizeof(e->d.inv_freq_short), hipMemcpyHostToDevice));
+    LR_HIP_CHECK(hipMemcpy(e->inv_l, e->d.inv_freq_long, sizeof(e->d.inv_freq_long), hipMemcpyHostToDevice));
+}
+
+// Phi-3.5-V names: modeling_phi3_v.py:1332-1374, :118-207; reward heads rw_model_general_preference.py:314-326
+void build_weight_table_phi(lr_engine* e) {
+    const lr_model_desc& d = e->d;
+    const int Hc = d.clip_hidden, D = d.hidden, I = d.intermediate;
+    const int od = e->op_dt;
+    const std::string ep = "model.vision_embed_tokens.";
+    e->wte = (unsigned short*)oalloc(e, (size_t)d.vocab_size * D);
+    add_slot(e, "model.embed_tokens.weight", {d.vocab_size, D}, e->wte, D, D, DT_BF16, PACK_PLAIN, 0.02, 0);
+    register_clip(e, "model.vision_embed_tokens.img_processor.vision_model.");
     e->glb_gn = falloc(e, 4 * Hc); e->sub_gn = falloc(e, 4 * Hc);
     vec_slot(e, ep + "glb_GN", {1, 1, 4 * Hc}, e->glb_gn, 0.02, 0);
     vec_slot(e, ep + "sub_GN", {1, 1, 1, 4 * Hc}, e->sub_gn, 0.02, 0);
@@ -200,6 +216,7 @@ void build_weight_table(lr_engine* e) {
         L.gu_w = oalloc(e, (size_t)2 * I * D); L.down_w = oalloc(e, (size_t)D * I);
         vec_slot(e, p + "input_layernorm.weight", {D}, L.ln1, 0.05, 1.0);
         add_slot(e, p + "self_attn.qkv_proj.weight", {3 * D, D}, L.qkv_w, D, D, od, PACK_ROPE_QKV, 0.02, 0);
+        e->slots.back().aux_d = D; e->slots.back().aux_hd = e->hd;
         add_slot(e, p + "self_attn.o_proj.weight", {D, D}, L.o_w, D, D, od, PACK_PLAIN, 0.02, 0);
         vec_slot(e, p + "post_attention_layernorm.weight", {D}, L.ln2, 0.05, 1.0);
         add_slot(e, p + "mlp.gate_up_proj.weight", {2 * I, D}, L.gu_w, D, D, od, PACK_SWIGLU, 0.02, 0);
@@ -219,10 +236,50 @@ void build_weight_table(lr_engine* e) {
     }
     e->vh = falloc(e, (size_t)d.value_head_dim * D);
     add_slot(e, "value_head.weight", {d.value_head_dim, D}, e->vh, D, D, DT_F32, PACK_PLAIN, 1.0 / std::sqrt((double)D), 0);
-    // rope tables
-    e->inv_s = falloc(e, LR_MAX_HALF_HEAD); e->inv_l = falloc(e, LR_MAX_HALF_HEAD);
-    LR_HIP_CHECK(hipMemcpy(e->inv_s, d.inv_freq_short, sizeof(d.inv_freq_short), hipMemcpyHostToDevice));
-    LR_HIP_CHECK(hipMemcpy(e->inv_l, d.inv_freq_long, sizeof(d.inv_freq_long), hipMemcpyHostToDevice));
+    upload_rope_tables(e);
+}
+
+// llava-v1.6-mistral-7b-hf checkpoint names (transformers LlavaNextForConditionalGeneration, 4.50 layout)
+void build_weight_table_llava(lr_engine* e) {
+    const lr_model_desc& d = e->d;
+    const int Hc = d.clip_hidden, D = d.hidden, I = d.intermediate, hd = e->hd, Hq = e->Hq, Hkv = e->Hkv;
+    const int od = e->op_dt;
+    e->wte = (unsigned short*)oalloc(e, (size_t)d.vocab_size * D);
+    add_slot(e, "language_model.model.embed_tokens.weight", {d.vocab_size, D}, e->wte, D, D, DT_BF16, PACK_PLAIN, 0.02, 0);
+    register_clip(e, "vision_tower.vision_model.");
+    e->p0_w = oalloc(e, (size_t)D * Hc); e->p0_b = falloc(e, D);
+    e->p2_w = oalloc(e, (size_t)D * D); e->p2_b = falloc(e, D);
+    add_slot(e, "multi_modal_projector.linear_1.weight", {D, Hc}, e->p0_w, Hc, Hc, od, PACK_PLAIN, 0.02, 0);
+    vec_slot(e, "multi_modal_projector.linear_1.bias", {D}, e->p0_b, 0.02, 0);
+    add_slot(e, "multi_modal_projector.linear_2.weight", {D, D}, e->p2_w, D, D, od, PACK_PLAIN, 0.02, 0);
+    vec_slot(e, "multi_modal_projector.linear_2.bias", {D}, e->p2_b, 0.02, 0);
+    e->newline = falloc(e, D);
+    vec_slot(e, "image_newline", {D}, e->newline, 0.02, 0);
+    e->dl.resize(d.layers);
+    for (int l = 0; l < d.layers; ++l) {
+        DecLayer& L = e->dl[l];
+        const std::string p = "language_model.model.layers." + std::to_string(l) + ".";
+        L.ln1 = falloc(e, D); L.ln2 = falloc(e, D);
+        L.qkv_w = oalloc(e, (size_t)e->Nqkv * D); L.o_w = oalloc(e, (size_t)D * Hq);
+        L.gu_w = oalloc(e, (size_t)2 * I * D); L.down_w = oalloc(e, (size_t)D * I);
+        vec_slot(e, p + "input_layernorm.weight", {D}, L.ln1, 0.05, 1.0);
+        // q, k, v land in one fused [Hq + 2 Hkv, D] matrix; q and k rows pair-interleaved per head for the RoPE epilogue
+        add_slot(e, p + "self_attn.q_proj.weight", {Hq, D}, L.qkv_w, D, D, od, PACK_ROPE_QKV, 0.02, 0);
+        e->slots.back().aux_d = Hq; e->slots.back().aux_hd = hd;
+        add_slot(e, p + "self_attn.k_proj.weight", {Hkv, D}, (char*)L.qkv_w + (size_t)Hq * D * 2, D, D, od, PACK_ROPE_QKV, 0.02, 0);
+        e->slots.back().aux_d = Hkv; e->slots.back().aux_hd = hd;
+        add_slot(e, p + "self_attn.v_proj.weight", {Hkv, D}, (char*)L.qkv_w + (size_t)(Hq + Hkv) * D * 2, D, D, od, PACK_PLAIN, 0.02, 0);
+        add_slot(e, p + "self_attn.o_proj.weight", {D, Hq}, L.o_w, Hq, Hq, od, PACK_PLAIN, 0.02, 0);
+        vec_slot(e, p + "post_attention_layernorm.weight", {D}, L.ln2, 0.05, 1.0);
+        add_slot(e, p + "mlp.gate_proj.weight", {I, D}, L.gu_w, D, D, od, PACK_SWIGLU_GATE, 0.02, 0);
+        add_slot(e, p + "mlp.up_proj.weight", {I, D}, L.gu_w, D, D, od, PACK_SWIGLU_UP, 0.02, 0);
+        add_slot(e, p + "mlp.down_proj.weight", {D, I}, L.down_w, I, I, od, PACK_PLAIN, 0.02, 0);
+    }
+    e->norm_w = falloc(e, D);
+    vec_slot(e, "language_model.model.norm.weight", {D}, e->norm_w, 0.05, 1.0);
+    e->vh = falloc(e, (size_t)d.value_head_dim * D);
+    add_slot(e, "value_head.weight", {d.value_head_dim, D}, e->vh, D, D, DT_F32, PACK_PLAIN, 1.0 / std::sqrt((double)D), 0);
+    upload_rope_tables(e);
 }
 
 void ensure_stage(lr_engine* e, size_t raw_bytes, size_t n_f32) {
@@ -240,16 +297,28 @@ void ensure_stage(lr_engine* e, size_t raw_bytes, size_t n_f32) {
 
 void pack_slot(lr_engine* e, Slot& s, const float* src_f32) {
     launch_pack(src_f32, s.dst, s.rows, s.cols, s.ld_dst, s.mode == PACK_TRANSPOSE ? s.cols : s.cols_dst, s.dst_dtype, s.mode, 0,
-                e->d.hidden, e->hd);
+                s.aux_d, s.aux_hd);
     s.provided = true;
 }
 
 void validate_desc(const lr_model_desc& d) {
     auto bad = [](const char* m) { throw std::invalid_argument(m); };
     if (d.struct_size != (int)sizeof(lr_model_desc)) bad("lr_model_desc.struct_size mismatch (ABI)");
-    if (d.hidden <= 0 || d.heads <= 0 || d.hidden % d.heads) bad("hidden must be divisible by heads");
-    const int hd = d.hidden / d.heads;
-    if (hd != 96 && hd != 64) bad("decoder head_dim must be 96 or 64");
+    if (d.hidden <= 0 || d.heads <= 0) bad("hidden and heads must be positive");
+    if (d.backbone != LR_BACKBONE_PHI3V && d.backbone != LR_BACKBONE_LLAVA_NEXT) bad("unknown backbone");
+    if (d.backbone == LR_BACKBONE_PHI3V) {
+        if (d.hidden % d.heads) bad("hidden must be divisible by heads");
+        const int hd = d.hidden / d.heads;
+        if (hd != 96 && hd != 64) bad("Phi-3-V decoder head_dim must be 96 or 64");
+        if (d.kv_heads != d.heads || d.head_dim != hd) bad("Phi-3-V: kv_heads must equal heads and head_dim hidden/heads");
+    } else {
+        if (d.head_dim != 128) bad("LLaVA decoder head_dim must be 128");
+        if (d.kv_heads < 1 || d.heads % d.kv_heads) bad("heads must be a multiple of kv_heads");
+        if (d.add_cross_attention) bad("the llava branch has no SkipCA (rw_model_general_preference.py:376-397)");
+        if (d.n_pinpoints < 1 || d.n_pinpoints > LR_MAX_PINPOINTS) bad("n_pinpoints out of range");
+        if (d.image_token_id < 0 || d.image_token_id >= d.vocab_size) bad("image_token_id out of range");
+        if (((d.heads + d.kv_heads) * d.head_dim) % 256) bad("(heads + kv_heads) * head_dim must be a multiple of 256");
+    }
     if (d.clip_hidden % d.clip_heads || d.clip_hidden / d.clip_heads != 64) bad("CLIP head_dim must be 64");
     if (d.hidden % 64 || d.intermediate % 64 || d.clip_hidden % 64 || d.clip_mlp % 64) bad("widths must be multiples of 64");
     if (d.hidden > 4096 || d.clip_hidden > 4096) bad("hidden sizes above 4096 are not supported by the norm kernels");
@@ -308,11 +377,26 @@ int lr_create(const lr_model_desc* desc, int device, lr_handle* out) {
         e->T = e->G * e->G + 1;
         e->Kpatch = 3 * desc->clip_patch * desc->clip_patch;
         e->Kpad = (e->Kpatch + 63) / 64 * 64;
-        e->hd = desc->hidden / desc->heads;
+        e->llava = desc->backbone == LR_BACKBONE_LLAVA_NEXT;
+        e->hd = desc->head_dim;
         e->half = e->hd / 2;
-        const int g2 = e->G / 2;
-        e->Vcap = desc->max_crops * g2 * g2 + 1 + desc->max_crops * g2;
-        build_weight_table(e);
+        e->Hq = desc->heads * e->hd; e->Hkv = desc->kv_heads * e->hd; e->Nqkv = e->Hq + 2 * e->Hkv;
+        if (e->llava) {
+            int vmax = 0, cmax = 0;
+            for (int i = 0; i < desc->n_pinpoints; ++i) {
+                const int gh = desc->pinpoints[2 * i] / desc->clip_image, gw = desc->pinpoints[2 * i + 1] / desc->clip_image;
+                if (gh < 1 || gw < 1) throw std::invalid_argument("pinpoints must be positive multiples of the crop size");
+                vmax = std::max(vmax, gh * e->G * (gw * e->G + 1));
+                cmax = std::max(cmax, gh * gw + 1);
+            }
+            if (desc->max_crops < cmax) throw std::invalid_argument("max_crops is smaller than the largest anyres grid + 1");
+            e->Vcap = e->G * e->G + vmax;
+            build_weight_table_llava(e);
+        } else {
+            const int g2 = e->G / 2;
+            e->Vcap = desc->max_crops * g2 * g2 + 1 + desc->max_crops * g2;
+            build_weight_table_phi(e);
+        }
     });
     if (rc != LR_OK) {
         if (e) { g_create_error = g_create_error.empty() ? e->err : g_create_error; lr_destroy(e); }
@@ -404,14 +488,19 @@ int lr_finalize(lr_handle h) {
         h->patchA = W(Rp * h->Kpad * 2); h->patch_out = (float*)W(Rp * Hc * 4);
         h->clip_x = (float*)W(Rc * Hc * 4); h->clip_h = W(Rc * Hc * 2); h->clip_qkv = W(Rc * 3 * Hc * 2);
         h->clip_att = W(Rc * Hc * 2); h->clip_ff = W(Rc * Mc * 2);
-        h->hdA = W(SV * 4 * Hc * 2); h->proj1 = W(SV * D * 2); h->ev = (float*)W(SV * D * 4);
-        h->x = (float*)W(Rl * D * 4); h->h = W(Rl * D * 2); h->qkv32 = (float*)W(Rl * 3 * D * 4); h->qkv = W(Rl * 3 * D * 2);
-        h->att = W(Rl * D * 2); h->ff = W(Rl * I * 2); h->cs = (float*)W(Rl * h->hd * 4);
+        if (h->llava) {       // projector runs on every crop token, packing afterwards
+            h->hdA = W(Rp * Hc * 2); h->proj1 = W(Rp * D * 2); h->pf32 = (float*)W(Rp * D * 4);
+        } else {              // HD-merged rows go through the projector
+            h->hdA = W(SV * 4 * Hc * 2); h->proj1 = W(SV * D * 2);
+        }
+        h->ev = (float*)W(SV * D * 4);
+        h->x = (float*)W(Rl * D * 4); h->h = W(Rl * D * 2); h->qkv32 = (float*)W(Rl * h->Nqkv * 4); h->qkv = W(Rl * h->Nqkv * 2);
+        h->att = W(Rl * h->Hq * 2); h->ff = W(Rl * I * 2); h->cs = (float*)W(Rl * h->hd * 4);
         h->pos_ids = (int*)W(Rl * 4); h->img_row = (int*)W(Rl * 4); h->tstat = (int*)W(B * 16);
         h->hL = (float*)W(B * D * 4); h->tq = (float*)W(B * D * 4); h->tkq = (float*)W(B * D * 4);
         h->tsc = (float*)W(B * (size_t)h->Vcap * 4); h->tctx = (float*)W(B * D * 4); h->tao = (float*)W(B * D * 4);
-        // tables: crop_src[NC] | HdSample[B] | voff[B+1]
-        h->tab_bytes = ((NC * 4 + B * sizeof(HdSample) + (B + 1) * 4) + 255) & ~(size_t)255;
+        // tables: crop_src[NC] | per-sample geometry [B] (HdSample or LlavaSample) | voff[B+1]
+        h->tab_bytes = ((NC * 4 + B * sizeof(LlavaSample) + (B + 1) * 4) + 255) & ~(size_t)255;
         LR_HIP_CHECK(hipHostMalloc((void**)&h->tab_host, h->tab_bytes * lr_engine::NSLOT));
         h->tab_dev = (char*)W(h->tab_bytes * lr_engine::NSLOT);
         for (int i = 0; i < lr_engine::NSLOT; ++i) LR_HIP_CHECK(hipEventCreateWithFlags(&h->tab_ev[i], hipEventDisableTiming));
@@ -447,25 +536,55 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
         const int Hc = d.clip_hidden, Mc = d.clip_mlp, D = d.hidden, I = d.intermediate, T = h->T, g2 = h->G / 2;
         const int img = d.clip_image;
 
-        // ---- host plan: active crops, HD layout, image-token offsets (modeling_phi3_v.py:276-297) ----
+        // ---- host plan: active crops, per-sample vision geometry, image-token offsets ----
+        // Phi-3-V: modeling_phi3_v.py:276-297 (HD crop grid);  LLaVA: modeling_llava_next.py:41-146,265-335 (anyres + unpad)
         const int slot = h->slot_i; h->slot_i = (h->slot_i + 1) % lr_engine::NSLOT;
         if (h->tab_used[slot]) LR_HIP_CHECK(hipEventSynchronize(h->tab_ev[slot]));   // bounds host run-ahead to NSLOT passes
         char* th = h->tab_host + (size_t)slot * h->tab_bytes;
         char* td = h->tab_dev + (size_t)slot * h->tab_bytes;
         const size_t NCcap = (size_t)d.max_batch * d.max_crops;
+        const size_t smp_off = NCcap * 4, voff_off = smp_off + (size_t)d.max_batch * sizeof(LlavaSample);
         int* crop_src = (int*)th;
-        HdSample* smp = (HdSample*)(th + NCcap * 4);
-        int* voff = (int*)(th + NCcap * 4 + (size_t)d.max_batch * sizeof(HdSample));
+        HdSample* smp = (HdSample*)(th + smp_off);
+        LlavaSample* lsmp = (LlavaSample*)(th + smp_off);
+        int* voff = (int*)(th + voff_off);
         int NC = 0, SV = 0, Vmax = 0;
         for (int b = 0; b < B; ++b) {
             const int64_t hh = image_sizes_host[2 * b], ww = image_sizes_host[2 * b + 1];
-            if (hh <= 0 || ww <= 0 || hh % img || ww % img) throw std::invalid_argument("lr_forward: image_sizes must be positive multiples of the crop size");
-            const int hc = (int)(hh / img), wc = (int)(ww / img);
-            if (hc * wc + 1 > n_crops) throw std::invalid_argument("lr_forward: image_sizes needs more crops than pixel_values holds");
-            smp[b] = HdSample{hc, wc, NC, SV};
+            int ncr, V;
+            if (h->llava) {
+                if (hh <= 0 || ww <= 0) throw std::invalid_argument("lr_forward: image_sizes must be positive");
+                // transformers select_best_resolution: max effective resolution, then min waste
+                long best_eff = 0, best_waste = 0; int bh = 0, bw = 0;
+                for (int i = 0; i < d.n_pinpoints; ++i) {
+                    const int ph = d.pinpoints[2 * i], pw = d.pinpoints[2 * i + 1];
+                    const double sc = std::min((double)pw / (double)ww, (double)ph / (double)hh);
+                    const long dw = (long)((double)ww * sc), dh = (long)((double)hh * sc);
+                    const long eff = std::min(dw * dh, (long)(ww * hh)), waste = (long)pw * ph - eff;
+                    if (eff > best_eff || (eff == best_eff && (bh == 0 || waste < best_waste))) { best_eff = eff; best_waste = waste; bh = ph; bw = pw; }
+                }
+                const int gh = bh / img, gw = bw / img, ch = gh * h->G, cw = gw * h->G;
+                int r0 = 0, r1 = ch, c0 = 0, c1 = cw;
+                // unpad_image (modeling_llava_next.py:109-146): new extent = int(round(x, 7)) -- 7 decimals, then truncation
+                auto trunc7 = [](double x) { return (int)(std::round(x * 1e7) / 1e7); };
+                if ((double)ww / (double)hh > (double)cw / (double)ch) {           // rows were padded
+                    const int pad = (ch - trunc7((double)hh * ((double)cw / (double)ww))) / 2; r0 = pad; r1 = ch - pad;
+                } else {                                                           // columns were padded
+                    const int pad = (cw - trunc7((double)ww * ((double)ch / (double)hh))) / 2; c0 = pad; c1 = cw - pad;
+                }
+                ncr = 1 + gh * gw;
+                V = h->G * h->G + (r1 - r0) * (c1 - c0 + 1);
+                lsmp[b] = LlavaSample{gh, gw, r0, r1, c0, c1, NC, SV};
+            } else {
+                if (hh <= 0 || ww <= 0 || hh % img || ww % img) throw std::invalid_argument("lr_forward: image_sizes must be positive multiples of the crop size");
+                const int hc = (int)(hh / img), wc = (int)(ww / img);
+                ncr = hc * wc + 1;
+                smp[b] = HdSample{hc, wc, NC, SV};
+                V = hc * g2 * (wc * g2 + 1) + 1 + g2 * (g2 + 1);
+            }
+            if (ncr > n_crops) throw std::invalid_argument("lr_forward: image_sizes needs more crops than pixel_values holds");
             voff[b] = SV;
-            for (int c = 0; c <= hc * wc; ++c) crop_src[NC++] = b * n_crops + c;
-            const int V = hc * g2 * (wc * g2 + 1) + 1 + g2 * (g2 + 1);
+            for (int c = 0; c < ncr; ++c) crop_src[NC++] = b * n_crops + c;
             SV += V;
             Vmax = V > Vmax ? V : Vmax;
         }
@@ -474,8 +593,9 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
         LR_HIP_CHECK(hipEventRecord(h->tab_ev[slot], st));
         h->tab_used[slot] = true;
         const int* d_crop_src = (const int*)td;
-        const HdSample* d_smp = (const HdSample*)(td + NCcap * 4);
-        const int* d_voff = (const int*)(td + NCcap * 4 + (size_t)d.max_batch * sizeof(HdSample));
+        const HdSample* d_smp = (const HdSample*)(td + smp_off);
+        const LlavaSample* d_lsmp = (const LlavaSample*)(td + smp_off);
+        const int* d_voff = (const int*)(td + voff_off);
         h->lastB = B; h->lastS = S; h->lastNC = NC; h->lastSV = SV;
 
         // ---- CLIP tower (utils/utils.py:266-273) ----
@@ -488,40 +608,51 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
             const ClipLayer& c = h->cl[l];
             launch_norm_rows(h->clip_x, c.ln1_w, c.ln1_b, h->clip_h, Rc, Hc, d.clip_ln_eps, h->op_dt, st);
             gemm(h, st, h->clip_h, c.qkv_w, h->clip_qkv, c.qkv_b, Rc, 3 * Hc, Hc, Hc, Hc, 3 * Hc, EPI_OUT_OP, ACT_NONE);
-            AttnParams ap{h->clip_qkv, h->clip_qkv, h->clip_qkv, h->clip_att, nullptr, nullptr, 0, 3 * Hc, Hc, 0, Hc, 2 * Hc, T, d.clip_heads, 0.125f};
+            AttnParams ap{h->clip_qkv, h->clip_qkv, h->clip_qkv, h->clip_att, nullptr, nullptr, 0, 3 * Hc, Hc, 0, Hc, 2 * Hc, T, d.clip_heads, 0.125f, 1};
             launch_attention(ap, NC, 64, false, h->op_dt, st);
             gemm(h, st, h->clip_att, c.out_w, h->clip_x, c.out_b, Rc, Hc, Hc, Hc, Hc, Hc, EPI_RESADD_F32, ACT_NONE);
             launch_norm_rows(h->clip_x, c.ln2_w, c.ln2_b, h->clip_h, Rc, Hc, d.clip_ln_eps, h->op_dt, st);
             gemm(h, st, h->clip_h, c.fc1_w, h->clip_ff, c.fc1_b, Rc, Mc, Hc, Hc, Hc, Mc, EPI_OUT_OP, ACT_QUICK_GELU);
             gemm(h, st, h->clip_ff, c.fc2_w, h->clip_x, c.fc2_b, Rc, Hc, Mc, Mc, Mc, Hc, EPI_RESADD_F32, ACT_NONE);
         }
-        // ---- HD transform + projector (modeling_phi3_v.py:254-303) ----
-        launch_hd_gather(h->clip_x, d_smp, B, SV, T, Hc, h->sub_gn, h->glb_gn, h->hdA, h->op_dt, st);
-        gemm(h, st, h->hdA, h->p0_w, h->proj1, h->p0_b, SV, D, 4 * Hc, 4 * Hc, 4 * Hc, D, EPI_OUT_OP, ACT_GELU_ERF);
-        gemm(h, st, h->proj1, h->p2_w, h->ev, h->p2_b, SV, D, D, D, D, D, EPI_OUT_F32, ACT_NONE);
-        // ---- embeddings, positions (modeling_phi3_v.py:228-249, rw_model:344-345) ----
+        if (h->llava) {
+            // ---- per-token projector, then anyres packing (modeling_llava_next.py get_image_features/pack_image_features) ----
+            launch_clip_tokens(h->clip_x, h->hdA, NC, T, Hc, h->op_dt, st);
+            gemm(h, st, h->hdA, h->p0_w, h->proj1, h->p0_b, Rp, D, Hc, Hc, Hc, D, EPI_OUT_OP, ACT_GELU_ERF);
+            gemm(h, st, h->proj1, h->p2_w, h->pf32, h->p2_b, Rp, D, D, D, D, D, EPI_OUT_F32, ACT_NONE);
+            launch_llava_pack(h->pf32, d_lsmp, B, SV, h->G, D, h->newline, h->ev, st);
+        } else {
+            // ---- HD transform + projector (modeling_phi3_v.py:254-303) ----
+            launch_hd_gather(h->clip_x, d_smp, B, SV, T, Hc, h->sub_gn, h->glb_gn, h->hdA, h->op_dt, st);
+            gemm(h, st, h->hdA, h->p0_w, h->proj1, h->p0_b, SV, D, 4 * Hc, 4 * Hc, 4 * Hc, D, EPI_OUT_OP, ACT_GELU_ERF);
+            gemm(h, st, h->proj1, h->p2_w, h->ev, h->p2_b, SV, D, D, D, D, D, EPI_OUT_F32, ACT_NONE);
+        }
+        // ---- embeddings, positions (modeling_phi3_v.py:228-249, rw_model:344-345 | llava: masked_scatter, arange positions) ----
         const int Rl = B * S;
-        launch_token_plan(input_ids, attention_mask, B, S, d_voff, h->img_row, h->pos_ids, h->tstat, st);
+        launch_token_plan(input_ids, attention_mask, B, S, d_voff, h->img_row, h->pos_ids, h->tstat, st,
+                          h->llava ? (long)d.image_token_id : -1L, h->llava ? 1 : 0);
         launch_embed(input_ids, h->img_row, h->wte, h->ev, h->x, Rl, D, d.vocab_size, st);
         launch_rope_table(h->pos_ids, h->tstat, B, S, h->inv_s, h->inv_l, d.rope_scaling, d.orig_max_pos, h->half, h->cs, st);
-        // ---- decoder stack (modeling_phi3_v.py:1144-1205) ----
+        // ---- decoder stack (modeling_phi3_v.py:1144-1205 | modeling_mistral.py decoder layer) ----
         const int nl = h->lim_layers >= 0 && h->lim_layers < d.layers ? h->lim_layers : d.layers;
         const float ascale = 1.0f / std::sqrt((float)h->hd);
+        const int Hq = h->Hq, Hkv = h->Hkv, Nqkv = h->Nqkv;
         for (int l = 0; l < nl; ++l) {
             const DecLayer& L = h->dl[l];
             launch_norm_rows(h->x, L.ln1, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st);
             {   // qkv projection with RoPE on q,k: fused in the GEMM epilogue when the deep-pipelined kernel runs
-                GemmParams gp{h->h, L.qkv_w, h->qkv, nullptr, Rl, 3 * D, D, D, D, 3 * D, EPI_ROPE_OP, ACT_NONE, h->cs, 2 * D, h->hd};
+                GemmParams gp{h->h, L.qkv_w, h->qkv, nullptr, Rl, Nqkv, D, D, D, Nqkv, EPI_ROPE_OP, ACT_NONE, h->cs, Hq + Hkv, h->hd};
                 if (gemm_bt_is_deep(gp, h->gemm_tile)) {
                     launch_gemm_bt(gp, h->op_dt, h->gemm_tile, st);
                 } else {
-                    gemm(h, st, h->h, L.qkv_w, h->qkv32, nullptr, Rl, 3 * D, D, D, D, 3 * D, EPI_OUT_F32, ACT_NONE);
-                    launch_rope_split(h->qkv32, h->cs, h->qkv, Rl, D, d.heads, h->op_dt, st);
+                    gemm(h, st, h->h, L.qkv_w, h->qkv32, nullptr, Rl, Nqkv, D, D, D, Nqkv, EPI_OUT_F32, ACT_NONE);
+                    launch_rope_split(h->qkv32, h->cs, h->qkv, Rl, Hq + Hkv, Hkv, h->hd, h->op_dt, st);
                 }
             }
-            AttnParams ap{h->qkv, h->qkv, h->qkv, h->att, attention_mask, h->tstat + 1, 4, 3 * D, D, 0, D, 2 * D, S, d.heads, ascale};
+            AttnParams ap{h->qkv, h->qkv, h->qkv, h->att, attention_mask, h->tstat + 1, 4, Nqkv, Hq, 0, Hq, Hq + Hkv, S, d.heads, ascale,
+                          d.heads / d.kv_heads};
             launch_attention(ap, B, h->hd, true, h->op_dt, st);
-            gemm(h, st, h->att, L.o_w, h->x, nullptr, Rl, D, D, D, D, D, EPI_RESADD_F32, ACT_NONE);
+            gemm(h, st, h->att, L.o_w, h->x, nullptr, Rl, D, Hq, Hq, Hq, D, EPI_RESADD_F32, ACT_NONE);
             launch_norm_rows(h->x, L.ln2, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st);
             gemm(h, st, h->h, L.gu_w, h->ff, nullptr, Rl, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE);
             gemm(h, st, h->ff, L.down_w, h->x, nullptr, Rl, D, I, I, I, D, EPI_RESADD_F32, ACT_NONE);
@@ -583,10 +714,10 @@ int lr_op_gemm_rope(const void* A, const void* W, void* C, const float* cs, int 
 }
 
 int lr_op_attention(const void* Q, const void* K, const void* V, void* O, const int64_t* mask, const int* kmin, int ldq, int ldo,
-                    int qoff, int koff, int voff, int batch, int S, int heads, int head_dim, int causal, float scale,
+                    int qoff, int koff, int voff, int batch, int S, int heads, int head_dim, int causal, int kv_group, float scale,
                     int operand_dtype, void* hip_stream) {
     return op_guard([&] {
-        AttnParams p{Q, K, V, O, mask, kmin, 1, ldq, ldo, qoff, koff, voff, S, heads, scale};
+        AttnParams p{Q, K, V, O, mask, kmin, 1, ldq, ldo, qoff, koff, voff, S, heads, scale, kv_group};
         launch_attention(p, batch, head_dim, causal != 0, operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16, (hipStream_t)hip_stream);
     });
 }

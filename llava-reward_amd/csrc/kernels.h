@@ -26,8 +26,10 @@ void launch_clip_embed(const float* patch_out, const float* cls, const float* po
                        float* x, int ncrop, int T, int H, float eps, hipStream_t st);
 // per-sample token plan: positions, image-slot ranks, last valid index, first valid index
 // tstat[b] = {last valid index, first valid index, #image slots, #valid tokens}
+// image slots: ids < 0 (Phi-3-V) when image_token_id < 0, else ids == image_token_id (LLaVA);
+// positions: cumsum(mask)-1 with pads -> 1 (rw_model:344-345) or arange(S) when pos_arange (no position_ids passed)
 void launch_token_plan(const int64_t* ids, const int64_t* mask, int B, int S, const int* voff, int* img_row, int* pos,
-                       int* tstat, hipStream_t st);
+                       int* tstat, hipStream_t st, long image_token_id = -1, int pos_arange = 0);
 // x[b*S+s] = img_row >= 0 ? ev[img_row] : wte[clamp(id)]
 void launch_embed(const int64_t* ids, const int* img_row, const unsigned short* wte_bf16, const float* ev, float* x,
                   int rows, int D, int vocab, hipStream_t st);
@@ -35,12 +37,20 @@ void launch_embed(const int64_t* ids, const int* img_row, const unsigned short* 
 void launch_rope_table(const int* pos, const int* tstat, int B, int S, const float* inv_freq_short,
                        const float* inv_freq_long, float scaling, int orig_max_pos, int half, float* cs, hipStream_t st);
 // qkv32 [rows, 3D] fp32 -> qkv operand dtype with RoPE applied to q and k heads (pair-interleaved head dims)
-void launch_rope_split(const float* qkv32, const float* cs, void* out, int rows, int D, int heads, int operand_dtype,
-                       hipStream_t st);
+void launch_rope_split(const float* qkv32, const float* cs, void* out, int rows, int rope_cols, int v_cols, int hd,
+                       int operand_dtype, hipStream_t st);
 // HD transform gather (modeling_phi3_v.py:254-362): rows of [sum V, 4H] from CLIP features x [ncrop*T, H]
 struct HdSample { int hc, wc, crop0, voff; };
 void launch_hd_gather(const float* clipx, const HdSample* samples, int B, int total_rows, int T, int H,
                       const float* sub_gn, const float* glb_gn, void* out, int operand_dtype, hipStream_t st);
+
+// LLaVA-1.6 (modeling_llava_next.py get_image_features / pack_image_features) -------------------
+// patch tokens of every crop (CLS dropped) as GEMM operand rows: out[crop*(T-1) + t] = clipx[crop*T + 1 + t]
+void launch_clip_tokens(const float* clipx, void* out, int ncrop, int T, int H, int operand_dtype, hipStream_t st);
+struct LlavaSample { int gh, gw, r0, r1, c0, c1, crop0, voff; };
+// ev rows of sample b: [base crop tokens; rows r0..r1 x cols c0..c1 of the hi-res grid, image_newline after each row]
+void launch_llava_pack(const float* proj, const LlavaSample* samples, int B, int total_rows, int g, int D,
+                       const float* newline, float* ev, hipStream_t st);
 
 // tail (fp32) -----------------------------------------------------------------------------------
 // y[b] = RMSNorm(x[b*S + (use_last_pos ? S-1 : tstat[b].last_valid)])
@@ -57,7 +67,7 @@ void launch_reward_head(const float* hL, const float* attn_o, const float* ca_w,
 
 // weights ---------------------------------------------------------------------------------------
 void launch_synth_fill(float* out, size_t n, uint64_t tseed, float scale, float offset, int bf16_round, hipStream_t st);
-enum : int { PACK_PLAIN = 0, PACK_SWIGLU = 1, PACK_TRANSPOSE = 2, PACK_ROPE_QKV = 3 };
+enum : int { PACK_PLAIN = 0, PACK_SWIGLU = 1, PACK_TRANSPOSE = 2, PACK_ROPE_QKV = 3, PACK_SWIGLU_GATE = 4, PACK_SWIGLU_UP = 5 };
 // dst[f(r)][c] (ld_dst elements, zero-padded columns up to cols_dst) = convert(src[r][c])
 // PACK_ROPE_QKV: rows [0, 2*aux_d) (q and k sections of a fused qkv weight, heads of aux_hd) get their head dims
 // pair-interleaved: dim i of the first half and dim i of the second half become neighbours (2i, 2i+1)

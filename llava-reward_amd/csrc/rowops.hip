@@ -185,7 +185,8 @@ void launch_clip_embed(const float* patch_out, const float* cls, const float* po
 // row-major order), rw_model:420/439 (last valid index).  tstat[b] = {last_valid, first_valid, n_img, n_valid}.
 __global__ __launch_bounds__(256) void token_plan_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask,
                                                          int S, const int* __restrict__ voff, int* __restrict__ img_row,
-                                                         int* __restrict__ pos, int* __restrict__ tstat) {
+                                                         int* __restrict__ pos, int* __restrict__ tstat, long image_token_id,
+                                                         int pos_arange) {
     __shared__ int wsum[2][4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int run_m = 0, run_n = 0, last = -1, first = S;
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void token_plan_kernel(const int64_t* __restri
         if (s < S) {
             m = mask[(size_t)b * S + s] != 0;
             const int64_t id = ids[(size_t)b * S + s];
-            n = id < 0 && id > -1000000000LL;
+            n = image_token_id >= 0 ? (id == image_token_id) : (id < 0 && id > -1000000000LL);
         }
         const unsigned long long bm = __ballot(m), bn = __ballot(n);
         const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void token_plan_kernel(const int64_t* __restri
             tm += wsum[0][w]; tn += wsum[1][w];
         }
         if (s < S) {
-            pos[(size_t)b * S + s] = m ? (om + pm) : 1;         // cumsum(mask) - 1, pads -> 1
+            pos[(size_t)b * S + s] = pos_arange ? s : (m ? (om + pm) : 1);     // arange | cumsum(mask) - 1, pads -> 1
             img_row[(size_t)b * S + s] = n ? (voff[b] + on + pn) : -1;
             if (m) { last = s; if (s < first) first = s; }
         }
@@ -233,9 +234,9 @@ __global__ __launch_bounds__(256) void token_plan_kernel(const int64_t* __restri
 }
 
 void launch_token_plan(const int64_t* ids, const int64_t* mask, int B, int S, const int* voff, int* img_row, int* pos,
-                       int* tstat, hipStream_t st) {
+                       int* tstat, hipStream_t st, long image_token_id, int pos_arange) {
     if (B <= 0) return;
-    hipLaunchKernelGGL(token_plan_kernel, dim3(B), dim3(256), 0, st, ids, mask, S, voff, img_row, pos, tstat);
+    hipLaunchKernelGGL(token_plan_kernel, dim3(B), dim3(256), 0, st, ids, mask, S, voff, img_row, pos, tstat, image_token_id, pos_arange);
 }
 
 // --------------------------------------------------------------------------------------- embedding
@@ -301,32 +302,31 @@ void launch_rope_table(const int* pos, const int* tstat, int B, int S, const flo
 // Fallback path for problems too small for the GEMM with the fused RoPE epilogue.
 template <typename OT>
 __global__ __launch_bounds__(256) void rope_split_kernel(const float* __restrict__ qkv, const float* __restrict__ cs,
-                                                         void* __restrict__ out, int D, int heads) {
+                                                         void* __restrict__ out, int rope_cols, int v_cols, int hd) {
     const int row = blockIdx.x;
-    const int hd = D / heads, half = hd >> 1;
-    const float* src = qkv + (size_t)row * 3 * D;
+    const int half = hd >> 1, ld = rope_cols + v_cols;
+    const float* src = qkv + (size_t)row * ld;
     const float4* t = (const float4*)(cs + (size_t)row * 2 * half);      // (c0,s0,c1,s1) per float4
-    const int quads = 2 * D / 4;                                       // 4 columns = 2 pairs
-    for (int it = threadIdx.x; it < quads; it += 256) {
+    for (int it = threadIdx.x; it < (rope_cols >> 2); it += 256) {        // 4 columns = 2 pairs
         const int col = 4 * it;
         const int i0 = (col % hd) >> 1;
         const float4 x = *(const float4*)(src + col);
         const float4 c = t[i0 >> 1];
-        store4<OT>(out, (size_t)row * 3 * D + col, x.x * c.x - x.y * c.y, x.y * c.x + x.x * c.y,
+        store4<OT>(out, (size_t)row * ld + col, x.x * c.x - x.y * c.y, x.y * c.x + x.x * c.y,
                    x.z * c.z - x.w * c.w, x.w * c.z + x.z * c.w);
     }
-    for (int c = threadIdx.x; c < (D >> 2); c += 256) {
-        const float4 v = *(const float4*)(src + 2 * D + 4 * c);
-        store4<OT>(out, (size_t)row * 3 * D + 2 * D + 4 * c, v.x, v.y, v.z, v.w);
+    for (int c = threadIdx.x; c < (v_cols >> 2); c += 256) {
+        const float4 v = *(const float4*)(src + rope_cols + 4 * c);
+        store4<OT>(out, (size_t)row * ld + rope_cols + 4 * c, v.x, v.y, v.z, v.w);
     }
 }
 
-void launch_rope_split(const float* qkv32, const float* cs, void* out, int rows, int D, int heads, int operand_dtype,
-                       hipStream_t st) {
+void launch_rope_split(const float* qkv32, const float* cs, void* out, int rows, int rope_cols, int v_cols, int hd,
+                       int operand_dtype, hipStream_t st) {
     if (rows <= 0) return;
-    if ((D / heads) % 8) throw std::runtime_error("rope_split: head_dim must be a multiple of 8");
-    if (operand_dtype == DT_F16) hipLaunchKernelGGL((rope_split_kernel<F16>), dim3(rows), dim3(256), 0, st, qkv32, cs, out, D, heads);
-    else hipLaunchKernelGGL((rope_split_kernel<BF16>), dim3(rows), dim3(256), 0, st, qkv32, cs, out, D, heads);
+    if (hd % 8 || rope_cols % hd || v_cols % 4) throw std::runtime_error("rope_split: bad geometry");
+    if (operand_dtype == DT_F16) hipLaunchKernelGGL((rope_split_kernel<F16>), dim3(rows), dim3(256), 0, st, qkv32, cs, out, rope_cols, v_cols, hd);
+    else hipLaunchKernelGGL((rope_split_kernel<BF16>), dim3(rows), dim3(256), 0, st, qkv32, cs, out, rope_cols, v_cols, hd);
 }
 
 // ------------------------------------------------------------------------------------- HD gather
@@ -383,6 +383,61 @@ void launch_hd_gather(const float* clipx, const HdSample* samples, int B, int to
     dim3 gr(cdiv(total_rows, 4)), t(256);
     if (operand_dtype == DT_F16) hipLaunchKernelGGL((hd_gather_kernel<F16>), gr, t, 0, st, clipx, samples, B, total_rows, T, H, g, sub_gn, glb_gn, out);
     else hipLaunchKernelGGL((hd_gather_kernel<BF16>), gr, t, 0, st, clipx, samples, B, total_rows, T, H, g, sub_gn, glb_gn, out);
+}
+
+// ------------------------------------------------------------------------------------------ LLaVA
+template <typename OT>
+__global__ __launch_bounds__(256) void clip_tokens_kernel(const float* __restrict__ clipx, void* __restrict__ out, int rows, int T, int H) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int crop = row / (T - 1), t = row - crop * (T - 1);
+    const float4* src = (const float4*)(clipx + ((size_t)crop * T + 1 + t) * H);
+    for (int c = lane; c < (H >> 2); c += 64) {
+        const float4 v = src[c];
+        store4<OT>(out, (size_t)row * H + 4 * c, v.x, v.y, v.z, v.w);
+    }
+}
+
+void launch_clip_tokens(const float* clipx, void* out, int ncrop, int T, int H, int operand_dtype, hipStream_t st) {
+    const int rows = ncrop * (T - 1);
+    if (rows <= 0) return;
+    if (operand_dtype == DT_F16) hipLaunchKernelGGL((clip_tokens_kernel<F16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, clipx, out, rows, T, H);
+    else hipLaunchKernelGGL((clip_tokens_kernel<BF16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, clipx, out, rows, T, H);
+}
+
+// modeling_llava_next.py:265-335 pack_image_features ("spatial_unpad"): per image [base crop; un-padded grid + newline column]
+__global__ __launch_bounds__(256) void llava_pack_kernel(const float* __restrict__ proj, const LlavaSample* __restrict__ smp, int B,
+                                                         int total_rows, int g, int D, const float* __restrict__ newline,
+                                                         float* __restrict__ ev) {
+    const int R = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (R >= total_rows) return;
+    int b = 0;
+    while (b + 1 < B && smp[b + 1].voff <= R) ++b;
+    const LlavaSample sm = smp[b];
+    const int local = R - sm.voff, gg = g * g;
+    const float* src;
+    if (local < gg) {
+        src = proj + ((size_t)sm.crop0 * gg + local) * D;
+    } else {
+        const int q = local - gg, wrow = sm.c1 - sm.c0 + 1;
+        const int y = sm.r0 + q / wrow, xx = q % wrow;
+        if (xx == wrow - 1) src = newline;
+        else {
+            const int x = sm.c0 + xx;
+            const int crop = sm.crop0 + 1 + (y / g) * sm.gw + x / g;
+            src = proj + ((size_t)crop * gg + (y % g) * g + (x % g)) * D;
+        }
+    }
+    float4* dst = (float4*)(ev + (size_t)R * D);
+    for (int c = lane; c < (D >> 2); c += 64) dst[c] = ((const float4*)src)[c];
+}
+
+void launch_llava_pack(const float* proj, const LlavaSample* samples, int B, int total_rows, int g, int D,
+                       const float* newline, float* ev, hipStream_t st) {
+    if (total_rows <= 0) return;
+    hipLaunchKernelGGL(llava_pack_kernel, dim3(cdiv(total_rows, 4)), dim3(256), 0, st, proj, samples, B, total_rows, g, D, newline, ev);
 }
 
 // ------------------------------------------------------------------------------------------- tail
@@ -600,6 +655,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
             const int g = r < I ? r : r - I;
             const int rr = (g >> 5) * 64 + (r < I ? 0 : 32) + (g & 31);
             o = (size_t)rr * ld_dst + c;
+        } else if (mode == PACK_SWIGLU_GATE || mode == PACK_SWIGLU_UP) {
+            // separate gate_proj / up_proj tensors written into one interleaved [2I, K] buffer
+            o = (size_t)((r >> 5) * 64 + (mode == PACK_SWIGLU_UP ? 32 : 0) + (r & 31)) * ld_dst + c;
         } else if (mode == PACK_ROPE_QKV) {
             int rr = r;
             if (r < 2 * aux_d) {
@@ -622,6 +680,7 @@ void launch_pack(const float* src, void* dst, int rows, int cols, int ld_dst, in
     const size_t total = (size_t)rows * cols_dst;
     if (!total) return;
     if (mode == PACK_SWIGLU && ((rows >> 1) % 32)) throw std::runtime_error("pack: SwiGLU interleave needs I % 32 == 0");
+    if ((mode == PACK_SWIGLU_GATE || mode == PACK_SWIGLU_UP) && (rows % 32)) throw std::runtime_error("pack: SwiGLU interleave needs I % 32 == 0");
     const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
     hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, st, src, dst, rows, cols, ld_dst, cols_dst, dst_dtype, mode, aux_d, aux_hd);
 }

@@ -9,6 +9,8 @@ from ._build import LIB_PATH
 LR_DT_BF16, LR_DT_F16, LR_DT_F32 = 0, 1, 2
 LR_FWD_TRAINING_LAST_TOKEN = 1
 LR_MAX_HALF_HEAD = 64
+LR_MAX_PINPOINTS = 8
+LR_BACKBONE_PHI3V, LR_BACKBONE_LLAVA_NEXT = 0, 1
 EPI_OUT_OP, EPI_OUT_F32, EPI_RESADD_F32, EPI_SWIGLU_OP, EPI_ROPE_OP = 0, 1, 2, 3, 4
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2
 
@@ -30,6 +32,8 @@ class ModelDesc(C.Structure):
         ("ca_eps", C.c_float),
         ("max_batch", C.c_int32), ("max_seq", C.c_int32), ("max_crops", C.c_int32),
         ("operand_dtype", C.c_int32),
+        ("backbone", C.c_int32), ("kv_heads", C.c_int32), ("head_dim", C.c_int32), ("image_token_id", C.c_int32),
+        ("n_pinpoints", C.c_int32), ("pinpoints", C.c_int32 * (2 * LR_MAX_PINPOINTS)),
     ]
 
 
@@ -53,7 +57,7 @@ _SIGS = {
     "lr_set_gemm_tile": (C.c_int, [C.c_void_p, C.c_int]),
     "lr_op_gemm_bt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]),
     "lr_op_gemm_rope": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_void_p]),
-    "lr_op_attention": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 10 + [C.c_float, C.c_int, C.c_void_p]),
+    "lr_op_attention": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 11 + [C.c_float, C.c_int, C.c_void_p]),
     "lr_op_norm_rows": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "lr_op_synth_fill": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_char_p, C.c_float, C.c_float, C.c_int, C.c_void_p]),
 }

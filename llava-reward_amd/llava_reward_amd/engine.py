@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .synth import RewardConfig
+from .synth import LlavaConfig, RewardConfig
 
 _DT = {"bf16": L.LR_DT_BF16, "f16": L.LR_DT_F16, "fp16": L.LR_DT_F16}
 
@@ -22,28 +22,43 @@ def rope_inv_freq(factors, head_dim: int, theta: float) -> torch.Tensor:
     return 1.0 / (ext * theta ** inv_shape)
 
 
-def make_desc(cfg: RewardConfig, max_batch: int, max_seq: int, max_crops: int, operand_dtype: str) -> L.ModelDesc:
+def make_desc(cfg, max_batch: int, max_seq: int, max_crops: int, operand_dtype: str) -> L.ModelDesc:
     d = L.ModelDesc()
     d.struct_size = C.sizeof(L.ModelDesc)
     d.vocab_size, d.hidden, d.intermediate = cfg.vocab_size, cfg.hidden, cfg.intermediate
     d.layers, d.heads = cfg.layers, cfg.heads
     d.rms_eps = cfg.rms_eps
-    d.orig_max_pos = cfg.orig_max_pos
-    scale = cfg.max_pos / cfg.orig_max_pos
-    d.rope_scaling = 1.0 if scale <= 1.0 else math.sqrt(1 + math.log(scale) / math.log(cfg.orig_max_pos))
     half = cfg.head_dim // 2
     if half > L.LR_MAX_HALF_HEAD:
         raise ValueError("head_dim too large")
-    for dst, fac in ((d.inv_freq_short, cfg.short_factor), (d.inv_freq_long, cfg.long_factor)):
-        inv = rope_inv_freq(fac, cfg.head_dim, cfg.rope_theta)
+    if isinstance(cfg, LlavaConfig):
+        d.backbone = L.LR_BACKBONE_LLAVA_NEXT
+        d.kv_heads, d.head_dim, d.image_token_id = cfg.kv_heads, cfg.head_dim, cfg.image_token_id
+        d.orig_max_pos, d.rope_scaling = 1 << 30, 1.0        # plain RoPE (modeling_mistral.py MistralRotaryEmbedding)
+        inv = rope_inv_freq([1.0] * half, cfg.head_dim, cfg.rope_theta)
         for i in range(half):
-            dst[i] = float(inv[i])
+            d.inv_freq_short[i] = d.inv_freq_long[i] = float(inv[i])
+        if len(cfg.pinpoints) > L.LR_MAX_PINPOINTS:
+            raise ValueError("too many image_grid_pinpoints")
+        d.n_pinpoints = len(cfg.pinpoints)
+        for i, (ph, pw) in enumerate(cfg.pinpoints):
+            d.pinpoints[2 * i], d.pinpoints[2 * i + 1] = ph, pw
+    else:
+        d.backbone = L.LR_BACKBONE_PHI3V
+        d.kv_heads, d.head_dim, d.image_token_id = cfg.heads, cfg.head_dim, -1
+        d.orig_max_pos = cfg.orig_max_pos
+        scale = cfg.max_pos / cfg.orig_max_pos
+        d.rope_scaling = 1.0 if scale <= 1.0 else math.sqrt(1 + math.log(scale) / math.log(cfg.orig_max_pos))
+        for dst, fac in ((d.inv_freq_short, cfg.short_factor), (d.inv_freq_long, cfg.long_factor)):
+            inv = rope_inv_freq(fac, cfg.head_dim, cfg.rope_theta)
+            for i in range(half):
+                dst[i] = float(inv[i])
     c = cfg.clip
     d.clip_hidden, d.clip_heads, d.clip_mlp, d.clip_layers = c.hidden, c.heads, c.mlp, c.layers_used
     d.clip_image, d.clip_patch, d.clip_ln_eps = c.image, c.patch, c.ln_eps
     d.value_head_dim = cfg.value_head_dim
     d.add_cross_attention = int(bool(cfg.add_cross_attention))
-    d.ca_eps = cfg.ca_eps
+    d.ca_eps = getattr(cfg, "ca_eps", 1e-5)
     d.max_batch, d.max_seq, d.max_crops = max_batch, max_seq, max_crops
     d.operand_dtype = _DT[operand_dtype]
     return d
@@ -52,7 +67,7 @@ def make_desc(cfg: RewardConfig, max_batch: int, max_seq: int, max_crops: int, o
 class RewardEngine:
     """Owns one lr_handle (one GPU).  Not thread-safe; forward() enqueues on the current torch stream."""
 
-    def __init__(self, cfg: RewardConfig, device: int = 0, max_batch: int = 32, max_seq: int = 2816,
+    def __init__(self, cfg, device: int = 0, max_batch: int = 32, max_seq: int = 2816,
                  max_crops: int = 17, operand_dtype: str = "f16"):
         if not torch.cuda.is_available():
             raise RuntimeError("RewardEngine needs a HIP device (torch.cuda.is_available() is False); "

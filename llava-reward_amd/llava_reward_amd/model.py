@@ -13,13 +13,11 @@ from typing import Dict, Optional
 
 import torch
 
-from .synth import RewardConfig
+from .synth import LlavaConfig, RewardConfig, llava_geometry
 
 
 class RewardModel:
-    model_type = "phi3v"
-
-    def __init__(self, cfg: RewardConfig, weights: Optional[Dict[str, torch.Tensor]] = None, synth_seed: Optional[int] = None,
+    def __init__(self, cfg, weights: Optional[Dict[str, torch.Tensor]] = None, synth_seed: Optional[int] = None,
                  max_batch: int = 32, max_seq: int = 2816, max_crops: int = 17, operand_dtype: str = "f16",
                  layer_id: int = 32, mean_hidden_state=None):
         if weights is None and synth_seed is None:
@@ -29,6 +27,7 @@ class RewardModel:
         if layer_id not in (32, cfg.layers):
             raise NotImplementedError("only the last-layer hidden state (layer_id == 32) is implemented")
         self.config = cfg
+        self.model_type = "llava" if isinstance(cfg, LlavaConfig) else "phi3v"
         self._weights = weights
         self._synth_seed = synth_seed
         self._opts = dict(max_batch=max_batch, max_seq=max_seq, max_crops=max_crops, operand_dtype=operand_dtype)
@@ -90,14 +89,23 @@ class RewardModel:
             raise UnboundLocalError("img_token_batch_embedding: every row must carry an image")
         if input_ids.dim() == 3:
             input_ids = input_ids.squeeze(1)
-        n_slots = (input_ids < 0).sum(dim=1).cpu()
-        g2 = self.config.clip.grid // 2
         sz = torch.as_tensor(image_sizes).cpu().long()
-        img = self.config.clip.image
-        expect = (sz[:, 0] // img) * g2 * ((sz[:, 1] // img) * g2 + 1) + 1 + g2 * (g2 + 1)
-        if not torch.equal(n_slots.long(), expect):
-            raise RuntimeError(f"shape mismatch: image slots per row {n_slots.tolist()} != projected image tokens "
-                               f"{expect.tolist()} (modeling_phi3_v.py:247 index_put)")
+        if self.model_type == "llava":
+            # rw_model:372-375 -> LlavaNext forward: image_sizes are the ORIGINAL (h, w); slots are image_token_id
+            n_slots = (input_ids == self.config.image_token_id).sum(dim=1).cpu()
+            expect = torch.tensor([llava_geometry(int(h), int(w), self.config.pinpoints, self.config.clip.image,
+                                                  self.config.clip.grid)[6] for h, w in sz.tolist()])
+            if not torch.equal(n_slots.long(), expect):
+                raise ValueError(f"Image features and image tokens do not match, tokens: {n_slots.tolist()}, "
+                                 f"features: {expect.tolist()}")          # modeling_llava_next.py get_placeholder_mask
+        else:
+            n_slots = (input_ids < 0).sum(dim=1).cpu()
+            g2 = self.config.clip.grid // 2
+            img = self.config.clip.image
+            expect = (sz[:, 0] // img) * g2 * ((sz[:, 1] // img) * g2 + 1) + 1 + g2 * (g2 + 1)
+            if not torch.equal(n_slots.long(), expect):
+                raise RuntimeError(f"shape mismatch: image slots per row {n_slots.tolist()} != projected image tokens "
+                                   f"{expect.tolist()} (modeling_phi3_v.py:247 index_put)")
         reward = self.engine.forward(input_ids, attention_mask, pixel_values, sz, training=self.training)
         if return_output:
             B, D = reward.shape[0], self.config.hidden

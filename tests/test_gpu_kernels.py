@@ -162,7 +162,7 @@ def test_attention(lib, dt, case):
         mask = mask.cuda()
     out = torch.zeros(B * S, D, device="cuda", dtype=tdt)
     scale = 1.0 / math.sqrt(hd)
-    rc = lib.lr_op_attention(P(qkv), P(qkv), P(qkv), P(out), P(mask), P(kmin), 3 * D, D, 0, D, 2 * D, B, S, H, hd, int(causal),
+    rc = lib.lr_op_attention(P(qkv), P(qkv), P(qkv), P(out), P(mask), P(kmin), 3 * D, D, 0, D, 2 * D, B, S, H, hd, int(causal), 1,
                              scale, code, stream())
     assert rc == 0
     f = qkv.float().view(B, S, 3, H, hd)
@@ -193,3 +193,34 @@ def test_norm_rows(lib, dt, H):
     assert lib.lr_op_norm_rows(P(x), P(w), P(None), P(y), rows, H, 1e-5, code, stream()) == 0
     ref = w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5))
     assert ((y.float() - ref).abs() <= ulp * ref.abs() + 1e-5).all()
+
+
+@pytest.mark.parametrize("dt", DTS, ids=[d[0] for d in DTS])
+@pytest.mark.parametrize("case", [(2, 8, 2, 333), (1, 4, 4, 700), (2, 4, 1, 130)])
+def test_attention_gqa_head_dim_128(lib, dt, case):
+    """Mistral-style attention of the LLaVA branch: head_dim 128, several query heads per K/V head, causal + left padding."""
+    _, code, tdt, ulp = dt
+    B, H, KV, S = case
+    hd = 128
+    Hq, Hkv = H * hd, KV * hd
+    ld = Hq + 2 * Hkv
+    qkv = rnd((B * S, ld), 41).to(tdt)
+    mask = torch.ones(B, S, dtype=torch.int64)
+    for b in range(B):
+        mask[b, : 29 * b] = 0
+    kmin = torch.tensor([29 * b for b in range(B)], dtype=torch.int32).cuda()
+    mask = mask.cuda()
+    out = torch.zeros(B * S, Hq, device="cuda", dtype=tdt)
+    scale = 1.0 / math.sqrt(hd)
+    rc = lib.lr_op_attention(P(qkv), P(qkv), P(qkv), P(out), P(mask), P(kmin), ld, Hq, 0, Hq, Hq + Hkv, B, S, H, hd, 1, H // KV,
+                             scale, code, stream())
+    assert rc == 0
+    f = qkv.float()
+    q = f[:, :Hq].view(B, S, H, hd).permute(0, 2, 1, 3)
+    k = f[:, Hq:Hq + Hkv].view(B, S, KV, hd).permute(0, 2, 1, 3).repeat_interleave(H // KV, dim=1)
+    v = f[:, Hq + Hkv:].view(B, S, KV, hd).permute(0, 2, 1, 3).repeat_interleave(H // KV, dim=1)
+    ref = _attn_ref(q, k, v, mask, True, scale).permute(0, 2, 1, 3).reshape(B * S, Hq)
+    valid = mask.bool().reshape(-1)
+    err = (out.float() - ref).abs()[valid]
+    assert err.max().item() < 2.5 * ulp * v.abs().max().item(), err.max().item()
+    assert (out.float()[~valid] == 0).all()

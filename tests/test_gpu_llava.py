@@ -1,0 +1,81 @@
+"""LLaVA-1.6 (LlavaNext + Mistral) reward path on the HIP engine: parity against the CPU oracle and against
+goldens produced by the reference's own custom_forward (model_type='llava', rw_model_general_preference.py:372-375).
+Tolerance 1e-3 (f16 operands); bf16 operands 8e-3."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from llava_reward_amd import synth
+from llava_reward_amd.model import RewardModel
+from oracle import llava_next_reward_oracle as lorc
+from oracle import phi3v_reward_oracle as orc
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _model(cfg, seed, dtype, upload, max_seq=4096):
+    if upload:
+        W = {k: torch.from_numpy(v) for k, v in synth.llava_make_weights(cfg, seed).items()}
+        m = RewardModel(cfg, weights=W, max_batch=3, max_seq=max_seq, max_crops=5, operand_dtype=dtype)
+    else:
+        m = RewardModel(cfg, synth_seed=seed, max_batch=3, max_seq=max_seq, max_crops=5, operand_dtype=dtype)
+    return m.to("cuda").eval()
+
+
+def _fwd(m, batch, rows=None):
+    tb = {k: torch.from_numpy(v if rows is None else v[rows]).cuda() for k, v in batch.items()}
+    r, _ = m.custom_forward(inputs_batch=tb)           # the llava branch takes inputs_batch only (rw_model:372-375)
+    torch.cuda.synchronize()
+    return r.cpu()
+
+
+@pytest.mark.parametrize("dtype,tol", [("f16", 1e-3), ("bf16", 8e-3)])
+@pytest.mark.parametrize("gpm", [False, True])
+def test_llava_tiny_vs_oracle(dtype, tol, gpm):
+    cfg = synth.llava_tiny_config(**(dict(is_general_preference=True, value_head_dim=2) if gpm else {}))
+    seed = 21
+    batch = synth.llava_synth_batch(cfg, seed, [7, 3, 5], [(336, 336), (512, 640), (300, 900)], max_crops=5)
+    W = orc.weights_to_torch(synth.llava_make_weights(cfg, seed))
+    ref = lorc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"])
+    m = _model(cfg, seed, dtype, upload=True)
+    assert m.model_type == "llava"
+    got = _fwd(m, batch)
+    err = (got - ref).abs().max().item()
+    print(f"[llava tiny gpm={gpm} {dtype}] max |reward err| = {err:.3e} rewards={got.flatten().tolist()}")
+    assert got.shape == ref.shape and err < tol
+    m2 = _model(cfg, seed, dtype, upload=False)         # device-side synthetic weights == uploaded ones
+    assert torch.equal(_fwd(m2, batch), got)
+    for b in range(3):                                  # batch invariance, bit-exact
+        assert torch.equal(_fwd(m2, batch, rows=slice(b, b + 1))[0], got[b])
+
+
+CASES = sorted(glob.glob(os.path.join(GOLD, "ref_llava_*.json")))
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-5] for p in CASES])
+def test_llava_reference_goldens(path):
+    g = json.load(open(path))
+    cfg = synth.LlavaConfig.from_json(g["config"])
+    batch = synth.llava_synth_batch(cfg, g["seed"], g["caption_lens"], [tuple(x) for x in g["image_sizes"]], max_crops=g["max_crops"])
+    ref = torch.tensor(g["reward"], dtype=torch.float32)
+    m = _model(cfg, g["seed"], "f16", upload=False)
+    got = _fwd(m, batch).reshape(ref.shape)
+    err = (got - ref).abs().max().item()
+    print(f"[{g['name']}] max |reward err| vs reference = {err:.3e}")
+    assert err < 1e-3
+
+
+def test_llava_slot_mismatch_raises():
+    cfg = synth.llava_tiny_config()
+    batch = synth.llava_synth_batch(cfg, 3, [4], [(336, 336)])
+    m = _model(cfg, 3, "f16", upload=False)
+    bad = dict(batch)
+    bad["input_ids"] = batch["input_ids"].copy()
+    bad["input_ids"][0, -2] = cfg.image_token_id
+    with pytest.raises(ValueError, match="do not match"):
+        _fwd(m, bad)

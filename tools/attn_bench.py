@@ -19,7 +19,7 @@ def run(lib, name, B, S, H, hd, causal, reps=5):
     kmin = torch.zeros(B, dtype=torch.int32, device="cuda") if causal else None
     st = torch.cuda.current_stream()
     P = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
-    args = (P(qkv), P(qkv), P(qkv), P(out), P(mask), P(kmin), 3 * D, D, 0, D, 2 * D, B, S, H, hd, int(causal), 1.0 / math.sqrt(hd),
+    args = (P(qkv), P(qkv), P(qkv), P(out), P(mask), P(kmin), 3 * D, D, 0, D, 2 * D, B, S, H, hd, int(causal), 1, 1.0 / math.sqrt(hd),
             L.LR_DT_F16, C.c_void_p(st.cuda_stream))
     assert lib.lr_op_attention(*args) == 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
