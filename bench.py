@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="MFMA operand type")
     ap.add_argument("--tile", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="phi3v", choices=["phi3v", "llava"],
+                    help="phi3v = BASELINE metric (default); llava = LLaVA-v1.6-Mistral-7B shapes of configs[4] with 16-bit operands")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests)")
     ap.add_argument("--all-ranks-on-device", type=int, default=-1, help="smoke test: put every rank on this one GPU")
     a = ap.parse_args()
@@ -141,18 +143,26 @@ def main():
     from llava_reward_amd.model import RewardModel
     from llava_reward_amd.scoring import gather_rewards
 
-    cfg = synth.full_config()                       # BT head (d=1) + SkipCA
     B = a.batch
-    gb = synth.synth_batch(cfg, 1234, [128] * (B * world), (4, 4), with_pixels=False)
-    S = gb["input_ids"].shape[1]
     rows = slice(rank * B, (rank + 1) * B)          # contiguous shard: gathered order == input order
+    gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    if a.model == "llava":
+        cfg = synth.llava_full_config()             # Mistral-7B decoder + CLIP-L, BT head, no SkipCA on this branch
+        gb = synth.llava_synth_batch(cfg, 1234, [128] * (B * world), [(336, 336)] * (B * world), with_pixels=False)
+        ncrop, flop_per_pair = 3, 19.9e12           # 3 crops -> 1176 image tokens; see DESIGN.md §9
+        workload = "LLaVA-v1.6-Mistral-7B (BASELINE configs[4] shapes, 16-bit operands), 3 crops/img, V=1176"
+    else:
+        cfg = synth.full_config()                   # BT head (d=1) + SkipCA
+        gb = synth.synth_batch(cfg, 1234, [128] * (B * world), (4, 4), with_pixels=False)
+        ncrop, flop_per_pair = 17, FLOP_PER_PAIR
+        workload = "BASELINE configs[1]: Phi-3.5-V BT head + SkipCA, 17 crops/img, V=2509"
+    S = gb["input_ids"].shape[1]
     ids = torch.from_numpy(gb["input_ids"][rows]).cuda()
     mask = torch.from_numpy(gb["attention_mask"][rows]).cuda()
     sizes = torch.from_numpy(gb["image_sizes"][rows])
-    gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
-    pix = torch.randn(B, 17, 3, 336, 336, device="cuda", generator=gen)      # CLIP-normalised pixel noise, fp32
+    pix = torch.randn(B, ncrop, 3, 336, 336, device="cuda", generator=gen)      # CLIP-normalised pixel noise, fp32
 
-    model = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=S, max_crops=17, operand_dtype=a.dtype).to(f"cuda:{local}").eval()
+    model = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=S, max_crops=max(ncrop, 5 if a.model == 'llava' else 17), operand_dtype=a.dtype).to(f"cuda:{local}").eval()
     if a.tile >= 0:
         model.engine.set_gemm_tile(a.tile)
 
@@ -186,21 +196,21 @@ def main():
 
     if rank == 0:
         value = world * B * a.steps / dt
-        tf_per_gpu = value * FLOP_PER_PAIR / world / 1e12
+        tf_per_gpu = value * flop_per_pair / world / 1e12
         res = {
-            "metric": "reward-pairs/sec (336px img, 128-tok caption) Phi-3.5-V", "value": value, "unit": "reward-pairs/sec",
+            "metric": "reward-pairs/sec (336px img, 128-tok caption) " + ("Phi-3.5-V" if a.model == "phi3v" else "LLaVA-v1.6-Mistral-7B"), "value": value, "unit": "reward-pairs/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": f"{a.dtype} MFMA operands (bf16-valued weights), f32 accumulate/residual/softmax",
             "data": "synthetic (seeded weights and inputs; no checkpoint offline)",
-            "config": {"workload": "BASELINE configs[1]: Phi-3.5-V BT head + SkipCA, 17 crops/img, V=2509, S=%d" % S,
+            "config": {"workload": workload + ", S=%d" % S,
                        "rows_per_gpu": B, "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
                        "collective": "all_gather rewards [B,1] fp32" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "achieved": tf_per_gpu, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf_per_gpu / PEAK_TFLOPS, "traffic": None,
-                         "note": "whole pass: pairs/s x 26.86 TFLOP algorithmic per pair, per GPU"},
+                         "note": "whole pass: pairs/s x %.2f TFLOP algorithmic per pair, per GPU" % (flop_per_pair / 1e12)},
         }
-        if world == 1:
+        if world == 1 and a.model == "phi3v":
             res["roofline"]["dominant_kernel"] = dominant_kernel_probe(L.LR_DT_F16 if a.dtype == "f16" else L.LR_DT_BF16, a.tile)
             if not a.no_cpu_baseline:
                 del model

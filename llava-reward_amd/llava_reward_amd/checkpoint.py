@@ -19,7 +19,7 @@ from typing import Dict, Tuple
 
 import torch
 
-from .synth import ClipConfig, RewardConfig
+from .synth import ClipConfig, LlavaConfig, RewardConfig
 
 
 def config_from_hf(path: str, reward_cfg: dict) -> RewardConfig:
@@ -52,7 +52,48 @@ def config_from_hf(path: str, reward_cfg: dict) -> RewardConfig:
         general_preference_tau=float(reward_cfg["general_preference_tau"]))
 
 
-def read_base_weights(path: str, wanted) -> Dict[str, torch.Tensor]:
+def llava_config_from_hf(path: str, reward_cfg: dict) -> LlavaConfig:
+    """llava-hf/llava-v1.6-*-hf config.json (LlavaNextConfig: text_config / vision_config) + reward_config.yaml."""
+    with open(os.path.join(path, "config.json")) as f:
+        c = json.load(f)
+    t, v = c.get("text_config") or {}, c.get("vision_config") or {}
+    if c.get("vision_feature_layer", -2) != -2 or c.get("vision_feature_select_strategy", "default") != "default":
+        raise NotImplementedError("only vision_feature_layer=-2 with the 'default' (CLS dropped) strategy is implemented")
+    if t.get("sliding_window") not in (None, 0):
+        raise NotImplementedError("sliding-window attention is not implemented (Mistral v0.2 text towers have none)")
+    if reward_cfg["add_cross_attention"]:
+        raise AttributeError("'LlavaNextConfig' object has no attribute 'hidden_size'")      # rw_model:315 with llava
+    heads = t.get("num_attention_heads", 32)
+    hidden = t.get("hidden_size", 4096)
+    layers_total = v.get("num_hidden_layers", 24)
+    clip = ClipConfig(hidden=v.get("hidden_size", 1024), heads=v.get("num_attention_heads", 16),
+                      mlp=v.get("intermediate_size", 4096), layers_used=layers_total - 1,
+                      image=v.get("image_size", 336), patch=v.get("patch_size", 14), ln_eps=v.get("layer_norm_eps", 1e-5))
+    return LlavaConfig(
+        vocab_size=t.get("vocab_size", 32064), hidden=hidden, intermediate=t.get("intermediate_size", 14336),
+        layers=t.get("num_hidden_layers", 32), heads=heads, kv_heads=t.get("num_key_value_heads", 8),
+        head_dim=t.get("head_dim") or hidden // heads, rms_eps=t.get("rms_norm_eps", 1e-5),
+        rope_theta=t.get("rope_theta", 1000000.0), clip=clip,
+        image_token_id=c.get("image_token_index", c.get("image_token_id", 32000)),
+        pad_token_id=t.get("pad_token_id") or c.get("pad_token_id") or 32001,
+        pinpoints=tuple(tuple(p) for p in c.get("image_grid_pinpoints", [[336, 672], [672, 336], [672, 672], [1008, 336], [336, 1008]])),
+        is_general_preference=bool(reward_cfg["is_general_preference"]), add_cross_attention=False,
+        value_head_dim=int(reward_cfg["value_head_dim"]), general_preference_tau=float(reward_cfg["general_preference_tau"]))
+
+
+def canon_llava_key(k: str) -> str:
+    """Accept both checkpoint layouts: 4.50-era (language_model.model.layers..., vision_tower.vision_model...) and the
+    5.x module tree (model.language_model.layers..., model.vision_tower...)."""
+    n = k[len("model."):] if k.startswith("model.") else k
+    n = n.replace("language_model.layers.", "language_model.model.layers.")
+    n = n.replace("language_model.embed_tokens.", "language_model.model.embed_tokens.")
+    n = n.replace("language_model.norm.", "language_model.model.norm.")
+    if n.startswith("vision_tower.") and not n.startswith("vision_tower.vision_model."):
+        n = n.replace("vision_tower.", "vision_tower.vision_model.", 1)
+    return n
+
+
+def read_base_weights(path: str, wanted, canon=None) -> Dict[str, torch.Tensor]:
     """Read the tensors named in `wanted` from *.safetensors (or pytorch_model*.bin) under `path`."""
     wanted = set(wanted)
     out: Dict[str, torch.Tensor] = {}
@@ -62,12 +103,13 @@ def read_base_weights(path: str, wanted) -> Dict[str, torch.Tensor]:
         for fn in files:
             with safe_open(fn, framework="pt", device="cpu") as f:
                 for k in f.keys():
-                    if k in wanted:
-                        out[k] = f.get_tensor(k)
+                    ck = canon(k) if canon else k
+                    if ck in wanted:
+                        out[ck] = f.get_tensor(k)
     else:
         for fn in sorted(glob.glob(os.path.join(path, "pytorch_model*.bin"))):
             sd = torch.load(fn, map_location="cpu")
-            out.update({k: v for k, v in sd.items() if k in wanted})
+            out.update({(canon(k) if canon else k): v for k, v in sd.items() if (canon(k) if canon else k) in wanted})
     missing = wanted - set(out)
     if missing:
         raise FileNotFoundError(f"{path}: base checkpoint lacks {sorted(missing)[:4]} (+{max(0, len(missing) - 4)} more)")
@@ -101,11 +143,13 @@ def read_lora(lora_dir: str) -> Tuple[Dict[str, Tuple[torch.Tensor, torch.Tensor
     return out, scale
 
 
-def merge_lora(weights: Dict[str, torch.Tensor], lora: Dict[str, Tuple[torch.Tensor, torch.Tensor]], scale: float) -> int:
+def merge_lora(weights: Dict[str, torch.Tensor], lora: Dict[str, Tuple[torch.Tensor, torch.Tensor]], scale: float, canon=None) -> int:
     """In place: weights[mod + '.weight'] += scale * B @ A (fp32).  Returns the number of merged modules."""
     n = 0
     for mod, (A, B) in lora.items():
         key = mod + ".weight"
+        if canon:
+            key = canon(key)
         if key not in weights:
             continue                 # adapter targets outside the scoring path (e.g. CLIP layer 24)
         w = weights[key].float()
@@ -132,5 +176,8 @@ def read_heads(pm_path: str, cfg: RewardConfig, ft_projector: bool) -> Dict[str,
             if not pick(nm, nm + "."):
                 raise KeyError(f"pytorch_model.bin has no {nm}")
     if ft_projector:
-        pick("img_projection", "model.vision_embed_tokens.img_projection.", nparts=2)
+        if isinstance(cfg, LlavaConfig):          # reward_adaptor_loader.py:137-145
+            pick("multi_modal_projector", "multi_modal_projector.", nparts=2)
+        else:
+            pick("img_projection", "model.vision_embed_tokens.img_projection.", nparts=2)
     return out

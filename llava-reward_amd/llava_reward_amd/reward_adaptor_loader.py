@@ -11,7 +11,7 @@ import yaml
 
 from . import checkpoint as ckpt
 from .model import RewardModel
-from .synth import weight_specs
+from .synth import llava_weight_specs, weight_specs
 
 
 class UnknownModelType(UnboundLocalError, ValueError):
@@ -54,9 +54,31 @@ def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=Fal
                 tokenizer.pad_token = tokenizer.eos_token
                 tokenizer.pad_token_id = tokenizer.eos_token_id
             tokenizer.truncation_side = "right"
-    elif model_type in ("qwen", "llava"):
-        raise NotImplementedError(f"model_type={model_type!r}: the Qwen2.5-VL / LLaVA-1.6 backbones are SURVEY.md §8f "
-                                  "'next' rows; only 'phi3v' runs on the HIP path in this round")
+    elif model_type == "llava":                      # reward_adaptor_loader.py:110-148
+        if not os.path.isdir(args.pretrain):
+            raise FileNotFoundError(f"args.pretrain={args.pretrain!r} must be a local checkpoint directory "
+                                    "(config.json + *.safetensors); hub download is not available offline")
+        cfg = ckpt.llava_config_from_hf(args.pretrain, reward_cfg)
+        names = [n for n, *_ in llava_weight_specs(cfg)]
+        weights = ckpt.read_base_weights(args.pretrain, [n for n in names if n != "value_head.weight"], canon=ckpt.canon_llava_key)
+        lora, scale = ckpt.read_lora(os.path.join(args.pm_path, "lora"))
+        ckpt.merge_lora(weights, lora, scale, canon=ckpt.canon_llava_key)
+        weights.update(ckpt.read_heads(args.pm_path, cfg, getattr(args, "ft_projector", False)))
+        model = RewardModel(cfg, weights=weights, max_batch=getattr(args, "max_batch", 32),
+                            max_seq=getattr(args, "max_seq", 4096), max_crops=getattr(args, "max_crops", 5),
+                            operand_dtype=getattr(args, "operand_dtype", "f16"))
+        if load_tokenizer:
+            from transformers import LlavaNextProcessor
+            processor = LlavaNextProcessor.from_pretrained(args.pretrain, cache_dir=getattr(args, "cache_dir", None))   # utils/utils.py:46-55
+            tokenizer = processor.tokenizer
+            tokenizer.padding_side = "left"
+            if tokenizer.pad_token is None:
+                tokenizer.pad_token = tokenizer.eos_token
+                tokenizer.pad_token_id = tokenizer.eos_token_id
+            tokenizer.truncation_side = "right"
+    elif model_type == "qwen":
+        raise NotImplementedError("model_type='qwen': the Qwen2.5-VL backbone (SURVEY.md §8 row a19) is not on the HIP path yet; "
+                                  "'phi3v' and 'llava' are")
     else:
         raise UnknownModelType(f"local variable 'model' referenced before assignment (model_type={model_type!r})")
     if load_tokenizer:

@@ -216,6 +216,8 @@ def main():
         run_llava_case("ref_llava_tiny_gpm2", C(is_general_preference=True, value_head_dim=2), 12, [5, 9], [(512, 640), (336, 336)], 5)
         run_llava_case("ref_llava_tiny_wide", C(), 13, [4], [(300, 900)], None)
         run_llava_case("ref_llava_tiny_tall", C(layers=3), 14, [2, 7], [(400, 300), (672, 672)], 5)
+    elif which == "llava_full":
+        run_llava_case("ref_llava_full_bt", synth.llava_full_config(), 1234, [128], [(336, 336)], None)
     elif which == "full":
         run_case(ref, "ref_full_bt_ca", synth.full_config(), 1234, [128], (4, 4), None)
     elif which == "full_gpm":

@@ -215,3 +215,44 @@ def test_reward_model_requires_weights_or_seed():
         RewardModel(synth.tiny_config())
     with pytest.raises(NotImplementedError):
         RewardModel(synth.tiny_config(), synth_seed=1, mean_hidden_state=True)
+
+
+def test_load_reward_adaptor_llava(tmp_path):
+    """model_type='llava' (eval/reward_adaptor_loader.py:110-148): LlavaNext checkpoint layout, LoRA merge, heads."""
+    from safetensors.torch import save_file
+    cfg = synth.llava_tiny_config()
+    pre, pm = os.path.join(str(tmp_path), "pre"), os.path.join(str(tmp_path), "pm")
+    os.makedirs(pre); os.makedirs(os.path.join(pm, "lora"))
+    c = cfg.clip
+    json.dump({"image_token_index": cfg.image_token_id, "image_grid_pinpoints": [list(p) for p in cfg.pinpoints],
+               "vision_feature_layer": -2, "vision_feature_select_strategy": "default",
+               "text_config": {"vocab_size": cfg.vocab_size, "hidden_size": cfg.hidden, "intermediate_size": cfg.intermediate,
+                               "num_hidden_layers": cfg.layers, "num_attention_heads": cfg.heads, "num_key_value_heads": cfg.kv_heads,
+                               "head_dim": cfg.head_dim, "rms_norm_eps": cfg.rms_eps, "rope_theta": cfg.rope_theta, "sliding_window": None},
+               "vision_config": {"hidden_size": c.hidden, "num_attention_heads": c.heads, "intermediate_size": c.mlp,
+                                 "num_hidden_layers": c.layers_used + 1, "image_size": 336, "patch_size": 14}},
+              open(os.path.join(pre, "config.json"), "w"))
+    W = {k: torch.from_numpy(v) for k, v in synth.llava_make_weights(cfg, 9).items()}
+    # store the base in the 5.x module-tree naming to exercise the key canonicaliser
+    def new_name(k):
+        k = k.replace("language_model.model.", "language_model.")
+        k = k.replace("vision_tower.vision_model.", "vision_tower.")
+        return "model." + k
+    save_file({new_name(k): v.to(torch.bfloat16) for k, v in W.items() if k != "value_head.weight"}, os.path.join(pre, "model.safetensors"))
+    torch.save({"base_model.model.value_head.weight": W["value_head.weight"]}, os.path.join(pm, "pytorch_model.bin"))
+    yaml.safe_dump({"is_general_preference": False, "add_cross_attention": False, "value_head_dim": 1, "general_preference_tau": 0.1},
+                   open(os.path.join(pm, "reward_config.yaml"), "w"))
+    g = torch.Generator().manual_seed(2)
+    mod = "language_model.model.layers.1.self_attn.k_proj"
+    A, Bm = torch.randn(4, cfg.hidden, generator=g) * 0.1, torch.randn(cfg.kv_heads * cfg.head_dim, 4, generator=g) * 0.1
+    torch.save({f"base_model.model.{mod}.lora_A.weight": A, f"base_model.model.{mod}.lora_B.weight": Bm}, os.path.join(pm, "lora", "adapter_model.bin"))
+    json.dump({"r": 4, "lora_alpha": 8}, open(os.path.join(pm, "lora", "adapter_config.json"), "w"))
+    args = types.SimpleNamespace(pm_path=pm, pretrain=pre, cache_dir=None, ft_projector=False, disable_fast_tokenizer=False)
+    args, model = load_reward_adaptor(args, "llava", os.path.join(pm, "reward_config.yaml"))
+    assert model.model_type == "llava" and model.config.kv_heads == cfg.kv_heads and model.config.clip.layers_used == c.layers_used
+    assert set(n for n, *_ in synth.llava_weight_specs(cfg)) <= set(model._weights)
+    assert torch.allclose(model._weights[mod + ".weight"], W[mod + ".weight"] + 2.0 * Bm @ A, atol=1e-6)
+    yaml.safe_dump({"is_general_preference": False, "add_cross_attention": True, "value_head_dim": 1, "general_preference_tau": 0.1},
+                   open(os.path.join(pm, "reward_config.yaml"), "w"))
+    with pytest.raises(AttributeError):          # the reference dies the same way (rw_model:315)
+        load_reward_adaptor(args, "llava", os.path.join(pm, "reward_config.yaml"))
