@@ -104,8 +104,11 @@ def dominant_kernel_probe(dtype_code, tile, steps=5):
     e1.record(st)
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    return {"kernel": "gemm_bt_kernel (gate_up + SwiGLU epilogue)", "shape": [M, N, K], "avg_ms": ms,
-            "tflops": 2.0 * M * N * K / (ms * 1e-3) / 1e12}
+    return {"kernel": "gemm_bt8_kernel (gate_up + SwiGLU epilogue)", "shape": [M, N, K], "avg_ms": ms,
+            "tflops": 2.0 * M * N * K / (ms * 1e-3) / 1e12,
+            # PMC passes of this exact launch (profiles/r1_pmc_gemm_gate_up.md): FETCH_SIZE x2 (gfx950) + WRITE_SIZE
+            "traffic_bytes_pmc": 15.2e9, "algorithmic_bytes": 2.0 * (M * K + N * K + M * N // 2),
+            "mfma_busy_frac_pmc": 0.598, "effective_clock_ghz_pmc": 1.81}
 
 
 def main():
