@@ -66,6 +66,23 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         for (int j = 0; j < 2; ++j) boff[j * 2 + ks] = img_off(wc * 32 + j * 16 + l15, 4 * ks + l4);
     }
 
+    // DBG == 3: in-kernel stamps (cdna_hip_programming.md §7): cycles per segment, summed over all K-tiles, per phase
+    unsigned segs[4][4];     // [phase][LOAD, BAR1, COMPUTE, BAR2]
+    unsigned lsegs[3] = {0, 0, 0};   // LOAD split: LDS reads (incl. their latency), DMA issue, vmcnt wait
+    if constexpr (DBG == 3) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < 4; ++b2) segs[a][b2] = 0;
+    }
+    auto stamp = [&]() -> unsigned long long {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    };
+
     // ---- persistent walk over tiles: virtual block id vb keeps the XCD-aware order of gemm.hip ----
     for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
         int L;
@@ -156,6 +173,8 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
             const char* sA1 = smem + s3 * HT;
 #pragma unroll
             for (int ph = 0; ph < 4; ++ph) {
+                unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+                if constexpr (DBG == 3) t0 = stamp();
                 // ---------------- LOAD ----------------
                 if (ph == 0 || ph == 1 || ph == 3) {
                     const char* sb = (ph == 1) ? sB1 : sB0;
@@ -167,15 +186,25 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 #pragma unroll
                     for (int f = 0; f < 8; ++f) af[f] = *(const uint4*)(sa + aoff[f]);
                 }
+                unsigned long long ta = 0, tb = 0;
+                if constexpr (DBG == 3) ta = stamp();
                 if (gi < Gtot) {
                     issue((ph + PF) & 3, kt + ((ph + PF) >> 2), islot);
+                    if constexpr (DBG == 3) tb = stamp();
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PF - 2)) : "memory");
                 } else {
+                    if constexpr (DBG == 3) tb = stamp();
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if constexpr (DBG == 3) {
+                    const unsigned long long tc = stamp();
+                    lsegs[0] += (unsigned)(ta - t0); lsegs[1] += (unsigned)(tb - ta); lsegs[2] += (unsigned)(tc - tb);
                 }
                 ++gi;
                 islot = (islot + 1 == NS) ? 0 : islot + 1;
+                if constexpr (DBG == 3) t1 = stamp();
                 LR_BARRIER();
+                if constexpr (DBG == 3) t2 = stamp();
                 // ---------------- COMPUTE ----------------
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -186,14 +215,31 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                         for (int j = 0; j < 2; ++j)
                             acc[ph][i][j] = Op<OT>::mfma16(af[i * 2 + ks], bf[j * 2 + ks], acc[ph][i][j]);
                 __builtin_amdgcn_s_setprio(0);
+                if constexpr (DBG == 3) t3 = stamp();
                 LR_BARRIER();
+                if constexpr (DBG == 3) {
+                    t4 = stamp();
+                    segs[ph][0] += (unsigned)(t1 - t0); segs[ph][1] += (unsigned)(t2 - t1);
+                    segs[ph][2] += (unsigned)(t3 - t2); segs[ph][3] += (unsigned)(t4 - t3);
+                }
             }
             rslot += 4;
             rslot = rslot >= NS ? rslot - NS : rslot;
         }
         if (wr == 0) LR_BARRIER();                      // balance the stagger barrier
 
-        if constexpr (DBG == 2) {   // diagnostic: no epilogue (keep the accumulators live)
+        if constexpr (DBG == 3) {   // diagnostic: write the segment sums of blocks 0..7 to the buffer passed as `bias`
+            if (blockIdx.x < 8 && lane == 0 && vb == (int)blockIdx.x) {
+                unsigned* dbg = (unsigned*)p.bias + ((size_t)blockIdx.x * 8 + wave) * 16;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b2 = 0; b2 < 4; ++b2) dbg[a * 4 + b2] = segs[a][b2];
+                unsigned* dbg2 = (unsigned*)p.bias + 8 * 8 * 16 + ((size_t)blockIdx.x * 8 + wave) * 4;
+                dbg2[0] = lsegs[0]; dbg2[1] = lsegs[1]; dbg2[2] = lsegs[2];
+            }
+        }
+        if constexpr (DBG >= 2) {   // diagnostic: no epilogue (keep the accumulators live)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -400,6 +446,7 @@ static void launch8_variant(const GemmParams& p, int variant, hipStream_t st) {
         case 4: case 6: launch8_epi<OT, 5, 0>(p, true, st); break;       // persistent walk (A/B)
         case 7: launch8<OT, 5, 1, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: cache-resident operands
         case 8: launch8<OT, 5, 2, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: no epilogue
+        case 9: launch8<OT, 5, 3, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: in-kernel stamps -> `bias` buffer
         default: throw std::runtime_error("gemm_bt8: unknown variant");
     }
 }
