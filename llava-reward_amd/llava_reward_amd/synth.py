@@ -528,3 +528,271 @@ def llava_synth_batch(cfg: LlavaConfig, seed: int, caption_lens: List[int], imag
             pix[b, :ncrops[b]] = synth_pixels(seed, f"pixel_values.{b}", (ncrops[b], 3, 336, 336))
     sizes = np.array([[int(h), int(w)] for h, w in image_sizes], dtype=np.int64)
     return dict(input_ids=ids, attention_mask=mask, pixel_values=pix, image_sizes=sizes)
+
+
+# ----------------------------------------------------------------------------------------------
+# Qwen2.5-VL reward model: rw_model_general_preference.py:354-371 + :387-397 branch
+# ----------------------------------------------------------------------------------------------
+QWEN_CA_TOKEN_ID = 151643      # hard-wired at rw_model_general_preference.py:358 (<|endoftext|>, the pad token)
+
+
+@dataclasses.dataclass
+class QwenVisionConfig:
+    """Qwen2.5-VL ViT geometry (public Qwen2.5-VL-7B-Instruct config.json `vision_config`; not in the reference tree)."""
+    depth: int = 32
+    hidden: int = 1280
+    heads: int = 16
+    intermediate: int = 3420
+    patch: int = 14
+    temporal_patch: int = 2
+    merge: int = 2
+    window: int = 112
+    fullatt: Tuple[int, ...] = (7, 15, 23, 31)
+    in_ch: int = 3
+    rope_theta: float = 10000.0
+    eps: float = 1e-6
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden // self.heads
+
+    @property
+    def patch_dim(self) -> int:
+        return self.in_ch * self.temporal_patch * self.patch * self.patch
+
+    @property
+    def merge_unit(self) -> int:
+        return self.merge * self.merge
+
+    @property
+    def window_merged(self) -> int:
+        """Side of an attention window in merged (LLM) tokens: window // merge // patch."""
+        return self.window // self.merge // self.patch
+
+
+@dataclasses.dataclass
+class QwenConfig:
+    """Qwen2.5-VL-7B-Instruct geometry (public config.json; BASELINE.json config #4) + the reward head keys."""
+    vocab_size: int = 152064
+    hidden: int = 3584
+    intermediate: int = 18944
+    layers: int = 28
+    heads: int = 28
+    kv_heads: int = 4
+    head_dim: int = 128
+    rms_eps: float = 1e-6
+    rope_theta: float = 1000000.0
+    mrope_section: Tuple[int, int, int] = (16, 24, 24)
+    vision: QwenVisionConfig = dataclasses.field(default_factory=QwenVisionConfig)
+    image_token_id: int = 151655      # <|image_pad|>
+    pad_token_id: int = 151643        # <|endoftext|>; left padding (utils/utils.py:40-42)
+    is_general_preference: bool = False
+    add_cross_attention: bool = True
+    value_head_dim: int = 1
+    general_preference_tau: float = 0.1
+    ca_eps: float = 1e-6              # RMSNorm_class_eps for qwen (eval/reward_adaptor_loader.py:68)
+
+    def __post_init__(self):
+        if not self.is_general_preference:
+            self.value_head_dim = 1
+        assert sum(self.mrope_section) * 2 == self.head_dim
+        assert self.heads * self.head_dim == self.hidden, "Qwen2_5_VLAttention requires heads*head_dim == hidden"
+
+    def to_json(self) -> dict:
+        d = dataclasses.asdict(self)
+        d["mrope_section"] = list(self.mrope_section)
+        d["vision"]["fullatt"] = list(self.vision.fullatt)
+        d["backbone"] = "qwen"
+        return d
+
+    @staticmethod
+    def from_json(d: dict) -> "QwenConfig":
+        d = dict(d)
+        d.pop("backbone", None)
+        v = dict(d.pop("vision"))
+        v["fullatt"] = tuple(v["fullatt"])
+        d["mrope_section"] = tuple(d["mrope_section"])
+        return QwenConfig(vision=QwenVisionConfig(**v), **d)
+
+
+def qwen_full_config(**kw) -> QwenConfig:
+    return QwenConfig(**kw)
+
+
+def qwen_tiny_config(**kw) -> QwenConfig:
+    """Small everything; vocab 1024 means no token can equal 151643, so SkipCA sees no rows (attn_o = 0)."""
+    base = dict(vocab_size=1024, hidden=512, intermediate=768, layers=2, heads=4, kv_heads=2, head_dim=128,
+                image_token_id=1000, pad_token_id=1001,
+                vision=QwenVisionConfig(depth=3, hidden=320, heads=4, intermediate=200, fullatt=(1,)))
+    base.update(kw)
+    return QwenConfig(**base)
+
+
+def qwen_quirk_config(**kw) -> QwenConfig:
+    """Tiny model with the real vocabulary ids, so that left padding (151643) feeds the as-written SkipCA."""
+    base = dict(vocab_size=151680, hidden=256, heads=2, kv_heads=1, image_token_id=151655, pad_token_id=151643)
+    base.update(kw)
+    return qwen_tiny_config(**base)
+
+
+def qwen_window_index(grid_thw, vc: QwenVisionConfig):
+    """transformers.vision_utils.get_vision_window_index (third party, restated): the permutation that groups
+    merge units (2x2 patches) into window-major order, and the cumulative TOKEN counts of the windows."""
+    ws, unit = vc.window_merged, vc.merge_unit
+    index, cu, base = [], [0], 0
+    for t, h, w in grid_thw:
+        gh, gw = h // vc.merge, w // vc.merge
+        idx = np.arange(t * gh * gw, dtype=np.int64).reshape(t, gh, gw)
+        ph, pw = ws - gh % ws, ws - gw % ws            # a full extra window when divisible: it stays empty
+        nh, nw = (gh + ph) // ws, (gw + pw) // ws
+        pad = np.full((t, gh + ph, gw + pw), -100, dtype=np.int64)
+        pad[:, :gh, :gw] = idx
+        pad = pad.reshape(t, nh, ws, nw, ws).transpose(0, 1, 3, 2, 4).reshape(t, nh * nw, ws, ws)
+        lens = (pad != -100).sum(axis=(2, 3)).reshape(-1)
+        flat = pad.reshape(-1)
+        index.append(flat[flat != -100] + base)
+        for n in lens:
+            cu.append(cu[-1] + int(n) * unit)
+        base += t * gh * gw
+    cu_u = [cu[0]]
+    for c in cu[1:]:
+        if c != cu_u[-1]:
+            cu_u.append(c)
+    return np.concatenate(index), np.array(cu_u, dtype=np.int64)
+
+
+def qwen_patch_positions(grid_thw, vc: QwenVisionConfig) -> np.ndarray:
+    """transformers.vision_utils.get_vision_position_ids: (h, w) of every patch, in the processor's patch order
+    (merge-block major: [h/m, w/m, m, m])."""
+    out = []
+    m = vc.merge
+    for t, h, w in grid_thw:
+        hp, wp = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+        hp = hp.reshape(h // m, m, w // m, m).transpose(0, 2, 1, 3).reshape(-1)
+        wp = wp.reshape(h // m, m, w // m, m).transpose(0, 2, 1, 3).reshape(-1)
+        out.append(np.tile(np.stack([hp, wp], axis=-1), (t, 1)))
+    return np.concatenate(out).astype(np.int64)
+
+
+def qwen_rope_index(input_ids: np.ndarray, attention_mask: np.ndarray, grid_thw, cfg: QwenConfig) -> np.ndarray:
+    """Qwen2_5_VLModel.get_rope_index for still images (third party, restated): [3, B, S] (t, h, w) positions.
+    Text runs count up from the running position; an image run gets t = start, h/w = start + merged-grid
+    coordinates, and advances the running position by max(h, w) / merge.  Masked positions stay 0."""
+    B, S = input_ids.shape
+    pos = np.zeros((3, B, S), dtype=np.int64)
+    it = iter(grid_thw)
+    m = cfg.vision.merge
+    for b in range(B):
+        keep = np.nonzero(attention_mask[b])[0]
+        ids = input_ids[b, keep]
+        out = np.zeros((3, len(ids)), dtype=np.int64)
+        cur, i = 0, 0
+        while i < len(ids):
+            is_img = ids[i] == cfg.image_token_id
+            j = i
+            while j < len(ids) and (ids[j] == cfg.image_token_id) == is_img:
+                j += 1
+            if not is_img:
+                out[:, i:j] = cur + np.arange(j - i)
+                cur += j - i
+            else:
+                t, h, w = next(it)
+                gh, gw = h // m, w // m
+                assert j - i == t * gh * gw, "image slot run does not match image_grid_thw"
+                tt, hh, ww = np.meshgrid(np.arange(t), np.arange(gh), np.arange(gw), indexing="ij")
+                out[0, i:j] = tt.reshape(-1) + cur
+                out[1, i:j] = hh.reshape(-1) + cur
+                out[2, i:j] = ww.reshape(-1) + cur
+                cur += max(h, w) // m
+            i = j
+        pos[:, b, keep] = out
+    return pos
+
+
+def qwen_weight_specs(cfg: QwenConfig) -> List[Tuple[str, Tuple[int, ...], float, float]]:
+    """Checkpoint (transformers 4.50 era) names of Qwen2.5-VL-*-Instruct + the reward head.  lm_head is
+    omitted: the reference computes the logits and never reads them (rw_model:357)."""
+    v = cfg.vision
+    D, I, hd = cfg.hidden, cfg.intermediate, cfg.head_dim
+    s: List[Tuple[str, Tuple[int, ...], float, float]] = []
+    s.append(("model.embed_tokens.weight", (cfg.vocab_size, D), 0.02, 0.0))
+    s.append(("visual.patch_embed.proj.weight", (v.hidden, v.in_ch, v.temporal_patch, v.patch, v.patch), 0.02, 0.0))
+    for l in range(v.depth):
+        q = f"visual.blocks.{l}."
+        s.append((q + "norm1.weight", (v.hidden,), 0.05, 1.0))
+        s.append((q + "attn.qkv.weight", (3 * v.hidden, v.hidden), 0.02, 0.0))
+        s.append((q + "attn.qkv.bias", (3 * v.hidden,), 0.02, 0.0))
+        s.append((q + "attn.proj.weight", (v.hidden, v.hidden), 0.02, 0.0))
+        s.append((q + "attn.proj.bias", (v.hidden,), 0.02, 0.0))
+        s.append((q + "norm2.weight", (v.hidden,), 0.05, 1.0))
+        for nm, sh in (("gate_proj", (v.intermediate, v.hidden)), ("up_proj", (v.intermediate, v.hidden)),
+                       ("down_proj", (v.hidden, v.intermediate))):
+            s.append((q + f"mlp.{nm}.weight", sh, 0.02, 0.0))
+            s.append((q + f"mlp.{nm}.bias", (sh[0],), 0.02, 0.0))
+    mh = v.hidden * v.merge_unit
+    s.append(("visual.merger.ln_q.weight", (v.hidden,), 0.05, 1.0))
+    s.append(("visual.merger.mlp.0.weight", (mh, mh), 0.02, 0.0))
+    s.append(("visual.merger.mlp.0.bias", (mh,), 0.02, 0.0))
+    s.append(("visual.merger.mlp.2.weight", (D, mh), 0.02, 0.0))
+    s.append(("visual.merger.mlp.2.bias", (D,), 0.02, 0.0))
+    for l in range(cfg.layers):
+        q = f"model.layers.{l}."
+        s.append((q + "input_layernorm.weight", (D,), 0.05, 1.0))
+        for nm, n in (("q_proj", cfg.heads * hd), ("k_proj", cfg.kv_heads * hd), ("v_proj", cfg.kv_heads * hd)):
+            s.append((q + f"self_attn.{nm}.weight", (n, D), 0.02, 0.0))
+            s.append((q + f"self_attn.{nm}.bias", (n,), 0.02, 0.0))
+        s.append((q + "self_attn.o_proj.weight", (D, cfg.heads * hd), 0.02, 0.0))
+        s.append((q + "post_attention_layernorm.weight", (D,), 0.05, 1.0))
+        s.append((q + "mlp.gate_proj.weight", (I, D), 0.02, 0.0))
+        s.append((q + "mlp.up_proj.weight", (I, D), 0.02, 0.0))
+        s.append((q + "mlp.down_proj.weight", (D, I), 0.02, 0.0))
+    s.append(("model.norm.weight", (D,), 0.05, 1.0))
+    if cfg.add_cross_attention:
+        # W_q / W_k exist in the checkpoint but cannot influence the reward: every un-masked K row is the same
+        # pad-token embedding, so the softmax is uniform whatever the scores are (rw_model:387-395).
+        s.append(("W_q.weight", (D, D), 0.02, 0.0))
+        s.append(("W_k.weight", (D, D), 0.02, 0.0))
+        s.append(("W_v.weight", (D, D), 0.02, 0.0))
+        s.append(("ca_layernorm.weight", (D,), 0.05, 1.0))
+    s.append(("value_head.weight", (cfg.value_head_dim, D), 1.0 / math.sqrt(D), 0.0))
+    return s
+
+
+def qwen_make_weights(cfg: QwenConfig, seed: int) -> Dict[str, np.ndarray]:
+    return {n: gen_tensor(seed, n, sh, std, off) for n, sh, std, off in qwen_weight_specs(cfg)}
+
+
+def qwen_synth_batch(cfg: QwenConfig, seed: int, caption_lens: List[int], grids, with_pixels: bool = True):
+    """inputs_batch of the qwen branch (what Qwen2_5_VLProcessor hands over): input_ids with the image slot
+    already expanded to t*h*w/4 <|image_pad|> tokens, attention_mask (left padded with the pad token),
+    pixel_values [sum t*h*w, 1176] fp32 (patches in merge-block order) and image_grid_thw [B, 3] (one image
+    per row).  `grids` = (h, w) in PATCHES per row (even numbers)."""
+    batch = len(caption_lens)
+    if isinstance(grids[0], int):
+        grids = [tuple(grids)] * batch
+    assert len(grids) == batch
+    v = cfg.vision
+    thw = [(1, int(h), int(w)) for h, w in grids]
+    special = {cfg.image_token_id, cfg.pad_token_id, QWEN_CA_TOKEN_ID}
+    lo, hi = 3, min(cfg.vocab_size, min(special)) - 4
+    rows = []
+    for b, n in enumerate(caption_lens):
+        t = tensor_seed(seed, f"caption.{b}")
+        cap = np.array([lo + splitmix64_scalar((t + i) & MASK64) % (hi - lo) for i in range(n)], dtype=np.int64)
+        nimg = thw[b][0] * thw[b][1] * thw[b][2] // v.merge_unit
+        rows.append(np.concatenate([np.array([hi + 1, 5, hi + 2], dtype=np.int64),            # <|im_start|> user <|vision_start|>
+                                    np.full(nimg, cfg.image_token_id, dtype=np.int64),
+                                    np.array([hi + 3], dtype=np.int64), cap,                  # <|vision_end|> caption
+                                    np.array([hi + 1], dtype=np.int64)]))
+    S = max(len(r) for r in rows)
+    ids = np.full((batch, S), cfg.pad_token_id, dtype=np.int64)
+    mask = np.zeros((batch, S), dtype=np.int64)
+    for b, row in enumerate(rows):
+        ids[b, S - len(row):] = row
+        mask[b, S - len(row):] = 1
+    pix = None
+    if with_pixels:
+        pix = np.concatenate([synth_pixels(seed, f"pixel_values.{b}", (t * h * w, v.patch_dim))
+                              for b, (t, h, w) in enumerate(thw)], axis=0)
+    return dict(input_ids=ids, attention_mask=mask, pixel_values=pix,
+                image_grid_thw=np.array(thw, dtype=np.int64))

@@ -199,6 +199,81 @@ def run_llava_case(name, cfg, seed, caption_lens, image_sizes, max_crops):
     return out
 
 
+def canon_qwen_name(name: str) -> str:
+    """transformers 5.x module tree -> checkpoint (4.50 era) tensor names of Qwen2.5-VL-*-Instruct."""
+    n = name
+    if n.startswith("model.visual."):
+        return n[len("model."):]
+    if n.startswith("model.language_model."):
+        return "model." + n[len("model.language_model."):]
+    return n
+
+
+def run_qwen_case(name, cfg, seed, caption_lens, grids):
+    """Reference custom_forward, model_type='qwen' (rw_model_general_preference.py:354-371,387-397,407-448).
+
+    Shims for running the 4.50-era reference code on transformers 5.x:
+      1. cfg.hidden_size = cfg.text_config.hidden_size   (4.50's Qwen2_5_VLConfig was flat; rw_model:313 reads it)
+      2. model.__dict__['visual'] = model.model.visual    (5.x moved the ViT under .model; rw_model:356 calls it)
+      3. inputs_batch carries mm_token_type_ids           (5.x builds the 3-D mRoPE positions only when the
+         processor's token-type ids are passed; 4.50 derived the same positions from input_ids alone)"""
+    import transformers
+    from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration, Qwen2_5_VLModel
+    sys.path.insert(0, "/root/reference")
+    from llava_reward.models.rw_model_general_preference import _get_reward_model, Qwen2RMSNorm
+    v = cfg.vision
+    vcfg = dict(depth=v.depth, hidden_size=v.hidden, hidden_act="silu", intermediate_size=v.intermediate, num_heads=v.heads,
+                in_channels=v.in_ch, patch_size=v.patch, spatial_merge_size=v.merge, temporal_patch_size=v.temporal_patch,
+                tokens_per_second=2, window_size=v.window, out_hidden_size=cfg.hidden, fullatt_block_indexes=list(v.fullatt))
+    tcfg = dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden, intermediate_size=cfg.intermediate,
+                num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads, num_key_value_heads=cfg.kv_heads,
+                hidden_act="silu", max_position_embeddings=32768, rms_norm_eps=cfg.rms_eps, use_cache=False,
+                tie_word_embeddings=False, use_sliding_window=False, sliding_window=32768, max_window_layers=cfg.layers,
+                attention_dropout=0.0, pad_token_id=None,
+                rope_parameters={"rope_type": "default", "rope_theta": cfg.rope_theta, "mrope_section": list(cfg.mrope_section)})
+    hcfg = Qwen2_5_VLConfig(text_config=tcfg, vision_config=vcfg, image_token_id=cfg.image_token_id,
+                            video_token_id=cfg.image_token_id + 1, vision_start_token_id=cfg.image_token_id - 3,
+                            vision_end_token_id=cfg.image_token_id - 2)
+    hcfg._attn_implementation = "eager"
+    hcfg.hidden_size = hcfg.text_config.hidden_size                                      # shim 1
+    cls = _get_reward_model(Qwen2_5_VLForConditionalGeneration, Qwen2_5_VLModel, RMSNorm_class=Qwen2RMSNorm,
+                            RMSNorm_class_eps=1e-6, is_general_preference=cfg.is_general_preference,
+                            add_cross_attention=cfg.add_cross_attention, value_head_dim=cfg.value_head_dim)
+    model = cls(hcfg)
+    model.model_type = "qwen"                                                            # reward_adaptor_loader.py:79
+    model.__dict__["visual"] = model.model.visual                                        # shim 2
+    model.eval()
+    specs = {n: (sh, std, off) for n, sh, std, off in synth.qwen_weight_specs(cfg)}
+    used = set()
+    with torch.no_grad():
+        for pname, p in model.named_parameters():
+            cn = canon_qwen_name(pname)
+            if cn in specs:
+                sh, std, off = specs[cn]
+                assert tuple(p.shape) == tuple(sh), (pname, p.shape, sh)
+                p.copy_(torch.from_numpy(synth.gen_tensor(seed, cn, sh, std, off)))
+                used.add(cn)
+            else:
+                assert cn == "lm_head.weight", f"reference parameter without a spec: {pname}"
+    missing = set(specs) - used
+    assert not missing, f"weights not consumed by the reference: {sorted(missing)[:6]}"
+    batch = synth.qwen_synth_batch(cfg, seed, caption_lens, grids)
+    tb = {k: torch.from_numpy(val) for k, val in batch.items()}
+    tb["mm_token_type_ids"] = (tb["input_ids"] == cfg.image_token_id).int()             # shim 3
+    t0 = time.time()
+    with torch.no_grad():
+        reward, _ = model.custom_forward(inputs_batch=tb)
+    dt = time.time() - t0
+    print(f"[{name}] reference qwen custom_forward {dt:.1f}s reward={reward.flatten().tolist()}", flush=True)
+    out = {"name": name, "backbone": "qwen", "config": cfg.to_json(), "seed": seed, "caption_lens": caption_lens,
+           "grids": [list(g) for g in grids], "reward": reward.float().tolist(),
+           "n_ca_rows": (tb["input_ids"] == synth.QWEN_CA_TOKEN_ID).sum(dim=1).tolist(),
+           "transformers": transformers.__version__, "torch": torch.__version__, "dtype": "float32"}
+    with open(os.path.join(HERE, f"{name}.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    return out
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "small"
     torch.manual_seed(0)
@@ -216,6 +291,14 @@ def main():
         run_llava_case("ref_llava_tiny_gpm2", C(is_general_preference=True, value_head_dim=2), 12, [5, 9], [(512, 640), (336, 336)], 5)
         run_llava_case("ref_llava_tiny_wide", C(), 13, [4], [(300, 900)], None)
         run_llava_case("ref_llava_tiny_tall", C(layers=3), 14, [2, 7], [(400, 300), (672, 672)], 5)
+    elif which == "qwen":
+        C, Q = synth.qwen_tiny_config, synth.qwen_quirk_config
+        run_qwen_case("ref_qwen_tiny_bt", C(), 21, [6, 3], [(16, 16), (16, 16)])
+        run_qwen_case("ref_qwen_tiny_gpm2_ragged", C(is_general_preference=True, value_head_dim=2), 22, [5, 9],
+                      [(10, 6), (18, 22)])
+        run_qwen_case("ref_qwen_tiny_noca", C(add_cross_attention=False, layers=3), 23, [4], [(8, 20)])
+        run_qwen_case("ref_qwen_quirk_bt", Q(), 24, [2, 7, 4], [(8, 8), (12, 16), (8, 8)])
+        run_qwen_case("ref_qwen_quirk_gpm4", Q(is_general_preference=True, value_head_dim=4), 25, [3, 3], [(16, 16), (16, 16)])
     elif which == "llava_full":
         run_llava_case("ref_llava_full_bt", synth.llava_full_config(), 1234, [128], [(336, 336)], None)
     elif which == "full":

@@ -76,7 +76,7 @@ def test_token_count_kats():
     assert synth.num_img_tokens(336, 336) == 313 and synth.num_img_tokens(336, 672) == 457
 
 
-LLAVA_CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref_llava_*.json")))
+LLAVA_CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref_llava_tiny_*.json")))   # the full-size row is GPU-only
 
 
 @pytest.mark.parametrize("path", LLAVA_CASES, ids=[os.path.basename(p)[:-5] for p in LLAVA_CASES])
@@ -97,3 +97,59 @@ def test_llava_geometry_kats():
     # 336x336 -> 1x2 grid, 3 crops, 1176 tokens (SURVEY.md §8c probe of the reference's llava branch)
     assert synth.llava_geometry(336, 336) == (1, 2, 0, 24, 12, 36, 1176)
     assert synth.select_best_resolution((512, 640), synth.LLAVA_PINPOINTS) == (672, 672)
+
+
+QWEN_CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref_qwen_*.json")))
+
+
+@pytest.mark.parametrize("path", QWEN_CASES, ids=[os.path.basename(p)[:-5] for p in QWEN_CASES])
+def test_qwen_oracle_matches_reference(path):
+    """oracle/qwen2_5_vl_reward_oracle.py vs the reference's custom_forward (model_type='qwen', incl. the
+    as-written pad-token SkipCA) run on the container's transformers Qwen2_5_VL* (make_goldens.py qwen)."""
+    from oracle import qwen2_5_vl_reward_oracle as qorc
+    g = json.load(open(path))
+    cfg = synth.QwenConfig.from_json(g["config"])
+    W = orc.weights_to_torch(synth.qwen_make_weights(cfg, g["seed"]))
+    batch = synth.qwen_synth_batch(cfg, g["seed"], g["caption_lens"], [tuple(x) for x in g["grids"]])
+    assert (batch["input_ids"] == synth.QWEN_CA_TOKEN_ID).sum(axis=1).tolist() == g["n_ca_rows"]
+    r = qorc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_grid_thw"])
+    ref = np.array(g["reward"], dtype=np.float32).reshape(r.shape)
+    assert np.abs(r.numpy() - ref).max() < TOL, (r, ref)
+
+
+def test_qwen_skipca_reduces_to_one_vector():
+    """The as-written SkipCA (rw_model:358-371,387-395) adds the same vector W_v wte[151643] to every query of
+    a row that has at least one pad token and nothing otherwise -- the closed form the HIP path computes."""
+    from oracle import qwen2_5_vl_reward_oracle as qorc
+    cfg = synth.qwen_quirk_config()
+    W = orc.weights_to_torch(synth.qwen_make_weights(cfg, 5))
+    batch = synth.qwen_synth_batch(cfg, 5, [2, 6], [(8, 8), (8, 8)], with_pixels=False)
+    ids = torch.from_numpy(batch["input_ids"])
+    emb = W["model.embed_tokens.weight"][ids]
+    last = torch.from_numpy(synth.gen_tensor(9, "last", (2, ids.shape[1], cfg.hidden), 1.0))
+    got = qorc.skip_ca(W, cfg, last, emb, ids)
+    u = W["W_v.weight"] @ W["model.embed_tokens.weight"][synth.QWEN_CA_TOKEN_ID]
+    has = (ids == synth.QWEN_CA_TOKEN_ID).any(dim=1).float()
+    assert has.tolist() == [1.0, 0.0]
+    want = orc.rms_norm(last + has[:, None, None] * u, W["ca_layernorm.weight"], cfg.ca_eps)
+    assert (got - want).abs().max().item() < 2e-6
+
+
+def test_qwen_geometry_kats():
+    vc = synth.QwenVisionConfig()
+    # 448x448 (the reference's min_pixels floor for a 336^2 image, utils/utils.py:35-37) -> 32x32 patches,
+    # 256 image tokens, 16 windows of 64 patches
+    widx, cu = synth.qwen_window_index([(1, 32, 32)], vc)
+    assert len(widx) == 256 and cu.tolist() == list(range(0, 1025, 64))
+    assert widx[:16].tolist() == [0, 1, 2, 3, 16, 17, 18, 19, 32, 33, 34, 35, 48, 49, 50, 51]
+    # ragged: 10x6 patches -> 5x3 merged, windows of 4x3, 1x3
+    widx, cu = synth.qwen_window_index([(1, 10, 6)], vc)
+    assert cu.tolist() == [0, 48, 60] and sorted(widx.tolist()) == list(range(15))
+    cfg = synth.qwen_tiny_config()
+    b = synth.qwen_synth_batch(cfg, 1, [5, 3], [(8, 8), (4, 12)], with_pixels=False)
+    pos = synth.qwen_rope_index(b["input_ids"], b["attention_mask"], b["image_grid_thw"].tolist(), cfg)
+    # row 1: 6 pad, 3 text, 2x6 image (t = 3, h = 3..4, w = 3..8), then text resumes at 3 + max(4, 12)/2 = 9
+    assert pos[:, 1, :9].tolist() == [[0] * 6 + [0, 1, 2]] * 3
+    assert pos[0, 1, 9:21].tolist() == [3] * 12
+    assert pos[1, 1, 9:21].tolist() == [3] * 6 + [4] * 6 and pos[2, 1, 9:21].tolist() == [3, 4, 5, 6, 7, 8] * 2
+    assert pos[:, 1, 21].tolist() == [9, 9, 9]
