@@ -12,6 +12,9 @@
  *        (phi3v branch), i.e. modeling_phi3_v.py:1376-1516 Phi3VModel.forward with :221-362
  *        Phi3ImageEmbedding, the CLIP tower (utils/utils.py:264-282), the decoder stack
  *        (:1144-1205), SkipCA (rw_model:376-386) and the value head + EOS gather (:407-448)
+ *   lr_forward_qwen
+ *        the same function's qwen branch (rw_model:354-371, :387-397) = transformers Qwen2_5_VLForConditionalGeneration
+ *        .forward (ViT, merger, mRoPE decoder) + the as-written pad-token SkipCA + value head
  *   lr_all_gather_plan: none (the reference scores on one GPU, eval/batch_inference_rm_phi.py:50-57)
  *
  * Conventions: every function returns 0 on success and a non-zero LR_E* code on failure; nothing
@@ -31,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LR_ABI_VERSION 2
+#define LR_ABI_VERSION 3
 
 enum { LR_OK = 0, LR_EINVAL = 1, LR_EHIP = 2, LR_ESTATE = 3, LR_ENOTFOUND = 4, LR_ENOMEM = 5 };
 enum { LR_DT_BF16 = 0, LR_DT_F16 = 1, LR_DT_F32 = 2 };
@@ -40,7 +43,8 @@ enum { LR_FWD_TRAINING_LAST_TOKEN = 1 };   /* self.training reward selection (rw
 
 #define LR_MAX_HALF_HEAD 64
 #define LR_MAX_PINPOINTS 8
-enum { LR_BACKBONE_PHI3V = 0, LR_BACKBONE_LLAVA_NEXT = 1 };
+#define LR_MAX_FULLATT 8
+enum { LR_BACKBONE_PHI3V = 0, LR_BACKBONE_LLAVA_NEXT = 1, LR_BACKBONE_QWEN2_5_VL = 2 };
 
 typedef struct lr_engine* lr_handle;
 
@@ -68,6 +72,19 @@ typedef struct lr_model_desc {
      * (h, w) pairs, no SkipCA.  Weight names are those of the llava-v1.6-*-hf checkpoints. */
     int32_t backbone, kv_heads, head_dim, image_token_id, n_pinpoints;
     int32_t pinpoints[2 * LR_MAX_PINPOINTS];
+    /* LR_BACKBONE_QWEN2_5_VL (ABI 3; rw_model_general_preference.py:354-371,387-397; transformers Qwen2_5_VL*):
+     * the clip_* fields are ignored.  ViT: `vit_depth` blocks of width vit_hidden (vit_heads heads, SwiGLU MLP of
+     * vit_intermediate with biases), patches of vit_in_ch x vit_temporal_patch x vit_patch^2 values, window attention
+     * over vit_window pixels except in the blocks listed in vit_fullatt, 2-D rotary (vit_rope_theta), vit_merge^2
+     * patches merged per LLM token.  Decoder: GQA with q/k/v bias, multimodal RoPE (inv_freq_short = 1/theta^(2i/hd);
+     * frequency i follows the temporal / height / width position for i < s0, < s0+s1, < s0+s1+s2).  SkipCA as written
+     * in the reference: K/V rows are the embedding rows of the tokens equal to ca_token_id (151643, rw_model:358).
+     * Capacity: max_patches = ViT tokens (rows of pixel_values) per lr_forward_qwen call, at most max_batch images. */
+    int32_t vit_depth, vit_hidden, vit_heads, vit_intermediate, vit_patch, vit_temporal_patch, vit_merge, vit_window, vit_in_ch;
+    int32_t vit_n_fullatt, vit_fullatt[LR_MAX_FULLATT];
+    float vit_rope_theta, vit_eps;
+    int32_t mrope_section[3];
+    int32_t ca_token_id, max_patches;
 } lr_model_desc;
 
 int lr_abi_version(void);
@@ -97,9 +114,19 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
                int pix_dtype, const int64_t* image_sizes_host, int B, int S, int n_crops, int flags, float* rewards_out,
                void* hip_stream);
 
+/* One scoring pass of the Qwen2.5-VL branch: the reference's `inputs_batch` (rw_model:354-357).  input_ids /
+ * attention_mask: device int64 [B,S], image slots = image_token_id, already expanded by the processor to
+ * t*h*w/merge^2 tokens per image; pixel_values: device [sum t*h*w, vit_in_ch*vit_temporal_patch*vit_patch^2] of
+ * pix_dtype, patches in the processor's merge-block order; image_grid_thw: HOST int64 [n_images,3] (t must be 1),
+ * images in the order their slots appear in input_ids (row-major).  rewards_out: device fp32 [B, value_head_dim]. */
+int lr_forward_qwen(lr_handle h, const int64_t* input_ids, const int64_t* attention_mask, const void* pixel_values,
+                    int pix_dtype, const int64_t* image_grid_thw_host, int n_images, int B, int S, int flags,
+                    float* rewards_out, void* hip_stream);
+
 /* Debug taps: copy an internal fp32 buffer of the last forward to host (synchronises).  Names:
  * "clip_x" [crops*T, Hc], "ev" [sumV, D], "x" [B*S, D] (residual stream after the last layer),
- * "hL" [B, D].  Returns the number of floats copied through *n. */
+ * "hL" [B, D]; Qwen: "vit_x" [patches, vit_hidden] (window order), "ev" [patches/merge^2, D] (window order),
+ * "pos3" [3, B*S] (as floats).  Returns the number of floats copied through *n. */
 int lr_read_tap(lr_handle h, const char* name, float* host_out, size_t capacity, size_t* n);
 /* Stop after `n_clip_layers` / `n_layers` (-1 = all); for stage-wise parity tests. */
 int lr_set_layer_limits(lr_handle h, int n_clip_layers, int n_layers);
@@ -111,11 +138,16 @@ int lr_op_gemm_bt(const void* A, const void* W, void* C, const float* bias, int 
                   int ldc, int epi, int act, int operand_dtype, int tile, void* hip_stream);
 /* QKV projection with the fused RoPE epilogue: C_op[m][n] = rotate(A W^T) for n < rope_cols, pairs (2i, 2i+1) of each
  * rope_hd-wide head rotated by cs[m][i] = (cos, sin); weight rows must already be pair-interleaved. */
-int lr_op_gemm_rope(const void* A, const void* W, void* C, const float* cs, int M, int N, int K, int rope_cols, int rope_hd,
-                    int operand_dtype, int tile, void* hip_stream);
+int lr_op_gemm_rope(const void* A, const void* W, void* C, const float* bias, const float* cs, int M, int N, int K,
+                    int rope_cols, int rope_hd, int operand_dtype, int tile, void* hip_stream);   /* bias: [N] packed like W's rows, or NULL */
 int lr_op_attention(const void* Q, const void* K, const void* V, void* O, const int64_t* mask, const int* kmin, int ldq,
                     int ldo, int qoff, int koff, int voff, int batch, int S, int heads, int head_dim, int causal,
                     int kv_group, float scale, int operand_dtype, void* hip_stream);   /* kv_group = query heads per K/V head */
+/* Block-diagonal (ragged) dense attention: rows [cu[i], cu[i+1]) attend to each other only (the ViT's windows /
+ * images, transformers Qwen2_5_VLVisionAttention over cu_seqlens).  cu_seqlens: HOST int32 [n_seg + 1]. */
+int lr_op_attention_segments(const void* Q, const void* K, const void* V, void* O, const int32_t* cu_seqlens_host, int n_seg,
+                             int ldq, int ldo, int qoff, int koff, int voff, int heads, int head_dim, float scale,
+                             int operand_dtype, void* hip_stream);
 int lr_op_norm_rows(const float* x, const float* w, const float* b, void* y, int rows, int H, float eps,
                     int operand_dtype, void* hip_stream);
 int lr_op_synth_fill(float* out, size_t n, uint64_t seed, const char* name, float std, float offset, int bf16_round,

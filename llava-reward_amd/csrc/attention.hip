@@ -69,11 +69,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lc = lane & 31, lh = lane >> 5;
-    const int nqt = (p.S + 127) / 128;
-    const int qt = nqt - 1 - (int)blockIdx.x;      // heavy (late) causal tiles first
     const int head = blockIdx.y, b = blockIdx.z;
+    int S = p.S, qt;
+    size_t rowbase;
+    if (!CAUSAL && p.items) {                      // ragged mode: one segment per workgroup
+        const int4 it = p.items[blockIdx.x];
+        rowbase = (size_t)it.x; S = it.y; qt = it.z;
+    } else {
+        const int nqt = (S + 127) / 128;
+        qt = nqt - 1 - (int)blockIdx.x;            // heavy (late) causal tiles first
+        rowbase = (size_t)b * S;
+    }
     const int q0 = qt * 128 + wave * 32;
-    const size_t rowbase = (size_t)b * p.S;
 
     const unsigned short* Qp = (const unsigned short*)p.Q + p.qoff + head * HD;
     const int kvh = head / p.kv_group;                 // GQA: several query heads share one key/value head
@@ -81,10 +88,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
     const unsigned short* Vp = (const unsigned short*)p.V + p.voff + kvh * HD;
 
     // ---- key range of this workgroup ----
-    int kbeg = 0, kend = p.S;
+    int kbeg = 0, kend = S;
     if (CAUSAL) {
-        kend = min(p.S, qt * 128 + 128);
-        if (p.kmin) kbeg = (min(p.kmin[b * p.kmin_stride], p.S) / KT) * KT;
+        kend = min(S, qt * 128 + 128);
+        if (p.kmin) kbeg = (min(p.kmin[b * p.kmin_stride], S) / KT) * KT;
     }
     const int ntiles = kbeg < kend ? (kend - kbeg + KT - 1) / KT : 0;
 
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
         const unsigned dstK = __builtin_amdgcn_readfirstlane(lds_base + slot * 2 * TILE + wave * 1024);
 #pragma unroll
         for (int it = 0; it < NPO; ++it) {
-            const size_t key = rowbase + min(k0 + drow[it], p.S - 1);
+            const size_t key = rowbase + min(k0 + drow[it], S - 1);
             const unsigned short* sk = Kp + key * p.ldq + dkc[it];
             const unsigned short* sv = Vp + key * p.ldq + dvc[it];
             const unsigned dk = dstK + it * 4096, dv = dk + TILE;
@@ -125,15 +132,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
         const int w0 = kbeg / KT, w1 = (kend + KT - 1) / KT;
         for (int w = w0 + wave; w < w1; w += 4) {
             const int kk = w * KT + lane;
-            bool ok = kk < p.S;
-            if (ok && p.mask) ok = p.mask[(size_t)b * p.S + kk] != 0;
+            bool ok = kk < S;
+            if (ok && p.mask) ok = p.mask[(size_t)b * S + kk] != 0;
             const unsigned long long bits = __ballot(ok);
             if (lane == 0) { sBits[2 * w] = (unsigned)bits; sBits[2 * w + 1] = (unsigned)(bits >> 32); }
         }
     }
     uint4 qf[KSTEPS];       // lane (c,h) holds Q[q0+c][16*ks + 8h .. +7]
     {
-        const int qrow = min(q0 + lc, p.S - 1);
+        const int qrow = min(q0 + lc, S - 1);
         const unsigned short* src = Qp + (rowbase + qrow) * p.ldq + 8 * lh;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = *(const uint4*)(src + 16 * ks);
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
     }
 
     // ---- epilogue: O[q][d], d = dt*32 + (r&3) + 8(r>>2) + 4h : 4 consecutive d per register quad ----
-    if (qpos < p.S) {
+    if (qpos < S) {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
         unsigned short* dst = (unsigned short*)p.O + (rowbase + qpos) * p.ldo + head * HD + 4 * lh;
 #pragma unroll
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
 
 template <typename OT, int HD, bool CAUSAL>
 static void launch_one(const AttnParams& p, int batch, hipStream_t st) {
-    const int nqt = (p.S + 127) / 128;
+    const int nqt = p.items ? p.n_items : (p.S + 127) / 128;
     hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL>), dim3(nqt, p.heads, batch), dim3(256), 0, st, p);
 }
 
@@ -299,6 +306,7 @@ void launch_attention(const AttnParams& p, int batch, int head_dim, bool causal,
     if (batch <= 0) return;
     if (p.ldq % 8 || p.qoff % 8 || p.koff % 8 || p.voff % 8 || p.ldo % 4)
         throw std::runtime_error("attention: operand rows must be 16-byte aligned");
+    if (p.items && (causal || p.mask || batch != 1 || p.n_items < 1)) throw std::runtime_error("attention: ragged mode is dense, unmasked, batch 1");
     if (p.S > ATT_MAX_S) throw std::runtime_error("attention: sequence length above 8192 is not supported");
     if (p.kv_group < 1 || p.heads % p.kv_group) throw std::runtime_error("attention: heads must be a multiple of kv_group");
     const bool f16 = operand_dtype == DT_F16;

@@ -113,6 +113,10 @@ struct AttnParams {
     int heads;
     float scale;    // 1/sqrt(HD)
     int kv_group;   // query heads per key/value head (GQA); 1 = MHA
+    // ragged (block-diagonal) mode, dense only: workgroup x handles query tile items[x].z of the segment that starts at
+    // row items[x].x and is items[x].y rows long; S, mask and kmin are ignored
+    const int4* items;
+    int n_items;
 };
 
 }  // namespace lr

@@ -1,0 +1,234 @@
+// Engine internals shared by engine.hip (Phi-3.5-V, LLaVA-1.6) and qwen.hip (Qwen2.5-VL): the weight-slot table,
+// the handle and small host helpers.  Not part of the ABI (include/llava_reward_hip.h is).
+#pragma once
+#include "../../include/llava_reward_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using namespace lr;
+
+inline thread_local std::string g_create_error;
+
+inline uint64_t fnv1a64(const char* s) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (; *s; ++s) { h ^= (unsigned char)*s; h *= 0x100000001B3ull; }
+    return h;
+}
+inline uint64_t splitmix64_host(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+inline uint64_t tensor_seed(uint64_t seed, const char* name) { return splitmix64_host(seed ^ fnv1a64(name)); }
+inline float uniform_scale(double std) { return (float)(std * std::sqrt(12.0) / 16777216.0); }
+
+struct Slot {
+    std::string name;
+    std::vector<int64_t> shape;
+    int rows, cols;            // 2-D view: [shape[0], prod(rest)] (1-D: [1, n])
+    void* dst;                 // destination (already offset for concatenated tensors)
+    int ld_dst, cols_dst, dst_dtype, mode;
+    double std_, offset;       // synthetic init (llava_reward_amd.synth.weight_specs)
+    int aux_d = 0, aux_hd = 0, aux_hdp = 0; // PACK_ROPE_QKV: rows of a section, head width, stored head width
+    bool provided = false;
+};
+
+struct ClipLayer {
+    void *qkv_w, *out_w, *fc1_w, *fc2_w;
+    float *qkv_b, *out_b, *fc1_b, *fc2_b, *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+};
+struct DecLayer {
+    void *qkv_w, *o_w, *gu_w, *down_w;
+    float *ln1, *ln2;
+    float* qkv_b = nullptr;    // Qwen2.5-VL: q/k/v bias, packed like the rows of qkv_w
+};
+struct VitLayer {              // Qwen2_5_VLVisionBlock
+    void *qkv_w, *proj_w, *gu_w, *down_w;
+    float *qkv_b, *proj_b, *gu_b, *down_b, *n1, *n2;
+};
+
+struct lr_engine {
+    lr_model_desc d;
+    int device = 0;
+    std::string err;
+    bool finalized = false;
+    std::vector<void*> allocs;
+    std::vector<Slot> slots;
+    std::unordered_map<std::string, int> index;
+    size_t ws_bytes = 0, weight_bytes = 0;
+    int gemm_tile = -1, lim_clip = -1, lim_layers = -1;
+
+    // derived
+    int T = 0, G = 0, Kpatch = 0, Kpad = 0, hd = 0, half = 0, Vcap = 0;
+    int Hq = 0, Hkv = 0, Nqkv = 0;      // decoder projection widths: heads*hd, kv_heads*hd, Hq + 2*Hkv
+    bool llava = false, qwen = false;
+    int op_dt = DT_BF16;
+
+    // Qwen2.5-VL ViT geometry: head dim vhd stored vhdp wide, MLP width vI stored vIp wide, patch vector vK padded to vKpad
+    int vH = 0, vhd = 0, vhdp = 0, vHp = 0, vI = 0, vIp = 0, vK = 0, vKpad = 0, vHm = 0, vunit = 0;
+    std::vector<VitLayer> vl;
+    void *vpatch_w = nullptr, *m0_w = nullptr, *m2_w = nullptr;
+    float *vlnq = nullptr, *m0_b = nullptr, *m2_b = nullptr, *vinv = nullptr, *ca_u = nullptr;
+    void *vA = nullptr, *vhn = nullptr, *vqkv = nullptr, *vatt = nullptr, *vff = nullptr, *vm1 = nullptr;
+    float *vx = nullptr, *vqkv32 = nullptr, *vcs = nullptr;
+    int *pos3 = nullptr, *rstat = nullptr;
+    int lastP = 0;
+
+    // weights
+    float *cls = nullptr, *pos = nullptr, *pre_w = nullptr, *pre_b = nullptr;
+    void* patch_w = nullptr;
+    std::vector<ClipLayer> cl;
+    float *sub_gn = nullptr, *glb_gn = nullptr, *p0_b = nullptr, *p2_b = nullptr, *newline = nullptr;
+    void *p0_w = nullptr, *p2_w = nullptr;
+    unsigned short* wte = nullptr;
+    std::vector<DecLayer> dl;
+    float* norm_w = nullptr;
+    unsigned short *Wq = nullptr, *WkT = nullptr, *Wv = nullptr;
+    float *ca_w = nullptr, *vh = nullptr;
+    float *inv_s = nullptr, *inv_l = nullptr;
+
+    // staging for uploads
+    void* stage_raw = nullptr; size_t stage_raw_cap = 0;
+    float* stage_f32 = nullptr; size_t stage_f32_cap = 0;
+
+    // workspace
+    void *patchA = nullptr, *clip_h = nullptr, *clip_qkv = nullptr, *clip_att = nullptr, *clip_ff = nullptr;
+    float *patch_out = nullptr, *clip_x = nullptr;
+    void *hdA = nullptr, *proj1 = nullptr;
+    float *ev = nullptr, *pf32 = nullptr;
+    float *x = nullptr, *qkv32 = nullptr, *cs = nullptr;
+    void *h = nullptr, *qkv = nullptr, *att = nullptr, *ff = nullptr;
+    int *pos_ids = nullptr, *img_row = nullptr, *tstat = nullptr;
+    float *hL = nullptr, *tq = nullptr, *tkq = nullptr, *tsc = nullptr, *tctx = nullptr, *tao = nullptr;
+    // per-forward tables (ring of pinned host slots + device mirrors)
+    static constexpr int NSLOT = 4;
+    int slot_i = 0;
+    char* tab_host = nullptr; char* tab_dev = nullptr; size_t tab_bytes = 0;
+    hipEvent_t tab_ev[NSLOT] = {}; bool tab_used[NSLOT] = {};
+    // last forward geometry (for taps)
+    int lastB = 0, lastS = 0, lastNC = 0, lastSV = 0;
+
+    void* dalloc(size_t bytes, bool weight) {
+        void* p = nullptr;
+        bytes = (bytes + 255) & ~(size_t)255;
+        LR_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 256));
+        if (weight) LR_HIP_CHECK(hipMemset(p, 0, bytes ? bytes : 256));     // padded operand layouts rely on zero fill
+        allocs.push_back(p);
+        (weight ? weight_bytes : ws_bytes) += bytes;
+        return p;
+    }
+    size_t opsz() const { return 2; }
+};
+
+inline void add_slot(lr_engine* e, const std::string& name, std::vector<int64_t> shape, void* dst, int ld_dst, int cols_dst,
+              int dst_dtype, int mode, double std_, double offset) {
+    Slot s;
+    s.name = name;
+    s.shape = shape;
+    if (shape.size() == 1) { s.rows = 1; s.cols = (int)shape[0]; }
+    else { s.rows = (int)shape[0]; int64_t c = 1; for (size_t i = 1; i < shape.size(); ++i) c *= shape[i]; s.cols = (int)c; }
+    s.dst = dst; s.ld_dst = ld_dst; s.cols_dst = cols_dst; s.dst_dtype = dst_dtype; s.mode = mode;
+    s.std_ = std_; s.offset = offset;
+    e->index[name] = (int)e->slots.size();
+    e->slots.push_back(s);
+}
+
+inline float* falloc(lr_engine* e, size_t n) { return (float*)e->dalloc(n * 4, true); }
+inline void* oalloc(lr_engine* e, size_t n) { return e->dalloc(n * 2, true); }
+
+inline void vec_slot(lr_engine* e, const std::string& name, std::vector<int64_t> shape, float* dst, double std_, double off) {
+    int64_t n = 1; for (auto v : shape) n *= v;
+    add_slot(e, name, shape, dst, (int)n, (int)n, DT_F32, PACK_PLAIN, std_, off);
+    // 1-D view of multi-dim vectors (glb_GN [1,1,4H]) : force [1, n]
+    e->slots.back().rows = 1; e->slots.back().cols = (int)n;
+}
+
+inline void register_clip(lr_engine* e, const std::string& cp) {
+    const lr_model_desc& d = e->d;
+    const int Hc = d.clip_hidden, Mc = d.clip_mlp;
+    const int od = e->op_dt;
+    e->cls = falloc(e, Hc);
+    vec_slot(e, cp + "embeddings.class_embedding", {Hc}, e->cls, 0.02, 0);
+    e->patch_w = oalloc(e, (size_t)Hc * e->Kpad);
+    add_slot(e, cp + "embeddings.patch_embedding.weight", {Hc, 3, d.clip_patch, d.clip_patch}, e->patch_w, e->Kpad, e->Kpad, od,
+             PACK_PLAIN, 0.02, 0);
+    e->pos = falloc(e, (size_t)e->T * Hc);
+    add_slot(e, cp + "embeddings.position_embedding.weight", {e->T, Hc}, e->pos, Hc, Hc, DT_F32, PACK_PLAIN, 0.02, 0);
+    e->pre_w = falloc(e, Hc); e->pre_b = falloc(e, Hc);
+    vec_slot(e, cp + "pre_layrnorm.weight", {Hc}, e->pre_w, 0.05, 1.0);
+    vec_slot(e, cp + "pre_layrnorm.bias", {Hc}, e->pre_b, 0.02, 0);
+    e->cl.resize(d.clip_layers);
+    for (int l = 0; l < d.clip_layers; ++l) {
+        ClipLayer& c = e->cl[l];
+        const std::string p = cp + "encoder.layers." + std::to_string(l) + ".";
+        c.qkv_w = oalloc(e, (size_t)3 * Hc * Hc); c.qkv_b = falloc(e, 3 * Hc);
+        const char* nm[3] = {"q_proj", "k_proj", "v_proj"};
+        for (int i = 0; i < 3; ++i) {
+            add_slot(e, p + "self_attn." + nm[i] + ".weight", {Hc, Hc}, (char*)c.qkv_w + (size_t)i * Hc * Hc * 2, Hc, Hc, od,
+                     PACK_PLAIN, 0.02, 0);
+            vec_slot(e, p + "self_attn." + nm[i] + ".bias", {Hc}, c.qkv_b + i * Hc, 0.02, 0);
+        }
+        c.out_w = oalloc(e, (size_t)Hc * Hc); c.out_b = falloc(e, Hc);
+        add_slot(e, p + "self_attn.out_proj.weight", {Hc, Hc}, c.out_w, Hc, Hc, od, PACK_PLAIN, 0.02, 0);
+        vec_slot(e, p + "self_attn.out_proj.bias", {Hc}, c.out_b, 0.02, 0);
+        c.ln1_w = falloc(e, Hc); c.ln1_b = falloc(e, Hc); c.ln2_w = falloc(e, Hc); c.ln2_b = falloc(e, Hc);
+        vec_slot(e, p + "layer_norm1.weight", {Hc}, c.ln1_w, 0.05, 1.0);
+        vec_slot(e, p + "layer_norm1.bias", {Hc}, c.ln1_b, 0.02, 0);
+        c.fc1_w = oalloc(e, (size_t)Mc * Hc); c.fc1_b = falloc(e, Mc);
+        add_slot(e, p + "mlp.fc1.weight", {Mc, Hc}, c.fc1_w, Hc, Hc, od, PACK_PLAIN, 0.02, 0);
+        vec_slot(e, p + "mlp.fc1.bias", {Mc}, c.fc1_b, 0.02, 0);
+        c.fc2_w = oalloc(e, (size_t)Hc * Mc); c.fc2_b = falloc(e, Hc);
+        add_slot(e, p + "mlp.fc2.weight", {Hc, Mc}, c.fc2_w, Mc, Mc, od, PACK_PLAIN, 0.02, 0);
+        vec_slot(e, p + "mlp.fc2.bias", {Hc}, c.fc2_b, 0.02, 0);
+        vec_slot(e, p + "layer_norm2.weight", {Hc}, c.ln2_w, 0.05, 1.0);
+        vec_slot(e, p + "layer_norm2.bias", {Hc}, c.ln2_b, 0.02, 0);
+    }
+}
+
+inline void upload_rope_tables(lr_engine* e) {
+    e->inv_s = falloc(e, LR_MAX_HALF_HEAD); e->inv_l = falloc(e, LR_MAX_HALF_HEAD);
+    LR_HIP_CHECK(hipMemcpy(e->inv_s, e->d.inv_freq_short, sizeof(e->d.inv_freq_short), hipMemcpyHostToDevice));
+    LR_HIP_CHECK(hipMemcpy(e->inv_l, e->d.inv_freq_long, sizeof(e->d.inv_freq_long), hipMemcpyHostToDevice));
+}
+
+
+template <typename F> int guarded(lr_engine* e, F&& f) {
+    try {
+        if (e) LR_HIP_CHECK(hipSetDevice(e->device));
+        f();
+        return LR_OK;
+    } catch (const std::invalid_argument& ex) {
+        (e ? e->err : g_create_error) = ex.what();
+        return LR_EINVAL;
+    } catch (const std::logic_error& ex) {
+        (e ? e->err : g_create_error) = ex.what();
+        return LR_ESTATE;
+    } catch (const std::exception& ex) {
+        (e ? e->err : g_create_error) = ex.what();
+        return LR_EHIP;
+    }
+}
+
+inline void gemm(lr_engine* e, hipStream_t st, const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int lda,
+          int ldw, int ldc, int epi, int act) {
+    GemmParams p{A, W, C, bias, M, N, K, lda, ldw, ldc, epi, act, nullptr, 0, 0};
+    launch_gemm_bt(p, e->op_dt, e->gemm_tile, st);
+}
+
+
+// engine.hip: pre-norm decoder stack shared by the three backbones (x, cs, tstat prepared by the caller)
+void run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_mask, int B, int S);
+// qwen.hip
+void build_weight_table_qwen(lr_engine* e);
+void validate_desc_qwen(const lr_model_desc& d);
+void finalize_qwen(lr_engine* h);

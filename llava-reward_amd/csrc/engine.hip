@@ -1,193 +1,9 @@
 // C-ABI engine: weight store, workspace and the launch sequence of one scoring pass.
 // See include/llava_reward_hip.h for the contract and the reference lines each entry replaces.
-#include "../../include/llava_reward_hip.h"
-#include "common.h"
-#include "kernels.h"
+#include "engine.h"
 
-#include <cmath>
-#include <cstring>
-#include <functional>
-#include <string>
-#include <unordered_map>
-#include <vector>
-
-using namespace lr;
 
 namespace {
-
-thread_local std::string g_create_error;
-
-uint64_t fnv1a64(const char* s) {
-    uint64_t h = 0xCBF29CE484222325ull;
-    for (; *s; ++s) { h ^= (unsigned char)*s; h *= 0x100000001B3ull; }
-    return h;
-}
-uint64_t splitmix64_host(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ull;
-    uint64_t z = x;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-uint64_t tensor_seed(uint64_t seed, const char* name) { return splitmix64_host(seed ^ fnv1a64(name)); }
-float uniform_scale(double std) { return (float)(std * std::sqrt(12.0) / 16777216.0); }
-
-struct Slot {
-    std::string name;
-    std::vector<int64_t> shape;
-    int rows, cols;            // 2-D view: [shape[0], prod(rest)] (1-D: [1, n])
-    void* dst;                 // destination (already offset for concatenated tensors)
-    int ld_dst, cols_dst, dst_dtype, mode;
-    double std_, offset;       // synthetic init (llava_reward_amd.synth.weight_specs)
-    int aux_d = 0, aux_hd = 0; // PACK_ROPE_QKV: width of a rotated section, head width
-    bool provided = false;
-};
-
-struct ClipLayer {
-    void *qkv_w, *out_w, *fc1_w, *fc2_w;
-    float *qkv_b, *out_b, *fc1_b, *fc2_b, *ln1_w, *ln1_b, *ln2_w, *ln2_b;
-};
-struct DecLayer {
-    void *qkv_w, *o_w, *gu_w, *down_w;
-    float *ln1, *ln2;
-};
-
-}  // namespace
-
-struct lr_engine {
-    lr_model_desc d;
-    int device = 0;
-    std::string err;
-    bool finalized = false;
-    std::vector<void*> allocs;
-    std::vector<Slot> slots;
-    std::unordered_map<std::string, int> index;
-    size_t ws_bytes = 0, weight_bytes = 0;
-    int gemm_tile = -1, lim_clip = -1, lim_layers = -1;
-
-    // derived
-    int T = 0, G = 0, Kpatch = 0, Kpad = 0, hd = 0, half = 0, Vcap = 0;
-    int Hq = 0, Hkv = 0, Nqkv = 0;      // decoder projection widths: heads*hd, kv_heads*hd, Hq + 2*Hkv
-    bool llava = false;
-    int op_dt = DT_BF16;
-
-    // weights
-    float *cls = nullptr, *pos = nullptr, *pre_w = nullptr, *pre_b = nullptr;
-    void* patch_w = nullptr;
-    std::vector<ClipLayer> cl;
-    float *sub_gn = nullptr, *glb_gn = nullptr, *p0_b = nullptr, *p2_b = nullptr, *newline = nullptr;
-    void *p0_w = nullptr, *p2_w = nullptr;
-    unsigned short* wte = nullptr;
-    std::vector<DecLayer> dl;
-    float* norm_w = nullptr;
-    unsigned short *Wq = nullptr, *WkT = nullptr, *Wv = nullptr;
-    float *ca_w = nullptr, *vh = nullptr;
-    float *inv_s = nullptr, *inv_l = nullptr;
-
-    // staging for uploads
-    void* stage_raw = nullptr; size_t stage_raw_cap = 0;
-    float* stage_f32 = nullptr; size_t stage_f32_cap = 0;
-
-    // workspace
-    void *patchA = nullptr, *clip_h = nullptr, *clip_qkv = nullptr, *clip_att = nullptr, *clip_ff = nullptr;
-    float *patch_out = nullptr, *clip_x = nullptr;
-    void *hdA = nullptr, *proj1 = nullptr;
-    float *ev = nullptr, *pf32 = nullptr;
-    float *x = nullptr, *qkv32 = nullptr, *cs = nullptr;
-    void *h = nullptr, *qkv = nullptr, *att = nullptr, *ff = nullptr;
-    int *pos_ids = nullptr, *img_row = nullptr, *tstat = nullptr;
-    float *hL = nullptr, *tq = nullptr, *tkq = nullptr, *tsc = nullptr, *tctx = nullptr, *tao = nullptr;
-    // per-forward tables (ring of pinned host slots + device mirrors)
-    static constexpr int NSLOT = 4;
-    int slot_i = 0;
-    char* tab_host = nullptr; char* tab_dev = nullptr; size_t tab_bytes = 0;
-    hipEvent_t tab_ev[NSLOT] = {}; bool tab_used[NSLOT] = {};
-    // last forward geometry (for taps)
-    int lastB = 0, lastS = 0, lastNC = 0, lastSV = 0;
-
-    void* dalloc(size_t bytes, bool weight) {
-        void* p = nullptr;
-        bytes = (bytes + 255) & ~(size_t)255;
-        LR_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 256));
-        allocs.push_back(p);
-        (weight ? weight_bytes : ws_bytes) += bytes;
-        return p;
-    }
-    size_t opsz() const { return 2; }
-};
-
-namespace {
-
-void add_slot(lr_engine* e, const std::string& name, std::vector<int64_t> shape, void* dst, int ld_dst, int cols_dst,
-              int dst_dtype, int mode, double std_, double offset) {
-    Slot s;
-    s.name = name;
-    s.shape = shape;
-    if (shape.size() == 1) { s.rows = 1; s.cols = (int)shape[0]; }
-    else { s.rows = (int)shape[0]; int64_t c = 1; for (size_t i = 1; i < shape.size(); ++i) c *= shape[i]; s.cols = (int)c; }
-    s.dst = dst; s.ld_dst = ld_dst; s.cols_dst = cols_dst; s.dst_dtype = dst_dtype; s.mode = mode;
-    s.std_ = std_; s.offset = offset;
-    e->index[name] = (int)e->slots.size();
-    e->slots.push_back(s);
-}
-
-float* falloc(lr_engine* e, size_t n) { return (float*)e->dalloc(n * 4, true); }
-void* oalloc(lr_engine* e, size_t n) { return e->dalloc(n * 2, true); }
-
-void vec_slot(lr_engine* e, const std::string& name, std::vector<int64_t> shape, float* dst, double std_, double off) {
-    int64_t n = 1; for (auto v : shape) n *= v;
-    add_slot(e, name, shape, dst, (int)n, (int)n, DT_F32, PACK_PLAIN, std_, off);
-    // 1-D view of multi-dim vectors (glb_GN [1,1,4H]) : force [1, n]
-    e->slots.back().rows = 1; e->slots.back().cols = (int)n;
-}
-
-void register_clip(lr_engine* e, const std::string& cp) {
-    const lr_model_desc& d = e->d;
-    const int Hc = d.clip_hidden, Mc = d.clip_mlp;
-    const int od = e->op_dt;
-    e->cls = falloc(e, Hc);
-    vec_slot(e, cp + "embeddings.class_embedding", {Hc}, e->cls, 0.02, 0);
-    e->patch_w = oalloc(e, (size_t)Hc * e->Kpad);
-    add_slot(e, cp + "embeddings.patch_embedding.weight", {Hc, 3, d.clip_patch, d.clip_patch}, e->patch_w, e->Kpad, e->Kpad, od,
-             PACK_PLAIN, 0.02, 0);
-    e->pos = falloc(e, (size_t)e->T * Hc);
-    add_slot(e, cp + "embeddings.position_embedding.weight", {e->T, Hc}, e->pos, Hc, Hc, DT_F32, PACK_PLAIN, 0.02, 0);
-    e->pre_w = falloc(e, Hc); e->pre_b = falloc(e, Hc);
-    vec_slot(e, cp + "pre_layrnorm.weight", {Hc}, e->pre_w, 0.05, 1.0);
-    vec_slot(e, cp + "pre_layrnorm.bias", {Hc}, e->pre_b, 0.02, 0);
-    e->cl.resize(d.clip_layers);
-    for (int l = 0; l < d.clip_layers; ++l) {
-        ClipLayer& c = e->cl[l];
-        const std::string p = cp + "encoder.layers." + std::to_string(l) + ".";
-        c.qkv_w = oalloc(e, (size_t)3 * Hc * Hc); c.qkv_b = falloc(e, 3 * Hc);
-        const char* nm[3] = {"q_proj", "k_proj", "v_proj"};
-        for (int i = 0; i < 3; ++i) {
-            add_slot(e, p + "self_attn." + nm[i] + ".weight", {Hc, Hc}, (char*)c.qkv_w + (size_t)i * Hc * Hc * 2, Hc, Hc, od,
-                     PACK_PLAIN, 0.02, 0);
-            vec_slot(e, p + "self_attn." + nm[i] + ".bias", {Hc}, c.qkv_b + i * Hc, 0.02, 0);
-        }
-        c.out_w = oalloc(e, (size_t)Hc * Hc); c.out_b = falloc(e, Hc);
-        add_slot(e, p + "self_attn.out_proj.weight", {Hc, Hc}, c.out_w, Hc, Hc, od, PACK_PLAIN, 0.02, 0);
-        vec_slot(e, p + "self_attn.out_proj.bias", {Hc}, c.out_b, 0.02, 0);
-        c.ln1_w = falloc(e, Hc); c.ln1_b = falloc(e, Hc); c.ln2_w = falloc(e, Hc); c.ln2_b = falloc(e, Hc);
-        vec_slot(e, p + "layer_norm1.weight", {Hc}, c.ln1_w, 0.05, 1.0);
-        vec_slot(e, p + "layer_norm1.bias", {Hc}, c.ln1_b, 0.02, 0);
-        c.fc1_w = oalloc(e, (size_t)Mc * Hc); c.fc1_b = falloc(e, Mc);
-        add_slot(e, p + "mlp.fc1.weight", {Mc, Hc}, c.fc1_w, Hc, Hc, od, PACK_PLAIN, 0.02, 0);
-        vec_slot(e, p + "mlp.fc1.bias", {Mc}, c.fc1_b, 0.02, 0);
-        c.fc2_w = oalloc(e, (size_t)Hc * Mc); c.fc2_b = falloc(e, Hc);
-        add_slot(e, p + "mlp.fc2.weight", {Hc, Mc}, c.fc2_w, Mc, Mc, od, PACK_PLAIN, 0.02, 0);
-        vec_slot(e, p + "mlp.fc2.bias", {Hc}, c.fc2_b, 0.02, 0);
-        vec_slot(e, p + "layer_norm2.weight", {Hc}, c.ln2_w, 0.05, 1.0);
-        vec_slot(e, p + "layer_norm2.bias", {Hc}, c.ln2_b, 0.02, 0);
-    }
-}
-
-void upload_rope_tables(lr_engine* e) {
-    e->inv_s = falloc(e, LR_MAX_HALF_HEAD); e->inv_l = falloc(e, LR_MAX_HALF_HEAD);
-    LR_HIP_CHECK(hipMemcpy(e->inv_s, e->d.inv_freq_short, sizeof(e->d.inv_freq_short), hipMemcpyHostToDevice));
-    LR_HIP_CHECK(hipMemcpy(e->inv_l, e->d.inv_freq_long, sizeof(e->d.inv_freq_long), hipMemcpyHostToDevice));
-}
 
 // Phi-3.5-V names: modeling_phi3_v.py:1332-1374, :118-207; reward heads rw_model_general_preference.py:314-326
 void build_weight_table_phi(lr_engine* e) {
@@ -297,7 +113,7 @@ void ensure_stage(lr_engine* e, size_t raw_bytes, size_t n_f32) {
 
 void pack_slot(lr_engine* e, Slot& s, const float* src_f32) {
     launch_pack(src_f32, s.dst, s.rows, s.cols, s.ld_dst, s.mode == PACK_TRANSPOSE ? s.cols : s.cols_dst, s.dst_dtype, s.mode, 0,
-                s.aux_d, s.aux_hd);
+                s.aux_d, s.aux_hd, s.aux_hdp);
     s.provided = true;
 }
 
@@ -305,12 +121,14 @@ void validate_desc(const lr_model_desc& d) {
     auto bad = [](const char* m) { throw std::invalid_argument(m); };
     if (d.struct_size != (int)sizeof(lr_model_desc)) bad("lr_model_desc.struct_size mismatch (ABI)");
     if (d.hidden <= 0 || d.heads <= 0) bad("hidden and heads must be positive");
-    if (d.backbone != LR_BACKBONE_PHI3V && d.backbone != LR_BACKBONE_LLAVA_NEXT) bad("unknown backbone");
+    if (d.backbone != LR_BACKBONE_PHI3V && d.backbone != LR_BACKBONE_LLAVA_NEXT && d.backbone != LR_BACKBONE_QWEN2_5_VL) bad("unknown backbone");
     if (d.backbone == LR_BACKBONE_PHI3V) {
         if (d.hidden % d.heads) bad("hidden must be divisible by heads");
         const int hd = d.hidden / d.heads;
         if (hd != 96 && hd != 64) bad("Phi-3-V decoder head_dim must be 96 or 64");
         if (d.kv_heads != d.heads || d.head_dim != hd) bad("Phi-3-V: kv_heads must equal heads and head_dim hidden/heads");
+    } else if (d.backbone == LR_BACKBONE_QWEN2_5_VL) {
+        validate_desc_qwen(d);
     } else {
         if (d.head_dim != 128) bad("LLaVA decoder head_dim must be 128");
         if (d.kv_heads < 1 || d.heads % d.kv_heads) bad("heads must be a multiple of kv_heads");
@@ -319,40 +137,54 @@ void validate_desc(const lr_model_desc& d) {
         if (d.image_token_id < 0 || d.image_token_id >= d.vocab_size) bad("image_token_id out of range");
         if (((d.heads + d.kv_heads) * d.head_dim) % 256) bad("(heads + kv_heads) * head_dim must be a multiple of 256");
     }
-    if (d.clip_hidden % d.clip_heads || d.clip_hidden / d.clip_heads != 64) bad("CLIP head_dim must be 64");
-    if (d.hidden % 64 || d.intermediate % 64 || d.clip_hidden % 64 || d.clip_mlp % 64) bad("widths must be multiples of 64");
-    if (d.hidden > 4096 || d.clip_hidden > 4096) bad("hidden sizes above 4096 are not supported by the norm kernels");
-    if (d.clip_image % d.clip_patch || (d.clip_image / d.clip_patch) % 2) bad("CLIP grid must be even");
+    const bool qwen = d.backbone == LR_BACKBONE_QWEN2_5_VL;
+    if (!qwen) {
+        if (d.clip_heads <= 0 || d.clip_patch <= 0) bad("CLIP geometry must be positive");
+        if (d.clip_hidden % d.clip_heads || d.clip_hidden / d.clip_heads != 64) bad("CLIP head_dim must be 64");
+        if (d.clip_hidden % 64 || d.clip_mlp % 64) bad("widths must be multiples of 64");
+        if (d.clip_hidden > 4096) bad("hidden sizes above 4096 are not supported by the norm kernels");
+        if (d.clip_image % d.clip_patch || (d.clip_image / d.clip_patch) % 2) bad("CLIP grid must be even");
+        if (d.max_crops < 2) bad("capacity fields must be positive (max_crops >= 2)");
+    }
+    if (d.hidden % 64 || d.intermediate % 64) bad("widths must be multiples of 64");
+    if (d.hidden > 4096) bad("hidden sizes above 4096 are not supported by the norm kernels");
     if (d.value_head_dim < 1 || d.value_head_dim > 64) bad("value_head_dim out of range");
-    if (d.max_batch < 1 || d.max_seq < 1 || d.max_crops < 2) bad("capacity fields must be positive (max_crops >= 2)");
+    if (d.max_batch < 1 || d.max_seq < 1) bad("capacity fields must be positive");
     if (d.operand_dtype != LR_DT_BF16 && d.operand_dtype != LR_DT_F16) bad("operand_dtype must be BF16 or F16");
     if (d.layers < 0 || d.clip_layers < 0) bad("layer counts must be non-negative");
 }
 
-template <typename F> int guarded(lr_engine* e, F&& f) {
-    try {
-        if (e) LR_HIP_CHECK(hipSetDevice(e->device));
-        f();
-        return LR_OK;
-    } catch (const std::invalid_argument& ex) {
-        (e ? e->err : g_create_error) = ex.what();
-        return LR_EINVAL;
-    } catch (const std::logic_error& ex) {
-        (e ? e->err : g_create_error) = ex.what();
-        return LR_ESTATE;
-    } catch (const std::exception& ex) {
-        (e ? e->err : g_create_error) = ex.what();
-        return LR_EHIP;
+}  // namespace
+
+// Pre-norm decoder stack: modeling_phi3_v.py:1144-1205 | modeling_mistral.py MistralDecoderLayer | modeling_qwen2_5_vl.py
+// Qwen2_5_VLDecoderLayer (q/k/v bias).  RoPE comes from the per-token (cos, sin) table h->cs.
+void run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_mask, int B, int S) {
+    const lr_model_desc& d = h->d;
+    const int D = d.hidden, I = d.intermediate, Rl = B * S;
+    const int nl = h->lim_layers >= 0 && h->lim_layers < d.layers ? h->lim_layers : d.layers;
+    const float ascale = 1.0f / std::sqrt((float)h->hd);
+    const int Hq = h->Hq, Hkv = h->Hkv, Nqkv = h->Nqkv;
+    for (int l = 0; l < nl; ++l) {
+        const DecLayer& L = h->dl[l];
+        launch_norm_rows(h->x, L.ln1, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st);
+        {   // qkv projection with RoPE on q,k: fused in the GEMM epilogue when the deep-pipelined kernel runs
+            GemmParams gp{h->h, L.qkv_w, h->qkv, L.qkv_b, Rl, Nqkv, D, D, D, Nqkv, EPI_ROPE_OP, ACT_NONE, h->cs, Hq + Hkv, h->hd};
+            if ((Hq + Hkv) % 256 == 0 && gemm_bt_is_deep(gp, h->gemm_tile)) {
+                launch_gemm_bt(gp, h->op_dt, h->gemm_tile, st);
+            } else {
+                gemm(h, st, h->h, L.qkv_w, h->qkv32, L.qkv_b, Rl, Nqkv, D, D, D, Nqkv, EPI_OUT_F32, ACT_NONE);
+                launch_rope_split(h->qkv32, h->cs, h->qkv, Rl, Hq + Hkv, Hkv, h->hd, h->op_dt, st);
+            }
+        }
+        AttnParams ap{h->qkv, h->qkv, h->qkv, h->att, attention_mask, h->tstat + 1, 4, Nqkv, Hq, 0, Hq, Hq + Hkv, S, d.heads, ascale,
+                      d.heads / d.kv_heads};
+        launch_attention(ap, B, h->hd, true, h->op_dt, st);
+        gemm(h, st, h->att, L.o_w, h->x, nullptr, Rl, D, Hq, Hq, Hq, D, EPI_RESADD_F32, ACT_NONE);
+        launch_norm_rows(h->x, L.ln2, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st);
+        gemm(h, st, h->h, L.gu_w, h->ff, nullptr, Rl, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE);
+        gemm(h, st, h->ff, L.down_w, h->x, nullptr, Rl, D, I, I, I, D, EPI_RESADD_F32, ACT_NONE);
     }
 }
-
-void gemm(lr_engine* e, hipStream_t st, const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int lda,
-          int ldw, int ldc, int epi, int act) {
-    GemmParams p{A, W, C, bias, M, N, K, lda, ldw, ldc, epi, act, nullptr, 0, 0};
-    launch_gemm_bt(p, e->op_dt, e->gemm_tile, st);
-}
-
-}  // namespace
 
 extern "C" {
 
@@ -373,15 +205,20 @@ int lr_create(const lr_model_desc* desc, int device, lr_handle* out) {
         e->d = *desc;
         e->device = device;
         e->op_dt = desc->operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16;
-        e->G = desc->clip_image / desc->clip_patch;
-        e->T = e->G * e->G + 1;
-        e->Kpatch = 3 * desc->clip_patch * desc->clip_patch;
-        e->Kpad = (e->Kpatch + 63) / 64 * 64;
         e->llava = desc->backbone == LR_BACKBONE_LLAVA_NEXT;
+        e->qwen = desc->backbone == LR_BACKBONE_QWEN2_5_VL;
+        if (!e->qwen) {
+            e->G = desc->clip_image / desc->clip_patch;
+            e->T = e->G * e->G + 1;
+            e->Kpatch = 3 * desc->clip_patch * desc->clip_patch;
+            e->Kpad = (e->Kpatch + 63) / 64 * 64;
+        }
         e->hd = desc->head_dim;
         e->half = e->hd / 2;
         e->Hq = desc->heads * e->hd; e->Hkv = desc->kv_heads * e->hd; e->Nqkv = e->Hq + 2 * e->Hkv;
-        if (e->llava) {
+        if (e->qwen) {
+            build_weight_table_qwen(e);
+        } else if (e->llava) {
             int vmax = 0, cmax = 0;
             for (int i = 0; i < desc->n_pinpoints; ++i) {
                 const int gh = desc->pinpoints[2 * i] / desc->clip_image, gw = desc->pinpoints[2 * i + 1] / desc->clip_image;
@@ -479,6 +316,7 @@ int lr_finalize(lr_handle h) {
             if (!s.provided) throw std::logic_error("lr_finalize: tensor never provided: " + s.name);
         if (h->stage_raw) { LR_HIP_CHECK(hipFree(h->stage_raw)); h->stage_raw = nullptr; h->stage_raw_cap = 0; }
         if (h->stage_f32) { LR_HIP_CHECK(hipFree(h->stage_f32)); h->stage_f32 = nullptr; h->stage_f32_cap = 0; }
+        if (h->qwen) { finalize_qwen(h); h->finalized = true; return; }
         const lr_model_desc& d = h->d;
         const size_t B = d.max_batch, S = d.max_seq, C = d.max_crops;
         const size_t Hc = d.clip_hidden, Mc = d.clip_mlp, D = d.hidden, I = d.intermediate;
@@ -525,6 +363,7 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
     if (!h) return LR_EINVAL;
     return guarded(h, [&] {
         if (!h->finalized) throw std::logic_error("lr_forward: call lr_finalize first");
+        if (h->qwen) throw std::logic_error("lr_forward: Qwen2.5-VL handles take lr_forward_qwen (inputs_batch carries image_grid_thw)");
         if (!input_ids || !attention_mask || !pixel_values || !image_sizes_host || !rewards_out)
             throw std::invalid_argument("lr_forward: null argument (every row must carry an image, modeling_phi3_v.py:252)");
         const lr_model_desc& d = h->d;
@@ -633,30 +472,7 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
                           h->llava ? (long)d.image_token_id : -1L, h->llava ? 1 : 0);
         launch_embed(input_ids, h->img_row, h->wte, h->ev, h->x, Rl, D, d.vocab_size, st);
         launch_rope_table(h->pos_ids, h->tstat, B, S, h->inv_s, h->inv_l, d.rope_scaling, d.orig_max_pos, h->half, h->cs, st);
-        // ---- decoder stack (modeling_phi3_v.py:1144-1205 | modeling_mistral.py decoder layer) ----
-        const int nl = h->lim_layers >= 0 && h->lim_layers < d.layers ? h->lim_layers : d.layers;
-        const float ascale = 1.0f / std::sqrt((float)h->hd);
-        const int Hq = h->Hq, Hkv = h->Hkv, Nqkv = h->Nqkv;
-        for (int l = 0; l < nl; ++l) {
-            const DecLayer& L = h->dl[l];
-            launch_norm_rows(h->x, L.ln1, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st);
-            {   // qkv projection with RoPE on q,k: fused in the GEMM epilogue when the deep-pipelined kernel runs
-                GemmParams gp{h->h, L.qkv_w, h->qkv, nullptr, Rl, Nqkv, D, D, D, Nqkv, EPI_ROPE_OP, ACT_NONE, h->cs, Hq + Hkv, h->hd};
-                if (gemm_bt_is_deep(gp, h->gemm_tile)) {
-                    launch_gemm_bt(gp, h->op_dt, h->gemm_tile, st);
-                } else {
-                    gemm(h, st, h->h, L.qkv_w, h->qkv32, nullptr, Rl, Nqkv, D, D, D, Nqkv, EPI_OUT_F32, ACT_NONE);
-                    launch_rope_split(h->qkv32, h->cs, h->qkv, Rl, Hq + Hkv, Hkv, h->hd, h->op_dt, st);
-                }
-            }
-            AttnParams ap{h->qkv, h->qkv, h->qkv, h->att, attention_mask, h->tstat + 1, 4, Nqkv, Hq, 0, Hq, Hq + Hkv, S, d.heads, ascale,
-                          d.heads / d.kv_heads};
-            launch_attention(ap, B, h->hd, true, h->op_dt, st);
-            gemm(h, st, h->att, L.o_w, h->x, nullptr, Rl, D, Hq, Hq, Hq, D, EPI_RESADD_F32, ACT_NONE);
-            launch_norm_rows(h->x, L.ln2, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st);
-            gemm(h, st, h->h, L.gu_w, h->ff, nullptr, Rl, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE);
-            gemm(h, st, h->ff, L.down_w, h->x, nullptr, Rl, D, I, I, I, D, EPI_RESADD_F32, ACT_NONE);
-        }
+        run_decoder_stack(h, st, attention_mask, B, S);
         // ---- tail: final norm of the gathered row, SkipCA, value head (rw_model:376-448) ----
         launch_gather_norm_rows(h->x, h->tstat, S, (flags & LR_FWD_TRAINING_LAST_TOKEN) ? 1 : 0, h->norm_w, d.rms_eps, h->hL, B, D, st);
         const float* ao = nullptr;
@@ -679,7 +495,19 @@ int lr_read_tap(lr_handle h, const char* name, float* host_out, size_t capacity,
     return guarded(h, [&] {
         const float* src = nullptr; size_t cnt = 0;
         const std::string nm = name;
-        if (nm == "clip_x") { src = h->clip_x; cnt = (size_t)h->lastNC * h->T * h->d.clip_hidden; }
+        std::vector<float> conv;
+        if (nm == "clip_x" && !h->qwen) { src = h->clip_x; cnt = (size_t)h->lastNC * h->T * h->d.clip_hidden; }
+        else if (nm == "vit_x" && h->qwen) { src = h->vx; cnt = (size_t)h->lastP * h->vH; }
+        else if (nm == "pos3" && h->qwen) {
+            cnt = (size_t)3 * h->lastB * h->lastS;
+            if (cnt > capacity) throw std::invalid_argument("lr_read_tap: buffer too small");
+            std::vector<int> tmp(cnt);
+            LR_HIP_CHECK(hipDeviceSynchronize());
+            LR_HIP_CHECK(hipMemcpy(tmp.data(), h->pos3, cnt * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < cnt; ++i) host_out[i] = (float)tmp[i];
+            *n = cnt;
+            return;
+        }
         else if (nm == "ev") { src = h->ev; cnt = (size_t)h->lastSV * h->d.hidden; }
         else if (nm == "x") { src = h->x; cnt = (size_t)h->lastB * h->lastS * h->d.hidden; }
         else if (nm == "hL") { src = h->hL; cnt = (size_t)h->lastB * h->d.hidden; }
@@ -705,10 +533,10 @@ int lr_op_gemm_bt(const void* A, const void* W, void* C, const float* bias, int 
     });
 }
 
-int lr_op_gemm_rope(const void* A, const void* W, void* C, const float* cs, int M, int N, int K, int rope_cols, int rope_hd,
-                    int operand_dtype, int tile, void* hip_stream) {
+int lr_op_gemm_rope(const void* A, const void* W, void* C, const float* bias, const float* cs, int M, int N, int K, int rope_cols,
+                    int rope_hd, int operand_dtype, int tile, void* hip_stream) {
     return op_guard([&] {
-        GemmParams p{A, W, C, nullptr, M, N, K, K, K, N, EPI_ROPE_OP, ACT_NONE, cs, rope_cols, rope_hd};
+        GemmParams p{A, W, C, bias, M, N, K, K, K, N, EPI_ROPE_OP, ACT_NONE, cs, rope_cols, rope_hd};
         launch_gemm_bt(p, operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16, tile, (hipStream_t)hip_stream);
     });
 }
@@ -719,6 +547,31 @@ int lr_op_attention(const void* Q, const void* K, const void* V, void* O, const 
     return op_guard([&] {
         AttnParams p{Q, K, V, O, mask, kmin, 1, ldq, ldo, qoff, koff, voff, S, heads, scale, kv_group};
         launch_attention(p, batch, head_dim, causal != 0, operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16, (hipStream_t)hip_stream);
+    });
+}
+
+int lr_op_attention_segments(const void* Q, const void* K, const void* V, void* O, const int32_t* cu, int n_seg, int ldq, int ldo,
+                             int qoff, int koff, int voff, int heads, int head_dim, float scale, int operand_dtype, void* hip_stream) {
+    return op_guard([&] {
+        if (!cu || n_seg < 1) throw std::invalid_argument("attention_segments: need at least one segment");
+        std::vector<int4> items;
+        int max_len = 0;
+        for (int i = 0; i < n_seg; ++i) {
+            const int len = cu[i + 1] - cu[i];
+            if (len < 0) throw std::invalid_argument("attention_segments: cu_seqlens must be non-decreasing");
+            for (int q = 0; q * 128 < len; ++q) items.push_back(make_int4(cu[i], len, q, 0));
+            max_len = std::max(max_len, len);
+        }
+        if (items.empty()) return;
+        int4* d_items = nullptr;
+        LR_HIP_CHECK(hipMalloc((void**)&d_items, items.size() * sizeof(int4)));
+        hipStream_t st = (hipStream_t)hip_stream;
+        LR_HIP_CHECK(hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice, st));
+        AttnParams p{Q, K, V, O, nullptr, nullptr, 0, ldq, ldo, qoff, koff, voff, max_len, heads, scale, 1, d_items, (int)items.size()};
+        try { launch_attention(p, 1, head_dim, false, operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16, st); }
+        catch (...) { hipStreamSynchronize(st); hipFree(d_items); throw; }
+        LR_HIP_CHECK(hipStreamSynchronize(st));
+        LR_HIP_CHECK(hipFree(d_items));
     });
 }
 

@@ -166,7 +166,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bt_kernel(GemmParams p) {
                 for (int r = 0; r < 16; ++r) {
                     const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
                     if (row < p.M) {
-                        const float g = acc[i][2 * jj][r], u = acc[i][2 * jj + 1][r];
+                        float g = acc[i][2 * jj][r], u = acc[i][2 * jj + 1][r];
+                        if (p.bias) { const int pc = n0 + wn * TN + jj * 64 + lr_; g += p.bias[pc]; u += p.bias[pc + 32]; }
                         const float v = u * (g / (1.f + expf(-g)));
                         C[(size_t)row * p.ldc + col] = Op<OT>::from_f32(v);
                     }

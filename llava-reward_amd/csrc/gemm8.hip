@@ -36,6 +36,9 @@ namespace lr {
 // unrolled in one kernel the code was ~130 KB and every tile's epilogue ran out of the instruction cache.
 template <typename OT, int PF, int NS, int DBG, int EPI>
 __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
+    constexpr int E_ = EPI & 15;          // epilogue selector; bit 4 = bias present (SwiGLU / RoPE epilogues)
+    constexpr bool BIAS_ = (EPI & 16) != 0;
+
     constexpr int BM = 256, BN = 256, BK = 64;
     constexpr int HT = 16384;                      // bytes per half-tile slot
     static_assert(NS - PF >= 4 && PF >= 3, "ring hazard distances");
@@ -266,18 +269,18 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 return (row < p.M && fcol < p.N) ? *(const float4*)((const float*)p.C + (size_t)row * p.ldc + fcol)
                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
             };
-            if constexpr (EPI == EPI_RESADD_F32) {
+            if constexpr (E_ == EPI_RESADD_F32) {
 #pragma unroll
                 for (int it = 0; it < 8; ++it) ca[it] = cload(it);
             }
             // RoPE epilogue: the (cos, sin) rows are prefetched the same way (ca: iterations 0-3, cb: 4-7; 2 float4 each)
-            const bool rot = EPI == EPI_ROPE_OP && n0 < p.rope_cols;         // rope_cols is a multiple of the tile width
+            const bool rot = E_ == EPI_ROPE_OP && n0 < p.rope_cols;         // rope_cols is a multiple of the tile width
             auto rload = [&](int it, int k) {
                 const int row = min(rowq + it * 16 + wave * 2 + (lane >> 5), p.M - 1);
                 const int col = n0 + (lane & 31) * 8;
                 return ((const float4*)(p.rope_cs + ((size_t)row * (p.rope_hd >> 1) + ((col % p.rope_hd) >> 1)) * 2))[k];
             };
-            if constexpr (EPI == EPI_ROPE_OP) {
+            if constexpr (E_ == EPI_ROPE_OP) {
                 if (rot) {
 #pragma unroll
                     for (int it = 0; it < 4; ++it) { ca[2 * it] = rload(it, 0); ca[2 * it + 1] = rload(it, 1); }
@@ -295,28 +298,40 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                         for (int r = 0; r < 4; ++r)
                             stg[(wr * 64 + i * 16 + 4 * l4 + r) * SLD + wc * 64 + qb * 32 + j * 16 + l15] = acc[q][i][j][r];
             }
-            if constexpr (EPI == EPI_RESADD_F32) {
+            if constexpr (E_ == EPI_RESADD_F32) {
 #pragma unroll
                 for (int it = 0; it < 8; ++it) cb[it] = cload(8 + it);
             }
-            if constexpr (EPI == EPI_ROPE_OP) {
+            if constexpr (E_ == EPI_ROPE_OP) {
                 if (rot) {
 #pragma unroll
                     for (int it = 0; it < 4; ++it) { cb[2 * it] = rload(4 + it, 0); cb[2 * it + 1] = rload(4 + it, 1); }
                 }
             }
             __syncthreads();
-            if constexpr (EPI == EPI_SWIGLU_OP) {
+            if constexpr (E_ == EPI_SWIGLU_OP) {
                 // 128 output columns per row = 16 chunks of 8: 16 lanes per row, 4 rows per wave-iteration
                 const int c8 = lane & 15, wcc = c8 >> 2, cc = c8 & 3;
                 const int ocol = (n0 >> 1) + c8 * 8;
+                float4 bg0 = make_float4(0.f, 0.f, 0.f, 0.f), bg1 = bg0, bu0 = bg0, bu1 = bg0;
+                if constexpr (BIAS_) {
+                    const int bc = n0 + wcc * 64 + cc * 8;                   // packed column of the gate chunk; up = +32
+                    if (n0 + wcc * 64 + 64 <= p.N) {
+                        bg0 = *(const float4*)(p.bias + bc); bg1 = *(const float4*)(p.bias + bc + 4);
+                        bu0 = *(const float4*)(p.bias + bc + 32); bu1 = *(const float4*)(p.bias + bc + 36);
+                    }
+                }
 #pragma unroll 2
                 for (int it = 0; it < 4; ++it) {
                     const int rl = it * 32 + wave * 4 + (lane >> 4);
                     const int row = rowq + rl;
                     const float* g = stg + rl * SLD + wcc * 64 + cc * 8;
-                    const float4 g0 = *(const float4*)g, g1 = *(const float4*)(g + 4);
-                    const float4 u0 = *(const float4*)(g + 32), u1 = *(const float4*)(g + 36);
+                    float4 g0 = *(const float4*)g, g1 = *(const float4*)(g + 4);
+                    float4 u0 = *(const float4*)(g + 32), u1 = *(const float4*)(g + 36);
+                    if constexpr (BIAS_) {
+                        g0.x += bg0.x; g0.y += bg0.y; g0.z += bg0.z; g0.w += bg0.w; g1.x += bg1.x; g1.y += bg1.y; g1.z += bg1.z; g1.w += bg1.w;
+                        u0.x += bu0.x; u0.y += bu0.y; u0.z += bu0.z; u0.w += bu0.w; u1.x += bu1.x; u1.y += bu1.y; u1.z += bu1.z; u1.w += bu1.w;
+                    }
                     if (row < p.M && n0 + wcc * 64 + 64 <= p.N) {
                         auto sw = [](float gg, float uu) { return uu * x_sigmoid_fast(gg, 1.f); };
                         uint4 w;
@@ -327,15 +342,22 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                         *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + ocol) = w;
                     }
                 }
-            } else if constexpr (EPI == EPI_ROPE_OP) {
+            } else if constexpr (E_ == EPI_ROPE_OP) {
                 // as OUT_OP, no bias; the 8 columns of a lane are 4 (x[i], x[i+hd/2]) pairs of one head
                 const int c8 = lane & 31;
                 const int col = n0 + c8 * 8;
+                float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0;
+                if constexpr (BIAS_) {
+                    if (col < p.N) { rb0 = *(const float4*)(p.bias + col); rb1 = *(const float4*)(p.bias + col + 4); }
+                }
                 auto body = [&](int it, const float4 a, const float4 bq) {      // a = (c0,s0,c1,s1), bq = (c2,s2,c3,s3)
                     const int rl = it * 16 + wave * 2 + (lane >> 5);
                     const int row = rowq + rl;
                     const float* sp = stg + rl * SLD + c8 * 8;
                     float4 v0 = *(const float4*)sp, v1 = *(const float4*)(sp + 4);
+                    if constexpr (BIAS_) {
+                        v0.x += rb0.x; v0.y += rb0.y; v0.z += rb0.z; v0.w += rb0.w; v1.x += rb1.x; v1.y += rb1.y; v1.z += rb1.z; v1.w += rb1.w;
+                    }
                     if (rot) {
                         const float4 x0 = v0, x1 = v1;
                         v0 = make_float4(x0.x * a.x - x0.y * a.y, x0.y * a.x + x0.x * a.y, x0.z * a.z - x0.w * a.w, x0.w * a.z + x0.z * a.w);
@@ -353,7 +375,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 __builtin_amdgcn_sched_barrier(0);          // keep the second half's LDS reads out of the first half's live range
 #pragma unroll
                 for (int it = 0; it < 4; ++it) body(4 + it, cb[2 * it], cb[2 * it + 1]);
-            } else if constexpr (EPI == EPI_OUT_OP) {
+            } else if constexpr (E_ == EPI_OUT_OP) {
                 // 256 columns = 32 chunks of 8: 32 lanes per row, 2 rows per wave-iteration
                 const int c8 = lane & 31;
                 const int col = n0 + c8 * 8;
@@ -389,7 +411,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                     float4 v = *(const float4*)(stg + rl * SLD + lane * 4);
                     if (row < p.M && fcol < p.N) {
                         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                        if constexpr (EPI == EPI_RESADD_F32) { const float4 c = it < 8 ? ca[it & 7] : cb[it & 7]; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+                        if constexpr (E_ == EPI_RESADD_F32) { const float4 c = it < 8 ? ca[it & 7] : cb[it & 7]; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
                         *(float4*)((float*)p.C + (size_t)row * p.ldc + fcol) = v;
                     }
                 }
@@ -433,8 +455,14 @@ static void launch8_epi(const GemmParams& p, bool persistent, hipStream_t st) {
         case EPI_OUT_OP: launch8<OT, PF, DBG, EPI_OUT_OP>(p, persistent, st); break;
         case EPI_OUT_F32: launch8<OT, PF, DBG, EPI_OUT_F32>(p, persistent, st); break;
         case EPI_RESADD_F32: launch8<OT, PF, DBG, EPI_RESADD_F32>(p, persistent, st); break;
-        case EPI_SWIGLU_OP: launch8<OT, PF, DBG, EPI_SWIGLU_OP>(p, persistent, st); break;
-        case EPI_ROPE_OP: launch8<OT, PF, DBG, EPI_ROPE_OP>(p, persistent, st); break;
+        case EPI_SWIGLU_OP:
+            if (p.bias) launch8<OT, PF, DBG, EPI_SWIGLU_OP | 16>(p, persistent, st);
+            else launch8<OT, PF, DBG, EPI_SWIGLU_OP>(p, persistent, st);
+            break;
+        case EPI_ROPE_OP:
+            if (p.bias) launch8<OT, PF, DBG, EPI_ROPE_OP | 16>(p, persistent, st);
+            else launch8<OT, PF, DBG, EPI_ROPE_OP>(p, persistent, st);
+            break;
         default: throw std::runtime_error("gemm_bt8: unknown epilogue");
     }
 }

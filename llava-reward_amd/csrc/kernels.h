@@ -52,6 +52,21 @@ struct LlavaSample { int gh, gw, r0, r1, c0, c1, crop0, voff; };
 void launch_llava_pack(const float* proj, const LlavaSample* samples, int B, int total_rows, int g, int D,
                        const float* newline, float* ev, hipStream_t st);
 
+// Qwen2.5-VL (rowops_qwen.hip; transformers modeling_qwen2_5_vl.py) -------------------------------
+// GEMM operand rows of the patch embedding: out[i] = pixels[src[i]][0..K) zero-padded to Kpad (window order)
+void launch_qwen_patch_gather(const void* pixels, int pix_dtype, const int* src, int rows, int K, int Kpad, void* out,
+                              int operand_dtype, hipStream_t st);
+// ViT 2-D rotary table cs[row][half_pad][2]: pair k < quarter rotates by h*inv[k], k < 2*quarter by w*inv[k-quarter], else (1,0)
+void launch_vit_rope_table(const int2* hw, int rows, const float* inv_freq, int quarter, int half_pad, float* cs, hipStream_t st);
+// get_rope_index (still images): rstat[b] = {image runs, tokens == ca_token, 0, 0}; pos3 [3][B*S]; img_row = merger row or -1.
+// imgs[k] = {merged grid h, merged grid w, position advance, first slot}; slot2row[n_slots]: slot -> merger output row.
+void launch_qwen_plan(const int64_t* ids, const int64_t* mask, int B, int S, long image_token, long ca_token, const int4* imgs,
+                      int n_images, const int* slot2row, int n_slots, int* rstat, int* pos3, int* img_row, hipStream_t st);
+// multimodal RoPE table cs[row][half][2] from pos3 [3][rows]; frequency k uses stream 0 / 1 / 2 for k < s0 / < s0+s1 / else
+void launch_mrope_table(const int* pos3, int rows, const float* inv_freq, int s0, int s1, int half, float* cs, hipStream_t st);
+// as-written SkipCA of the qwen branch: out[b] = rstat[b].n_ca > 0 ? u : 0
+void launch_qwen_ca_vec(const int* rstat, const float* u, int B, int D, float* out, hipStream_t st);
+
 // tail (fp32) -----------------------------------------------------------------------------------
 // y[b] = RMSNorm(x[b*S + (use_last_pos ? S-1 : tstat[b].last_valid)])
 void launch_gather_norm_rows(const float* x, const int* tstat, int S, int use_last_pos, const float* w, float eps,
@@ -67,12 +82,15 @@ void launch_reward_head(const float* hL, const float* attn_o, const float* ca_w,
 
 // weights ---------------------------------------------------------------------------------------
 void launch_synth_fill(float* out, size_t n, uint64_t tseed, float scale, float offset, int bf16_round, hipStream_t st);
-enum : int { PACK_PLAIN = 0, PACK_SWIGLU = 1, PACK_TRANSPOSE = 2, PACK_ROPE_QKV = 3, PACK_SWIGLU_GATE = 4, PACK_SWIGLU_UP = 5 };
+enum : int { PACK_PLAIN = 0, PACK_SWIGLU = 1, PACK_TRANSPOSE = 2, PACK_ROPE_QKV = 3, PACK_SWIGLU_GATE = 4, PACK_SWIGLU_UP = 5,
+             PACK_HEADPAD_COLS = 6 };
 // dst[f(r)][c] (ld_dst elements, zero-padded columns up to cols_dst) = convert(src[r][c])
 // PACK_ROPE_QKV: rows [0, 2*aux_d) (q and k sections of a fused qkv weight, heads of aux_hd) get their head dims
-// pair-interleaved: dim i of the first half and dim i of the second half become neighbours (2i, 2i+1)
+// pair-interleaved: dim i of the first half and dim i of the second half become neighbours (2i, 2i+1); with
+// aux_hdp > aux_hd every head is stored aux_hdp wide (destination pre-zeroed).  PACK_SWIGLU_GATE/UP accept any row
+// count (destination rows rounded up to 32 and pre-zeroed).  PACK_HEADPAD_COLS pads the heads along the columns.
 void launch_pack(const float* src, void* dst, int rows, int cols, int ld_dst, int cols_dst, int dst_dtype, int mode,
-                 hipStream_t st, int aux_d = 0, int aux_hd = 0);
+                 hipStream_t st, int aux_d = 0, int aux_hd = 0, int aux_hdp = 0);
 void launch_cvt_to_f32(const void* src, int src_dtype, float* dst, size_t n, hipStream_t st);
 
 }  // namespace lr

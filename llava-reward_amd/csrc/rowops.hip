@@ -644,7 +644,8 @@ __device__ __forceinline__ void store_elem(void* dst, size_t i, float v, int dt)
 }
 
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, void* __restrict__ dst, int rows, int cols,
-                                                   int ld_dst, int cols_dst, int dst_dtype, int mode, int aux_d, int aux_hd) {
+                                                   int ld_dst, int cols_dst, int dst_dtype, int mode, int aux_d, int aux_hd,
+                                                   int aux_hdp) {
     const size_t total = (size_t)rows * cols_dst;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int r = (int)(i / cols_dst), c = (int)(i - (size_t)r * cols_dst);
@@ -659,13 +660,15 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
             // separate gate_proj / up_proj tensors written into one interleaved [2I, K] buffer
             o = (size_t)((r >> 5) * 64 + (mode == PACK_SWIGLU_UP ? 32 : 0) + (r & 31)) * ld_dst + c;
         } else if (mode == PACK_ROPE_QKV) {
-            int rr = r;
-            if (r < 2 * aux_d) {
-                const int sec = r / aux_d, w = r - sec * aux_d;
-                const int hh = w / aux_hd, d = w - hh * aux_hd, half = aux_hd >> 1;
-                rr = sec * aux_d + hh * aux_hd + 2 * (d % half) + d / half;
-            }
-            o = (size_t)rr * ld_dst + c;
+            // sections q | k | v of aux_d source rows each (heads of aux_hd dims, stored aux_hdp wide: the pad dims of the
+            // destination were zeroed at allocation); q and k dims pair-interleaved, v dims in place
+            const int sec = min(r / aux_d, 2), w = r - sec * aux_d;
+            const int hh = w / aux_hd, d = w - hh * aux_hd, half = aux_hd >> 1;
+            const int dd = sec < 2 ? 2 * (d % half) + d / half : d;
+            o = (size_t)(sec * (aux_d / aux_hd) * aux_hdp + hh * aux_hdp + dd) * ld_dst + c;
+        } else if (mode == PACK_HEADPAD_COLS) {
+            // columns are heads of aux_hd dims, stored aux_hdp wide (K operand of the projection after padded-head attention)
+            o = (size_t)r * ld_dst + (c / aux_hd) * aux_hdp + (c % aux_hd);
         } else if (mode == PACK_TRANSPOSE) {
             o = (size_t)c * ld_dst + r;
         } else {
@@ -676,13 +679,15 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
 }
 
 void launch_pack(const float* src, void* dst, int rows, int cols, int ld_dst, int cols_dst, int dst_dtype, int mode,
-                 hipStream_t st, int aux_d, int aux_hd) {
+                 hipStream_t st, int aux_d, int aux_hd, int aux_hdp) {
     const size_t total = (size_t)rows * cols_dst;
     if (!total) return;
     if (mode == PACK_SWIGLU && ((rows >> 1) % 32)) throw std::runtime_error("pack: SwiGLU interleave needs I % 32 == 0");
-    if ((mode == PACK_SWIGLU_GATE || mode == PACK_SWIGLU_UP) && (rows % 32)) throw std::runtime_error("pack: SwiGLU interleave needs I % 32 == 0");
+    if (mode == PACK_HEADPAD_COLS && (cols_dst != cols || aux_hd < 1 || aux_hdp < aux_hd)) throw std::runtime_error("pack: bad head padding");
+    if (mode == PACK_ROPE_QKV && (aux_hd < 2 || aux_d % aux_hd)) throw std::runtime_error("pack: bad RoPE section geometry");
+    if (aux_hdp <= 0) aux_hdp = aux_hd;
     const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
-    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, st, src, dst, rows, cols, ld_dst, cols_dst, dst_dtype, mode, aux_d, aux_hd);
+    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, st, src, dst, rows, cols, ld_dst, cols_dst, dst_dtype, mode, aux_d, aux_hd, aux_hdp);
 }
 
 __global__ __launch_bounds__(256) void cvt_to_f32_kernel(const void* __restrict__ src, int dt, float* __restrict__ dst, size_t n) {

@@ -10,7 +10,9 @@ LR_DT_BF16, LR_DT_F16, LR_DT_F32 = 0, 1, 2
 LR_FWD_TRAINING_LAST_TOKEN = 1
 LR_MAX_HALF_HEAD = 64
 LR_MAX_PINPOINTS = 8
-LR_BACKBONE_PHI3V, LR_BACKBONE_LLAVA_NEXT = 0, 1
+LR_MAX_FULLATT = 8
+LR_BACKBONE_PHI3V, LR_BACKBONE_LLAVA_NEXT, LR_BACKBONE_QWEN2_5_VL = 0, 1, 2
+LR_ABI_VERSION = 3
 EPI_OUT_OP, EPI_OUT_F32, EPI_RESADD_F32, EPI_SWIGLU_OP, EPI_ROPE_OP = 0, 1, 2, 3, 4
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2
 
@@ -34,6 +36,13 @@ class ModelDesc(C.Structure):
         ("operand_dtype", C.c_int32),
         ("backbone", C.c_int32), ("kv_heads", C.c_int32), ("head_dim", C.c_int32), ("image_token_id", C.c_int32),
         ("n_pinpoints", C.c_int32), ("pinpoints", C.c_int32 * (2 * LR_MAX_PINPOINTS)),
+        ("vit_depth", C.c_int32), ("vit_hidden", C.c_int32), ("vit_heads", C.c_int32), ("vit_intermediate", C.c_int32),
+        ("vit_patch", C.c_int32), ("vit_temporal_patch", C.c_int32), ("vit_merge", C.c_int32), ("vit_window", C.c_int32),
+        ("vit_in_ch", C.c_int32),
+        ("vit_n_fullatt", C.c_int32), ("vit_fullatt", C.c_int32 * LR_MAX_FULLATT),
+        ("vit_rope_theta", C.c_float), ("vit_eps", C.c_float),
+        ("mrope_section", C.c_int32 * 3),
+        ("ca_token_id", C.c_int32), ("max_patches", C.c_int32),
     ]
 
 
@@ -52,12 +61,15 @@ _SIGS = {
     "lr_workspace_bytes": (C.c_size_t, [C.c_void_p]),
     "lr_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64),
                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "lr_forward_qwen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64),
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "lr_read_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "lr_set_layer_limits": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "lr_set_gemm_tile": (C.c_int, [C.c_void_p, C.c_int]),
     "lr_op_gemm_bt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]),
-    "lr_op_gemm_rope": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_void_p]),
+    "lr_op_gemm_rope": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p]),
     "lr_op_attention": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 11 + [C.c_float, C.c_int, C.c_void_p]),
+    "lr_op_attention_segments": (C.c_int, [C.c_void_p] * 4 + [C.POINTER(C.c_int32)] + [C.c_int] * 8 + [C.c_float, C.c_int, C.c_void_p]),
     "lr_op_norm_rows": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "lr_op_synth_fill": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_char_p, C.c_float, C.c_float, C.c_int, C.c_void_p]),
 }

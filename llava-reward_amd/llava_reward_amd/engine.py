@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .synth import LlavaConfig, RewardConfig
+from .synth import LlavaConfig, QwenConfig, RewardConfig
 
 _DT = {"bf16": L.LR_DT_BF16, "f16": L.LR_DT_F16, "fp16": L.LR_DT_F16}
 
@@ -22,7 +22,7 @@ def rope_inv_freq(factors, head_dim: int, theta: float) -> torch.Tensor:
     return 1.0 / (ext * theta ** inv_shape)
 
 
-def make_desc(cfg, max_batch: int, max_seq: int, max_crops: int, operand_dtype: str) -> L.ModelDesc:
+def make_desc(cfg, max_batch: int, max_seq: int, max_crops: int, operand_dtype: str, max_patches: int = 0) -> L.ModelDesc:
     d = L.ModelDesc()
     d.struct_size = C.sizeof(L.ModelDesc)
     d.vocab_size, d.hidden, d.intermediate = cfg.vocab_size, cfg.hidden, cfg.intermediate
@@ -31,7 +31,28 @@ def make_desc(cfg, max_batch: int, max_seq: int, max_crops: int, operand_dtype: 
     half = cfg.head_dim // 2
     if half > L.LR_MAX_HALF_HEAD:
         raise ValueError("head_dim too large")
-    if isinstance(cfg, LlavaConfig):
+    if isinstance(cfg, QwenConfig):
+        v = cfg.vision
+        d.backbone = L.LR_BACKBONE_QWEN2_5_VL
+        d.kv_heads, d.head_dim, d.image_token_id = cfg.kv_heads, cfg.head_dim, cfg.image_token_id
+        d.orig_max_pos, d.rope_scaling = 1 << 30, 1.0        # default rope_type (Qwen2_5_VLRotaryEmbedding)
+        inv = rope_inv_freq([1.0] * half, cfg.head_dim, cfg.rope_theta)
+        for i in range(half):
+            d.inv_freq_short[i] = d.inv_freq_long[i] = float(inv[i])
+        d.vit_depth, d.vit_hidden, d.vit_heads, d.vit_intermediate = v.depth, v.hidden, v.heads, v.intermediate
+        d.vit_patch, d.vit_temporal_patch, d.vit_merge, d.vit_window, d.vit_in_ch = v.patch, v.temporal_patch, v.merge, v.window, v.in_ch
+        if len(v.fullatt) > L.LR_MAX_FULLATT:
+            raise ValueError("too many fullatt_block_indexes")
+        d.vit_n_fullatt = len(v.fullatt)
+        for i, b in enumerate(v.fullatt):
+            d.vit_fullatt[i] = b
+        d.vit_rope_theta, d.vit_eps = v.rope_theta, v.eps
+        for i in range(3):
+            d.mrope_section[i] = cfg.mrope_section[i]
+        from .synth import QWEN_CA_TOKEN_ID
+        d.ca_token_id = QWEN_CA_TOKEN_ID
+        d.max_patches = max_patches
+    elif isinstance(cfg, LlavaConfig):
         d.backbone = L.LR_BACKBONE_LLAVA_NEXT
         d.kv_heads, d.head_dim, d.image_token_id = cfg.kv_heads, cfg.head_dim, cfg.image_token_id
         d.orig_max_pos, d.rope_scaling = 1 << 30, 1.0        # plain RoPE (modeling_mistral.py MistralRotaryEmbedding)
@@ -53,9 +74,10 @@ def make_desc(cfg, max_batch: int, max_seq: int, max_crops: int, operand_dtype: 
             inv = rope_inv_freq(fac, cfg.head_dim, cfg.rope_theta)
             for i in range(half):
                 dst[i] = float(inv[i])
-    c = cfg.clip
-    d.clip_hidden, d.clip_heads, d.clip_mlp, d.clip_layers = c.hidden, c.heads, c.mlp, c.layers_used
-    d.clip_image, d.clip_patch, d.clip_ln_eps = c.image, c.patch, c.ln_eps
+    if not isinstance(cfg, QwenConfig):
+        c = cfg.clip
+        d.clip_hidden, d.clip_heads, d.clip_mlp, d.clip_layers = c.hidden, c.heads, c.mlp, c.layers_used
+        d.clip_image, d.clip_patch, d.clip_ln_eps = c.image, c.patch, c.ln_eps
     d.value_head_dim = cfg.value_head_dim
     d.add_cross_attention = int(bool(cfg.add_cross_attention))
     d.ca_eps = getattr(cfg, "ca_eps", 1e-5)
@@ -68,7 +90,7 @@ class RewardEngine:
     """Owns one lr_handle (one GPU).  Not thread-safe; forward() enqueues on the current torch stream."""
 
     def __init__(self, cfg, device: int = 0, max_batch: int = 32, max_seq: int = 2816,
-                 max_crops: int = 17, operand_dtype: str = "f16"):
+                 max_crops: int = 17, operand_dtype: str = "f16", max_patches: int = 0):
         if not torch.cuda.is_available():
             raise RuntimeError("RewardEngine needs a HIP device (torch.cuda.is_available() is False); "
                                "the scoring path has no CPU fallback")
@@ -79,7 +101,10 @@ class RewardEngine:
         self.max_batch, self.max_seq, self.max_crops = max_batch, max_seq, max_crops
         torch.cuda.set_device(self.device)
         torch.zeros(1, device=f"cuda:{self.device}")       # make sure torch owns a context on this device
-        self._desc = make_desc(cfg, max_batch, max_seq, max_crops, operand_dtype)
+        if isinstance(cfg, QwenConfig) and max_patches <= 0:
+            max_patches = max_batch * 1280 * cfg.vision.merge_unit      # the reference's max_pixels = 1280 * 28^2 (utils/utils.py:36)
+        self.max_patches = max_patches
+        self._desc = make_desc(cfg, max_batch, max_seq, max_crops, operand_dtype, max_patches)
         h = C.c_void_p()
         L.check(self.lib, self.lib.lr_create(C.byref(self._desc), self.device, C.byref(h)), None, "lr_create")
         self.h = h
@@ -147,6 +172,35 @@ class RewardEngine:
                                  C.c_void_p(stream))
         L.check(self.lib, rc, self.h, "lr_forward")
         # keep inputs alive until the stream has consumed them
+        for t in (ids, mask, pix):
+            t.record_stream(torch.cuda.current_stream(dev))
+        return out
+
+    def forward_qwen(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, pixel_values: torch.Tensor,
+                     image_grid_thw, training: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The qwen branch's inputs_batch (rw_model_general_preference.py:354-357): pixel_values [sum t*h*w, 1176]."""
+        dev = torch.device("cuda", self.device)
+        ids = input_ids.to(dev, torch.int64).contiguous()
+        mask = attention_mask.to(dev, torch.int64).contiguous()
+        if pixel_values.dtype == torch.bfloat16:
+            pdt = L.LR_DT_BF16
+        else:
+            pixel_values, pdt = pixel_values.to(torch.float32), L.LR_DT_F32
+        pix = pixel_values.to(dev).contiguous()
+        grid = torch.as_tensor(image_grid_thw).to("cpu", torch.int64).contiguous()
+        B, S = ids.shape
+        if grid.dim() != 2 or grid.shape[1] != 3:
+            raise ValueError("image_grid_thw must be [n_images, 3]")
+        if pix.dim() != 2 or pix.shape[1] != self.cfg.vision.patch_dim or pix.shape[0] != int(grid.prod(dim=1).sum()):
+            raise ValueError("pixel_values must be [sum(t*h*w), in_ch*temporal_patch*patch^2] matching image_grid_thw")
+        if out is None:
+            out = torch.empty(B, self.cfg.value_head_dim, device=dev, dtype=torch.float32)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = self.lib.lr_forward_qwen(self.h, C.c_void_p(ids.data_ptr()), C.c_void_p(mask.data_ptr()), C.c_void_p(pix.data_ptr()),
+                                      pdt, C.cast(grid.data_ptr(), C.POINTER(C.c_int64)), grid.shape[0], B, S,
+                                      L.LR_FWD_TRAINING_LAST_TOKEN if training else 0, C.c_void_p(out.data_ptr()),
+                                      C.c_void_p(stream))
+        L.check(self.lib, rc, self.h, "lr_forward_qwen")
         for t in (ids, mask, pix):
             t.record_stream(torch.cuda.current_stream(dev))
         return out

@@ -13,13 +13,13 @@ from typing import Dict, Optional
 
 import torch
 
-from .synth import LlavaConfig, RewardConfig, llava_geometry
+from .synth import LlavaConfig, QwenConfig, RewardConfig, llava_geometry
 
 
 class RewardModel:
     def __init__(self, cfg, weights: Optional[Dict[str, torch.Tensor]] = None, synth_seed: Optional[int] = None,
                  max_batch: int = 32, max_seq: int = 2816, max_crops: int = 17, operand_dtype: str = "f16",
-                 layer_id: int = 32, mean_hidden_state=None):
+                 layer_id: int = 32, mean_hidden_state=None, max_patches: int = 0):
         if weights is None and synth_seed is None:
             raise ValueError("RewardModel needs weights or a synth_seed")
         if mean_hidden_state:
@@ -27,10 +27,11 @@ class RewardModel:
         if layer_id not in (32, cfg.layers):
             raise NotImplementedError("only the last-layer hidden state (layer_id == 32) is implemented")
         self.config = cfg
-        self.model_type = "llava" if isinstance(cfg, LlavaConfig) else "phi3v"
+        self.model_type = "qwen" if isinstance(cfg, QwenConfig) else "llava" if isinstance(cfg, LlavaConfig) else "phi3v"
         self._weights = weights
         self._synth_seed = synth_seed
-        self._opts = dict(max_batch=max_batch, max_seq=max_seq, max_crops=max_crops, operand_dtype=operand_dtype)
+        self._opts = dict(max_batch=max_batch, max_seq=max_seq, max_crops=max_crops, operand_dtype=operand_dtype,
+                          max_patches=max_patches)
         self.engine = None
         self.training = False
         self.device = torch.device("cpu")
@@ -79,6 +80,8 @@ class RewardModel:
         if self.engine is None:
             raise RuntimeError("custom_forward: model is on CPU; call model.to('cuda') first "
                                "(the scoring path has no CPU fallback)")
+        if self.model_type == "qwen":
+            return self._custom_forward_qwen(inputs_batch, return_output)
         if inputs_batch is not None and input_ids is None:
             input_ids = inputs_batch["input_ids"]
             attention_mask = inputs_batch["attention_mask"]
@@ -107,6 +110,27 @@ class RewardModel:
                 raise RuntimeError(f"shape mismatch: image slots per row {n_slots.tolist()} != projected image tokens "
                                    f"{expect.tolist()} (modeling_phi3_v.py:247 index_put)")
         reward = self.engine.forward(input_ids, attention_mask, pixel_values, sz, training=self.training)
+        if return_output:
+            B, D = reward.shape[0], self.config.hidden
+            hl = torch.from_numpy(self.engine.read_tap("hL", B * D).reshape(B, D).copy())
+            return reward, {"last_hidden_state_at_reward_token": hl}
+        return reward, None
+
+    def _custom_forward_qwen(self, inputs_batch, return_output):
+        """rw_model_general_preference.py:354-371: the qwen branch reads everything from `inputs_batch` (the
+        processor's BatchFeature: input_ids, attention_mask, pixel_values [sum t*h*w, 1176], image_grid_thw)."""
+        if inputs_batch is None:
+            raise TypeError("'NoneType' object is not subscriptable (model_type == 'qwen' takes inputs_batch=..., rw_model:355)")
+        ids = inputs_batch["input_ids"]
+        mask = inputs_batch["attention_mask"]
+        pix = inputs_batch["pixel_values"]
+        grid = torch.as_tensor(inputs_batch["image_grid_thw"]).cpu().long()
+        unit = self.config.vision.merge_unit
+        n_slots = int((ids == self.config.image_token_id).sum())
+        n_feat = int(grid.prod(dim=1).sum()) // unit
+        if n_slots != n_feat:
+            raise ValueError(f"Image features and image tokens do not match, tokens: {n_slots}, features: {n_feat}")
+        reward = self.engine.forward_qwen(ids, mask, pix, grid, training=self.training)
         if return_output:
             B, D = reward.shape[0], self.config.hidden
             hl = torch.from_numpy(self.engine.read_tap("hL", B * D).reshape(B, D).copy())

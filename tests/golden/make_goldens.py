@@ -299,6 +299,10 @@ def main():
         run_qwen_case("ref_qwen_tiny_noca", C(add_cross_attention=False, layers=3), 23, [4], [(8, 20)])
         run_qwen_case("ref_qwen_quirk_bt", Q(), 24, [2, 7, 4], [(8, 8), (12, 16), (8, 8)])
         run_qwen_case("ref_qwen_quirk_gpm4", Q(is_general_preference=True, value_head_dim=4), 25, [3, 3], [(16, 16), (16, 16)])
+    elif which == "qwen_full":
+        # Qwen2.5-VL-7B shapes, one row: 448x448 image (the reference's min_pixels floor for a 336^2 input) = 32x32
+        # patches = 256 image tokens, 128-token caption (BASELINE.json config #4); ~35 GB RSS
+        run_qwen_case("ref_qwen_full_bt", synth.qwen_full_config(), 1234, [128], [(32, 32)])
     elif which == "llava_full":
         run_llava_case("ref_llava_full_bt", synth.llava_full_config(), 1234, [128], [(336, 336)], None)
     elif which == "full":

@@ -107,6 +107,14 @@ def test_gemm_swiglu(lib, dt, tile):
     assert lib.lr_op_gemm_bt(P(A), P(Wp), P(out), P(None), M, 2 * I, K, K, K, I, L.EPI_SWIGLU_OP, 0, code, tile, stream()) == 0
     err = (out.float() - ref).abs()
     assert (err <= ulp * ref.abs() + 1e-4).all(), err.max().item()
+    # with gate / up biases (Qwen2.5-VL ViT MLP, modeling_qwen2_5_vl.py Qwen2_5_VLMLP(bias=True)), packed like the rows
+    bias = rnd((2 * I,), 10, 0.5)
+    gub = gu + bias
+    refb = gub[:, I:] * torch.nn.functional.silu(gub[:, :I])
+    bp = bias[perm.cuda()].contiguous()
+    assert lib.lr_op_gemm_bt(P(A), P(Wp), P(out), P(bp), M, 2 * I, K, K, K, I, L.EPI_SWIGLU_OP, 0, code, tile, stream()) == 0
+    err = (out.float() - refb).abs()
+    assert (err <= ulp * refb.abs() + 1e-4).all(), err.max().item()
 
 
 @pytest.mark.parametrize("dt", DTS, ids=[d[0] for d in DTS])
@@ -125,9 +133,18 @@ def test_gemm_fused_rope_epilogue(lib, dt):
     c, s_ = cs[:, None, :, 0], cs[:, None, :, 1]
     ref[:, :2 * D] = torch.stack([qk[..., 0] * c - qk[..., 1] * s_, qk[..., 1] * c + qk[..., 0] * s_], dim=-1).reshape(M, 2 * D)
     out = torch.zeros(M, N, device="cuda", dtype=tdt)
-    assert lib.lr_op_gemm_rope(P(A), P(W), P(out), P(cs), M, N, K, 2 * D, hd, code, 5, stream()) == 0
+    assert lib.lr_op_gemm_rope(P(A), P(W), P(out), P(None), P(cs), M, N, K, 2 * D, hd, code, 5, stream()) == 0
     err = (out.float() - ref).abs()
     assert (err <= ulp * ref.abs() + 2e-4).all(), err.max().item()
+    # q/k/v bias added before the rotation (Qwen2.5-VL: Qwen2_5_VLAttention q_proj/k_proj/v_proj bias=True)
+    bias = rnd((N,), 34, 0.5)
+    yb = y + bias
+    refb = yb.clone()
+    qk = yb[:, :2 * D].view(M, 2 * D // hd, half, 2)
+    refb[:, :2 * D] = torch.stack([qk[..., 0] * c - qk[..., 1] * s_, qk[..., 1] * c + qk[..., 0] * s_], dim=-1).reshape(M, 2 * D)
+    assert lib.lr_op_gemm_rope(P(A), P(W), P(out), P(bias), P(cs), M, N, K, 2 * D, hd, code, 5, stream()) == 0
+    err = (out.float() - refb).abs()
+    assert (err <= ulp * refb.abs() + 2e-4).all(), err.max().item()
 
 
 def _attn_ref(q, k, v, mask, causal, scale):
@@ -224,3 +241,31 @@ def test_attention_gqa_head_dim_128(lib, dt, case):
     err = (out.float() - ref).abs()[valid]
     assert err.max().item() < 2.5 * ulp * v.abs().max().item(), err.max().item()
     assert (out.float()[~valid] == 0).all()
+
+
+@pytest.mark.parametrize("dt", DTS, ids=[d[0] for d in DTS])
+@pytest.mark.parametrize("hd", [96, 64])
+def test_attention_ragged_segments(lib, dt, hd):
+    """Block-diagonal dense attention over cu_seqlens (Qwen2_5_VLVisionAttention: windows of <= 64 patches, or one
+    segment per image), including empty, 1-row, exactly-128 and multi-tile segments."""
+    _, code, tdt, ulp = dt
+    H = 3
+    lens = [64, 48, 1, 0, 128, 130, 700, 64, 12]
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    N = int(cu[-1])
+    ld = 3 * H * hd
+    qkv = rnd((N, ld), 51, 0.7).to(tdt)
+    out = torch.zeros(N, H * hd, device="cuda", dtype=tdt)
+    scale = 80 ** -0.5                         # the ViT scales by the TRUE head dim (80), not the stored width
+    assert lib.lr_op_attention_segments(P(qkv), P(qkv), P(qkv), P(out), cu.ctypes.data_as(C.POINTER(C.c_int32)), len(lens),
+                                        ld, H * hd, 0, H * hd, 2 * H * hd, H, hd, scale, code, stream()) == 0
+    torch.cuda.synchronize()
+    f = qkv.float().view(N, 3, H, hd)
+    ref = torch.zeros(N, H, hd, device="cuda")
+    for a, b in zip(cu[:-1], cu[1:]):
+        if b > a:
+            q, k, v = (f[a:b, i].transpose(0, 1) for i in range(3))
+            ref[a:b] = (torch.softmax(q @ k.transpose(1, 2) * scale, dim=-1) @ v).transpose(0, 1)
+    err = (out.float().view(N, H, hd) - ref).abs()
+    # P is rounded to the operand dtype before the PV product, the output once more: error ~ ulp * |v|max
+    assert err.max().item() < 3 * ulp * f[:, 2].abs().max().item(), err.max().item()

@@ -1,0 +1,202 @@
+"""Qwen2.5-VL reward path on the HIP engine (lr_forward_qwen through the C ABI): parity against the CPU oracle and
+against goldens produced by the reference's own custom_forward (model_type='qwen', rw_model_general_preference.py:
+354-371, 387-397), including the as-written pad-token SkipCA.  Tolerance: 1e-3 in the assert_close sense
+(atol = rtol = 1e-3) with f16 operands -- these synthetic models produce |reward| up to ~2 and the f16-operand
+emulation inside the oracle already deviates from fp32 by 0.3e-3..1.4e-3 there; bf16 operands 8e-3.
+Batch invariance / preference ordering: bit-exact."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from llava_reward_amd import synth
+from llava_reward_amd.model import RewardModel
+from oracle import phi3v_reward_oracle as orc
+from oracle import qwen2_5_vl_reward_oracle as qorc
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _model(cfg, seed, dtype, upload, max_batch=4, max_seq=1024, max_patches=4096):
+    if upload:
+        W = {k: torch.from_numpy(v) for k, v in synth.qwen_make_weights(cfg, seed).items()}
+        m = RewardModel(cfg, weights=W, max_batch=max_batch, max_seq=max_seq, operand_dtype=dtype, max_patches=max_patches)
+    else:
+        m = RewardModel(cfg, synth_seed=seed, max_batch=max_batch, max_seq=max_seq, operand_dtype=dtype, max_patches=max_patches)
+    return m.to("cuda").eval()
+
+
+def _rows(batch, rows):
+    """Sub-batch: rows of ids/mask and the matching slices of pixel_values / image_grid_thw (one image per row)."""
+    if rows is None:
+        return batch
+    idx = list(range(*rows.indices(batch["input_ids"].shape[0])))
+    n = batch["image_grid_thw"].prod(axis=1)
+    off = np.concatenate([[0], np.cumsum(n)])
+    pix = np.concatenate([batch["pixel_values"][off[i]:off[i + 1]] for i in idx])
+    return dict(input_ids=batch["input_ids"][idx], attention_mask=batch["attention_mask"][idx], pixel_values=pix,
+                image_grid_thw=batch["image_grid_thw"][idx])
+
+
+def _fwd(m, batch, rows=None):
+    tb = {k: torch.from_numpy(v).cuda() for k, v in _rows(batch, rows).items()}
+    r, _ = m.custom_forward(inputs_batch=tb)           # the qwen branch takes inputs_batch only (rw_model:354-357)
+    torch.cuda.synchronize()
+    return r.cpu()
+
+
+def _close(got, ref, tol=1e-3):
+    return bool(((got - ref).abs() <= tol + tol * ref.abs()).all())
+
+
+def _oracle(cfg, seed, batch, **kw):
+    W = orc.weights_to_torch(synth.qwen_make_weights(cfg, seed))
+    return qorc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"],
+                               batch["image_grid_thw"], **kw)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f16", 1e-3), ("bf16", 8e-3)])
+@pytest.mark.parametrize("variant", ["bt", "gpm2", "noca"])
+def test_qwen_tiny_vs_oracle(dtype, tol, variant):
+    kw = dict(bt={}, gpm2=dict(is_general_preference=True, value_head_dim=2), noca=dict(add_cross_attention=False))[variant]
+    cfg = synth.qwen_tiny_config(**kw)
+    seed = 31
+    # ragged grids: 16x16 (4 full windows), 10x6 (windows of 4x3 and 1x3 merged tokens), 18x22 (edge windows both ways)
+    batch = synth.qwen_synth_batch(cfg, seed, [7, 3, 5], [(16, 16), (10, 6), (18, 22)])
+    ref = _oracle(cfg, seed, batch)
+    m = _model(cfg, seed, dtype, upload=True)
+    assert m.model_type == "qwen"
+    got = _fwd(m, batch)
+    err = (got - ref).abs().max().item()
+    print(f"[qwen tiny {variant} {dtype}] max |reward err| = {err:.3e} rewards={got.flatten().tolist()}")
+    assert got.shape == ref.shape and _close(got, ref, tol)
+    emu = _oracle(cfg, seed, batch, opr=orc.f16_round if dtype == "f16" else orc.bf16_round)
+    assert (got - emu).abs().max().item() < (1e-3 if dtype == "f16" else 4e-3)
+    m2 = _model(cfg, seed, dtype, upload=False)         # device-side synthetic weights == uploaded ones
+    assert torch.equal(_fwd(m2, batch), got)
+    for b in range(3):                                  # batch invariance, bit-exact
+        assert torch.equal(_fwd(m2, batch, rows=slice(b, b + 1))[0], got[b])
+
+
+def test_qwen_positions_and_stage_taps():
+    """3-D positions (get_rope_index) bit-exact; ViT output and merged image rows close to the oracle's."""
+    cfg = synth.qwen_tiny_config()
+    seed = 7
+    batch = synth.qwen_synth_batch(cfg, seed, [4, 9, 2], [(8, 20), (16, 16), (6, 4)])
+    taps = {}
+    _oracle(cfg, seed, batch, taps=taps)
+    m = _model(cfg, seed, "f16", upload=True)
+    _fwd(m, batch)
+    e = m.engine
+    B, S = batch["input_ids"].shape
+    grid = batch["image_grid_thw"].tolist()
+    pos = e.read_tap("pos3", 3 * B * S).reshape(3, B, S).astype(np.int64)
+    want = synth.qwen_rope_index(batch["input_ids"], batch["attention_mask"], grid, cfg)
+    assert np.array_equal(pos, want)
+    # ViT residual stream after the last block, window order on the device
+    vc = cfg.vision
+    widx, _ = synth.qwen_window_index(grid, vc)
+    N = int(batch["pixel_values"].shape[0])
+    vx = e.read_tap("vit_x", N * vc.hidden).reshape(N, vc.hidden)
+    ref_vx = taps[f"vit{vc.depth - 1}"].numpy()
+    assert np.abs(vx - ref_vx).max() < 2e-2 * np.abs(ref_vx).max()
+    ev = e.read_tap("ev", (N // vc.merge_unit) * cfg.hidden).reshape(N // vc.merge_unit, cfg.hidden)
+    ref_rows = taps["image_rows"].numpy()[widx]          # oracle rows are in processor order
+    assert np.abs(ev - ref_rows).max() < 2e-2 * np.abs(ref_rows).max()
+    x = e.read_tap("x", B * S * cfg.hidden).reshape(B, S, cfg.hidden)
+    ref_x = taps[f"layer{cfg.layers - 1}"].numpy()
+    valid = batch["attention_mask"].astype(bool)
+    assert np.abs(x - ref_x)[valid].max() < 2e-2 * np.abs(ref_x[valid]).max()
+
+
+def test_qwen_skipca_quirk_and_preference_order():
+    """Left padding with token 151643 feeds the as-written SkipCA (rows with / without pad tokens in one batch);
+    rewards of a row do not depend on the batch around it, so preference ordering is bit-exact under sharding."""
+    from llava_reward_amd.reward_adaptor_loader import preference_compute
+    cfg = synth.qwen_quirk_config(is_general_preference=True, value_head_dim=2)
+    seed = 41
+    batch = synth.qwen_synth_batch(cfg, seed, [2, 9, 4, 9], [(8, 8), (12, 16), (8, 8), (12, 16)])
+    n_ca = (batch["input_ids"] == synth.QWEN_CA_TOKEN_ID).sum(axis=1)
+    assert (n_ca > 0).any() and (n_ca == 0).any()
+    ref = _oracle(cfg, seed, batch)
+    m = _model(cfg, seed, "f16", upload=False)
+    got = _fwd(m, batch)
+    err = (got - ref).abs().max().item()
+    print(f"[qwen quirk] n_ca={n_ca.tolist()} max |reward err| = {err:.3e} max |reward| = {ref.abs().max().item():.2f}")
+    assert _close(got, ref)
+    # a row scored alone has no padding at all -> no pad-token rows -> a DIFFERENT reward in the reference too;
+    # so shard with the padding kept (what a data-parallel split of a collated batch does)
+    two = _fwd(m, batch, rows=slice(2, 4))
+    assert torch.equal(two, got[2:4])
+
+    class A:
+        is_general_preference, value_head_dim, general_preference_tau = True, 2, 0.1
+    p_full = preference_compute(A, got[:2], got[2:])
+    p_split = preference_compute(A, _fwd(m, batch, rows=slice(0, 2)), two)
+    assert np.array_equal(p_full, p_split)
+
+
+def test_qwen_training_flag_and_errors():
+    cfg = synth.qwen_tiny_config()
+    batch = synth.qwen_synth_batch(cfg, 5, [3, 6], [(8, 8), (8, 8)])
+    m = _model(cfg, 5, "f16", upload=False)
+    ev = _fwd(m, batch)
+    m.train()
+    tr = _fwd(m, batch)
+    m.eval()
+    assert torch.equal(ev, tr)                       # left padding: last position == last valid token (rw_model:410-421)
+    bad = dict(batch)
+    bad["input_ids"] = batch["input_ids"].copy()
+    bad["input_ids"][0, -2] = cfg.image_token_id     # one image slot too many
+    with pytest.raises(ValueError, match="do not match"):
+        _fwd(m, bad)
+    with pytest.raises(TypeError):
+        m.custom_forward(torch.from_numpy(batch["input_ids"]).cuda(), torch.from_numpy(batch["attention_mask"]).cuda())
+    vid = dict(batch)
+    vid["image_grid_thw"] = batch["image_grid_thw"].copy()
+    vid["image_grid_thw"][0] = [2, 4, 8]             # a video grid with the same patch count
+    with pytest.raises(RuntimeError, match="video"):
+        _fwd(m, vid)
+
+
+CASES = sorted(glob.glob(os.path.join(GOLD, "ref_qwen_tiny_*.json")) + glob.glob(os.path.join(GOLD, "ref_qwen_quirk_*.json")))
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-5] for p in CASES])
+def test_qwen_reference_goldens(path):
+    g = json.load(open(path))
+    cfg = synth.QwenConfig.from_json(g["config"])
+    batch = synth.qwen_synth_batch(cfg, g["seed"], g["caption_lens"], [tuple(x) for x in g["grids"]])
+    ref = torch.tensor(g["reward"], dtype=torch.float32)
+    m = _model(cfg, g["seed"], "f16", upload=False)
+    got = _fwd(m, batch).reshape(ref.shape)
+    err = (got - ref).abs().max().item()
+    print(f"[{g['name']}] max |reward err| vs reference = {err:.3e}")
+    assert _close(got, ref)
+
+
+FULL = sorted(glob.glob(os.path.join(GOLD, "ref_qwen_full_*.json")))
+
+
+@pytest.mark.parametrize("path", FULL, ids=[os.path.basename(p)[:-5] for p in FULL])
+def test_qwen_reference_golden_full_size(path):
+    """Qwen2.5-VL-7B shapes (ViT 32 x 1280, 28 layers, D = 3584, 28/4 heads, vocab 152064): reward of the reference's
+    fp32 CPU custom_forward vs the HIP path with weights regenerated in HBM by the same integer hash."""
+    g = json.load(open(path))
+    cfg = synth.QwenConfig.from_json(g["config"])
+    batch = synth.qwen_synth_batch(cfg, g["seed"], g["caption_lens"], [tuple(x) for x in g["grids"]])
+    ref = torch.tensor(g["reward"], dtype=torch.float32)
+    S = batch["input_ids"].shape[1]
+    m = _model(cfg, g["seed"], "f16", upload=False, max_batch=2, max_seq=S, max_patches=2 * 1024)
+    got = _fwd(m, batch).reshape(ref.shape)
+    err = (got - ref).abs().max().item()
+    print(f"[{g['name']}] reward hip={got.flatten().tolist()} ref={ref.flatten().tolist()} err={err:.3e}")
+    assert _close(got, ref)                                             # atol = rtol = 1e-3, see DESIGN.md §4
+    dup = dict(input_ids=np.concatenate([batch["input_ids"]] * 2), attention_mask=np.concatenate([batch["attention_mask"]] * 2),
+               pixel_values=np.concatenate([batch["pixel_values"]] * 2), image_grid_thw=np.concatenate([batch["image_grid_thw"]] * 2))
+    r2 = _fwd(m, dup)
+    assert torch.equal(r2[0], r2[1]) and torch.equal(r2[0], got.reshape(r2[0].shape))
