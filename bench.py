@@ -83,6 +83,24 @@ def cpu_baseline(cfg_full):
                       f"timed ({spent:.1f}s CPU), per-layer cost scaled to full depth -> {total:.1f}s per row, fp32 torch"}
 
 
+def qwen_flop_per_row(cfg, grid, S):
+    """Algorithmic FLOP of one Qwen2.5-VL row: ViT linears + window/full attention + merger, decoder
+    linears + causal attention (lm_head excluded: the reference computes the logits and never reads them)."""
+    v = cfg.vision
+    N = grid[0] * grid[1]
+    hd = v.head_dim
+    lin = 2 * N * v.hidden * (3 * v.hidden + v.hidden + 3 * v.intermediate) * v.depth
+    win = (v.window // v.patch) ** 2                                   # patches per full window
+    att = 4 * N * hd * v.heads * (win * (v.depth - len(v.fullatt)) + N * len(v.fullatt))
+    patch = 2 * N * v.patch_dim * v.hidden
+    mh = v.hidden * v.merge_unit
+    merger = 2 * (N // v.merge_unit) * (mh * mh + mh * cfg.hidden)
+    D, I = cfg.hidden, cfg.intermediate
+    dec = 2 * S * (D * (cfg.heads + 2 * cfg.kv_heads) * cfg.head_dim + cfg.heads * cfg.head_dim * D + 3 * D * I) * cfg.layers
+    datt = 4 * (S * S // 2) * cfg.head_dim * cfg.heads * cfg.layers
+    return float(lin + att + patch + merger + dec + datt)
+
+
 def dominant_kernel_probe(dtype_code, tile, steps=5):
     """HIP-event timing of the dominant kernel (gemm_bt at the gate_up shape) on the launch stream."""
     import ctypes as C
@@ -120,8 +138,9 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="MFMA operand type")
     ap.add_argument("--tile", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--model", default="phi3v", choices=["phi3v", "llava"],
-                    help="phi3v = BASELINE metric (default); llava = LLaVA-v1.6-Mistral-7B shapes of configs[4] with 16-bit operands")
+    ap.add_argument("--model", default="phi3v", choices=["phi3v", "llava", "qwen"],
+                    help="phi3v = BASELINE metric (default); llava = LLaVA-v1.6-Mistral-7B shapes of configs[4] with 16-bit operands; "
+                         "qwen = Qwen2.5-VL-7B shapes of configs[3]")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests)")
     ap.add_argument("--all-ranks-on-device", type=int, default=-1, help="smoke test: put every rank on this one GPU")
     a = ap.parse_args()
@@ -149,10 +168,16 @@ def main():
     B = a.batch
     rows = slice(rank * B, (rank + 1) * B)          # contiguous shard: gathered order == input order
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
-    if a.model == "llava":
+    if a.model == "qwen":
+        cfg = synth.qwen_full_config()              # Qwen2.5-VL-7B, BT head + the as-written SkipCA
+        # 336^2 image -> 448^2 after the reference's min_pixels = 256*28^2 floor (utils/utils.py:35) -> 32x32 patches, 256 slots
+        gb = synth.qwen_synth_batch(cfg, 1234, [128] * (B * world), [(32, 32)] * (B * world), with_pixels=False)
+        ncrop, flop_per_pair = 0, qwen_flop_per_row(cfg, (32, 32), gb["input_ids"].shape[1])
+        workload = "BASELINE configs[3] shapes: Qwen2.5-VL-7B, 448x448 px (32x32 patches, 256 image tokens), BT head + SkipCA"
+    elif a.model == "llava":
         cfg = synth.llava_full_config()             # Mistral-7B decoder + CLIP-L, BT head, no SkipCA on this branch
         gb = synth.llava_synth_batch(cfg, 1234, [128] * (B * world), [(336, 336)] * (B * world), with_pixels=False)
-        ncrop, flop_per_pair = 3, 19.9e12           # 3 crops -> 1176 image tokens; see DESIGN.md §9
+        ncrop, flop_per_pair = 3, 19.9e12           # 3 crops -> 1176 image tokens; see DESIGN.md §8
         workload = "LLaVA-v1.6-Mistral-7B (BASELINE configs[4] shapes, 16-bit operands), 3 crops/img, V=1176"
     else:
         cfg = synth.full_config()                   # BT head (d=1) + SkipCA
@@ -162,15 +187,20 @@ def main():
     S = gb["input_ids"].shape[1]
     ids = torch.from_numpy(gb["input_ids"][rows]).cuda()
     mask = torch.from_numpy(gb["attention_mask"][rows]).cuda()
-    sizes = torch.from_numpy(gb["image_sizes"][rows])
-    pix = torch.randn(B, ncrop, 3, 336, 336, device="cuda", generator=gen)      # CLIP-normalised pixel noise, fp32
-
-    model = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=S, max_crops=max(ncrop, 5 if a.model == 'llava' else 17), operand_dtype=a.dtype).to(f"cuda:{local}").eval()
+    if a.model == "qwen":
+        sizes = torch.from_numpy(gb["image_grid_thw"][rows])
+        pix = torch.randn(B * 32 * 32, cfg.vision.patch_dim, device="cuda", generator=gen)   # normalised pixel noise, fp32
+        model = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=S, max_patches=B * 32 * 32, operand_dtype=a.dtype)
+    else:
+        sizes = torch.from_numpy(gb["image_sizes"][rows])
+        pix = torch.randn(B, ncrop, 3, 336, 336, device="cuda", generator=gen)      # CLIP-normalised pixel noise, fp32
+        model = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=S, max_crops=max(ncrop, 5 if a.model == 'llava' else 17), operand_dtype=a.dtype)
+    model = model.to(f"cuda:{local}").eval()
     if a.tile >= 0:
         model.engine.set_gemm_tile(a.tile)
 
     def step():
-        r = model.engine.forward(ids, mask, pix, sizes)
+        r = model.engine.forward_qwen(ids, mask, pix, sizes) if a.model == "qwen" else model.engine.forward(ids, mask, pix, sizes)
         if world == 1:
             return r
         if a.backend != "nccl":               # gloo smoke path: collectives on host tensors
@@ -201,7 +231,7 @@ def main():
         value = world * B * a.steps / dt
         tf_per_gpu = value * flop_per_pair / world / 1e12
         res = {
-            "metric": "reward-pairs/sec (336px img, 128-tok caption) " + ("Phi-3.5-V" if a.model == "phi3v" else "LLaVA-v1.6-Mistral-7B"), "value": value, "unit": "reward-pairs/sec",
+            "metric": "reward-pairs/sec (336px img, 128-tok caption) " + {"phi3v": "Phi-3.5-V", "llava": "LLaVA-v1.6-Mistral-7B", "qwen": "Qwen2.5-VL-7B"}[a.model], "value": value, "unit": "reward-pairs/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": f"{a.dtype} MFMA operands (bf16-valued weights), f32 accumulate/residual/softmax",

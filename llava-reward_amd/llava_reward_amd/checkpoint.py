@@ -19,7 +19,7 @@ from typing import Dict, Tuple
 
 import torch
 
-from .synth import ClipConfig, LlavaConfig, RewardConfig
+from .synth import ClipConfig, LlavaConfig, QwenConfig, QwenVisionConfig, RewardConfig
 
 
 def config_from_hf(path: str, reward_cfg: dict) -> RewardConfig:
@@ -79,6 +79,53 @@ def llava_config_from_hf(path: str, reward_cfg: dict) -> LlavaConfig:
         pinpoints=tuple(tuple(p) for p in c.get("image_grid_pinpoints", [[336, 672], [672, 336], [672, 672], [1008, 336], [336, 1008]])),
         is_general_preference=bool(reward_cfg["is_general_preference"]), add_cross_attention=False,
         value_head_dim=int(reward_cfg["value_head_dim"]), general_preference_tau=float(reward_cfg["general_preference_tau"]))
+
+
+def qwen_config_from_hf(path: str, reward_cfg: dict) -> QwenConfig:
+    """Qwen2.5-VL-*-Instruct config.json (flat text fields in the 4.50-era layout, `text_config` in the 5.x one;
+    `vision_config`; rope_scaling.mrope_section) + reward_config.yaml -> QwenConfig."""
+    with open(os.path.join(path, "config.json")) as f:
+        c = json.load(f)
+    t = dict(c)
+    t.update(c.get("text_config") or {})
+    v = c.get("vision_config") or {}
+    if t.get("use_sliding_window", False):
+        raise NotImplementedError("sliding-window attention is not implemented (Qwen2.5-VL checkpoints ship use_sliding_window=false)")
+    rs = t.get("rope_scaling") or t.get("rope_parameters") or {}
+    if "mrope_section" not in rs:
+        raise ValueError("rope_scaling.mrope_section is required (Qwen2.5-VL multimodal RoPE)")
+    if rs.get("rope_type", rs.get("type", "default")) not in ("default", "mrope"):
+        raise NotImplementedError(f"rope type {rs.get('rope_type', rs.get('type'))!r} is not implemented")
+    if v.get("hidden_act", "silu") != "silu" or t.get("hidden_act", "silu") != "silu":
+        raise NotImplementedError("only SiLU MLPs are implemented")
+    heads = t["num_attention_heads"]
+    hidden = t["hidden_size"]
+    if v.get("out_hidden_size", hidden) != hidden:
+        raise ValueError("vision_config.out_hidden_size must equal the decoder hidden size")
+    vis = QwenVisionConfig(depth=v.get("depth", 32), hidden=v.get("hidden_size", 1280), heads=v.get("num_heads", 16),
+                           intermediate=v.get("intermediate_size", 3420), patch=v.get("patch_size", 14),
+                           temporal_patch=v.get("temporal_patch_size", 2), merge=v.get("spatial_merge_size", 2),
+                           window=v.get("window_size", 112), fullatt=tuple(v.get("fullatt_block_indexes", [7, 15, 23, 31])),
+                           in_ch=v.get("in_channels", v.get("in_chans", 3)))
+    return QwenConfig(
+        vocab_size=t["vocab_size"], hidden=hidden, intermediate=t["intermediate_size"], layers=t["num_hidden_layers"],
+        heads=heads, kv_heads=t.get("num_key_value_heads", heads), head_dim=hidden // heads,
+        rms_eps=t.get("rms_norm_eps", 1e-6), rope_theta=rs.get("rope_theta", t.get("rope_theta", 1000000.0)),
+        mrope_section=tuple(rs["mrope_section"]), vision=vis, image_token_id=c.get("image_token_id", 151655),
+        pad_token_id=151643,
+        is_general_preference=bool(reward_cfg["is_general_preference"]),
+        add_cross_attention=bool(reward_cfg["add_cross_attention"]),
+        value_head_dim=int(reward_cfg["value_head_dim"]), general_preference_tau=float(reward_cfg["general_preference_tau"]))
+
+
+def canon_qwen_key(k: str) -> str:
+    """Accept both checkpoint layouts: 4.50-era (visual.*, model.layers...) and the 5.x module tree
+    (model.visual.*, model.language_model.layers...)."""
+    if k.startswith("model.visual."):
+        return k[len("model."):]
+    if k.startswith("model.language_model."):
+        return "model." + k[len("model.language_model."):]
+    return k
 
 
 def canon_llava_key(k: str) -> str:
@@ -175,7 +222,12 @@ def read_heads(pm_path: str, cfg: RewardConfig, ft_projector: bool) -> Dict[str,
         for nm in ("W_q", "W_k", "W_v", "ca_layernorm"):
             if not pick(nm, nm + "."):
                 raise KeyError(f"pytorch_model.bin has no {nm}")
-    if ft_projector:
+    if ft_projector and isinstance(cfg, QwenConfig):      # reward_adaptor_loader.py:92-104: keys containing 'merger'
+        found = {".".join(k.split(".")[-2:]): v for k, v in sd.items() if "merger" in k}
+        for src, dst in (("ln_q.weight", "ln_q.weight"), ("0.weight", "mlp.0.weight"), ("0.bias", "mlp.0.bias"),
+                         ("2.weight", "mlp.2.weight"), ("2.bias", "mlp.2.bias")):
+            out["visual.merger." + dst] = found[src]       # KeyError if the head file lacks it, as in the reference
+    elif ft_projector:
         if isinstance(cfg, LlavaConfig):          # reward_adaptor_loader.py:137-145
             pick("multi_modal_projector", "multi_modal_projector.", nparts=2)
         else:

@@ -11,7 +11,7 @@ import yaml
 
 from . import checkpoint as ckpt
 from .model import RewardModel
-from .synth import llava_weight_specs, weight_specs
+from .synth import llava_weight_specs, qwen_weight_specs, weight_specs
 
 
 class UnknownModelType(UnboundLocalError, ValueError):
@@ -76,9 +76,30 @@ def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=Fal
                 tokenizer.pad_token = tokenizer.eos_token
                 tokenizer.pad_token_id = tokenizer.eos_token_id
             tokenizer.truncation_side = "right"
-    elif model_type == "qwen":
-        raise NotImplementedError("model_type='qwen': the Qwen2.5-VL backbone (SURVEY.md §8 row a19) is not on the HIP path yet; "
-                                  "'phi3v' and 'llava' are")
+    elif model_type == "qwen":                       # reward_adaptor_loader.py:64-109
+        if not os.path.isdir(args.pretrain):
+            raise FileNotFoundError(f"args.pretrain={args.pretrain!r} must be a local checkpoint directory "
+                                    "(config.json + *.safetensors); hub download is not available offline")
+        cfg = ckpt.qwen_config_from_hf(args.pretrain, reward_cfg)
+        names = [n for n, *_ in qwen_weight_specs(cfg)]
+        head_names = {n for n in names if n.split(".")[0] in ("value_head", "W_q", "W_k", "W_v", "ca_layernorm")}
+        weights = ckpt.read_base_weights(args.pretrain, [n for n in names if n not in head_names], canon=ckpt.canon_qwen_key)
+        lora, scale = ckpt.read_lora(os.path.join(args.pm_path, "lora"))
+        ckpt.merge_lora(weights, lora, scale, canon=ckpt.canon_qwen_key)
+        weights.update(ckpt.read_heads(args.pm_path, cfg, getattr(args, "ft_projector", False)))
+        model = RewardModel(cfg, weights=weights, max_batch=getattr(args, "max_batch", 32),
+                            max_seq=getattr(args, "max_seq", 2048), max_patches=getattr(args, "max_patches", 0),
+                            operand_dtype=getattr(args, "operand_dtype", "f16"))
+        if load_tokenizer:
+            from transformers import AutoProcessor
+            processor = AutoProcessor.from_pretrained(args.pretrain, cache_dir=getattr(args, "cache_dir", None),
+                                                      min_pixels=256 * 28 * 28, max_pixels=1280 * 28 * 28)    # utils/utils.py:34-44
+            tokenizer = processor.tokenizer
+            tokenizer.padding_side = "left"
+            if tokenizer.pad_token is None:
+                tokenizer.pad_token = tokenizer.eos_token
+                tokenizer.pad_token_id = tokenizer.eos_token_id
+            tokenizer.truncation_side = "right"
     else:
         raise UnknownModelType(f"local variable 'model' referenced before assignment (model_type={model_type!r})")
     if load_tokenizer:

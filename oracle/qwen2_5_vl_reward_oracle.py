@@ -20,7 +20,7 @@ patch-embed conv3d == linear over 1176, window re-ordering, 2-D rotary, per-wind
 RMSNorm + biased SwiGLU MLP, 2x2 patch merger; `Qwen2_5_VLModel.get_rope_index`; `Qwen2_5_VLTextModel`:
 pre-norm decoder, biased q/k/v, GQA, multimodal RoPE with `mrope_section`, SwiGLU).
 Parity pin: tests/golden/ref_qwen_*.json, produced by tests/golden/make_goldens.py from the reference's own
-custom_forward running on the container's transformers (three shims, listed there and in DESIGN.md §10).
+custom_forward running on the container's transformers (three shims, listed there and in DESIGN.md §9).
 """
 from __future__ import annotations
 

@@ -107,7 +107,7 @@ def test_load_reward_adaptor_contract(tmp_path):
     # error behaviour
     with pytest.raises(UnboundLocalError):
         load_reward_adaptor(args, "gemma", os.path.join(pm, "reward_config.yaml"))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises((ValueError, KeyError)):              # a Phi-3-V checkpoint is not a Qwen2.5-VL one
         load_reward_adaptor(args, "qwen", os.path.join(pm, "reward_config.yaml"))
     with pytest.raises(FileNotFoundError):
         load_reward_adaptor(args, "phi3v", os.path.join(pm, "missing.yaml"))
@@ -256,3 +256,53 @@ def test_load_reward_adaptor_llava(tmp_path):
                    open(os.path.join(pm, "reward_config.yaml"), "w"))
     with pytest.raises(AttributeError):          # the reference dies the same way (rw_model:315)
         load_reward_adaptor(args, "llava", os.path.join(pm, "reward_config.yaml"))
+
+
+def test_load_reward_adaptor_qwen(tmp_path):
+    """model_type='qwen' (eval/reward_adaptor_loader.py:64-109): Qwen2.5-VL checkpoint layout (4.50-era flat config and
+    the 5.x module-tree tensor names), LoRA merge, reward heads incl. SkipCA, ft_projector -> visual.merger."""
+    from safetensors.torch import save_file
+    cfg = synth.qwen_tiny_config()
+    v = cfg.vision
+    pre, pm = os.path.join(str(tmp_path), "pre"), os.path.join(str(tmp_path), "pm")
+    os.makedirs(pre); os.makedirs(os.path.join(pm, "lora"))
+    json.dump({"vocab_size": cfg.vocab_size, "hidden_size": cfg.hidden, "intermediate_size": cfg.intermediate,
+               "num_hidden_layers": cfg.layers, "num_attention_heads": cfg.heads, "num_key_value_heads": cfg.kv_heads,
+               "rms_norm_eps": cfg.rms_eps, "rope_theta": cfg.rope_theta, "hidden_act": "silu", "use_sliding_window": False,
+               "rope_scaling": {"type": "mrope", "mrope_section": list(cfg.mrope_section)}, "image_token_id": cfg.image_token_id,
+               "vision_config": {"depth": v.depth, "hidden_size": v.hidden, "num_heads": v.heads, "intermediate_size": v.intermediate,
+                                 "patch_size": 14, "temporal_patch_size": 2, "spatial_merge_size": 2, "window_size": 112,
+                                 "fullatt_block_indexes": list(v.fullatt), "out_hidden_size": cfg.hidden, "hidden_act": "silu"}},
+              open(os.path.join(pre, "config.json"), "w"))
+    W = {k: torch.from_numpy(a) for k, a in synth.qwen_make_weights(cfg, 9).items()}
+    heads = ("value_head", "W_q", "W_k", "W_v", "ca_layernorm")
+
+    def new_name(k):                                 # 5.x module tree: model.visual.*, model.language_model.*
+        return "model." + k if k.startswith("visual.") else k.replace("model.", "model.language_model.", 1)
+    save_file({new_name(k): t.to(torch.bfloat16) for k, t in W.items() if k.split(".")[0] not in heads},
+              os.path.join(pre, "model.safetensors"))
+    ft = {"base_model.model.visual.merger.ln_q.weight": W["visual.merger.ln_q.weight"] + 1.0,
+          "base_model.model.visual.merger.mlp.0.weight": W["visual.merger.mlp.0.weight"], "base_model.model.visual.merger.mlp.0.bias": W["visual.merger.mlp.0.bias"],
+          "base_model.model.visual.merger.mlp.2.weight": W["visual.merger.mlp.2.weight"], "base_model.model.visual.merger.mlp.2.bias": W["visual.merger.mlp.2.bias"]}
+    sd = {f"base_model.model.{k}": t for k, t in W.items() if k.split(".")[0] in heads}
+    sd.update(ft)
+    torch.save(sd, os.path.join(pm, "pytorch_model.bin"))
+    yaml.safe_dump({"is_general_preference": True, "add_cross_attention": True, "value_head_dim": 2, "general_preference_tau": 0.1},
+                   open(os.path.join(pm, "reward_config.yaml"), "w"))
+    cfg2 = synth.qwen_tiny_config(is_general_preference=True, value_head_dim=2)
+    sd["base_model.model.value_head.weight"] = torch.from_numpy(synth.qwen_make_weights(cfg2, 9)["value_head.weight"])
+    torch.save(sd, os.path.join(pm, "pytorch_model.bin"))
+    g = torch.Generator().manual_seed(2)
+    mod = "model.layers.1.self_attn.v_proj"
+    A, Bm = torch.randn(4, cfg.hidden, generator=g) * 0.1, torch.randn(cfg.kv_heads * cfg.head_dim, 4, generator=g) * 0.1
+    torch.save({f"base_model.model.{mod}.lora_A.weight": A, f"base_model.model.{mod}.lora_B.weight": Bm}, os.path.join(pm, "lora", "adapter_model.bin"))
+    json.dump({"r": 4, "lora_alpha": 8}, open(os.path.join(pm, "lora", "adapter_config.json"), "w"))
+    args = types.SimpleNamespace(pm_path=pm, pretrain=pre, cache_dir=None, ft_projector=True, disable_fast_tokenizer=False)
+    args, model = load_reward_adaptor(args, "qwen", os.path.join(pm, "reward_config.yaml"))
+    assert model.model_type == "qwen" and args.add_cross_attention is True and args.value_head_dim == 2
+    assert model.config.vision.fullatt == v.fullatt and model.config.mrope_section == cfg.mrope_section and model.config.ca_eps == 1e-6
+    assert set(n for n, *_ in synth.qwen_weight_specs(cfg2)) == set(model._weights)
+    assert torch.allclose(model._weights[mod + ".weight"], W[mod + ".weight"] + 2.0 * Bm @ A, atol=1e-6)
+    assert torch.equal(model._weights["visual.merger.ln_q.weight"], W["visual.merger.ln_q.weight"] + 1.0)      # ft_projector wins
+    with pytest.raises(RuntimeError):                # no GPU here: the product path refuses, it does not fall back
+        model.custom_forward(inputs_batch={})
