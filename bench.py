@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=32, help="rows per GPU")
-    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="MFMA operand type")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f16x2", "bf16x2"], help="MFMA operand type; x2 = split-operand (parity) mode")
     ap.add_argument("--tile", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="phi3v", choices=["phi3v", "llava", "qwen"],
@@ -244,7 +244,7 @@ def main():
                          "note": "whole pass: pairs/s x %.2f TFLOP algorithmic per pair, per GPU" % (flop_per_pair / 1e12)},
         }
         if world == 1 and a.model == "phi3v":
-            res["roofline"]["dominant_kernel"] = dominant_kernel_probe(L.LR_DT_F16 if a.dtype == "f16" else L.LR_DT_BF16, a.tile)
+            res["roofline"]["dominant_kernel"] = dominant_kernel_probe(L.LR_DT_F16 if a.dtype.startswith("f16") else L.LR_DT_BF16, a.tile)
             if not a.no_cpu_baseline:
                 del model
                 torch.cuda.empty_cache()

@@ -85,6 +85,10 @@ typedef struct lr_model_desc {
     float vit_rope_theta, vit_eps;
     int32_t mrope_section[3];
     int32_t ca_token_id, max_patches;
+    /* Split-operand ("precise") mode, any backbone: every activation that feeds an MFMA is carried as hi + lo in the
+     * operand type (f16: 22 mantissa bits), weights stay single (bf16 checkpoints are exact in f16); every contraction
+     * costs 2x (linears) / 3x (attention) the MFMA work.  0 = single-pass operands (default). */
+    int32_t precise;
 } lr_model_desc;
 
 int lr_abi_version(void);

@@ -50,7 +50,10 @@ template <> __device__ __forceinline__ unsigned pack2_fast<BF16>(float lo, float
 
 constexpr int ATT_MAX_S = 8192;        // keys covered by the LDS bitmask
 
-template <typename OT, int HD, bool CAUSAL>
+// PREC (split-operand mode): Q, K, V rows carry their rounding residuals p.lo_off columns to the right; both
+// contractions are evaluated as hi.hi + hi.lo + lo.hi (the lo.lo term is below 2^-22), P is split the same way in
+// registers, and O leaves as [O_hi | O_lo].  K_lo / V_lo tiles ride in the same ring slot as K / V.
+template <typename OT, int HD, bool CAUSAL, bool PREC>
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 waves/SIMD: <= 256 unified registers, MFMA results stay in VGPRs
     constexpr int KT = 64;                 // keys per tile
     constexpr int KSTEPS = HD / 16;        // MFMA k-steps over the head dim
@@ -58,13 +61,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
     constexpr int ROW = HD * 2;            // image row stride (bytes), unpadded (LDS-DMA is lane-linear)
     constexpr int CH = HD / 8;             // 16-byte chunks per row
     constexpr int NPO = KT * CH / 256;     // DMA instructions per thread per operand tile (3 or 2)
-    constexpr int NPT = 2 * NPO;           // ... per K+V tile
+    constexpr int NOPS = PREC ? 4 : 2;     // operand tiles per ring slot: K, V (, K_lo, V_lo)
+    constexpr int NPT = NOPS * NPO;        // DMA instructions per thread per slot
     constexpr int TILE = KT * ROW;         // bytes of one operand tile
-    constexpr int NSLOT = 3;
+    constexpr int NSLOT = (PREC && HD == 128) ? 2 : 3;          // 160 KB of LDS: 2 x 4 x 16 KB is all that fits at HD 128
+    constexpr int PD = NSLOT - 1;          // tiles in flight ahead of the one being consumed
     static_assert(KT * CH % 256 == 0, "tile/threads mismatch");
 
-    __shared__ __attribute__((aligned(16))) char smem[NSLOT * 2 * TILE + ATT_MAX_S / 8];
-    unsigned* sBits = (unsigned*)(smem + NSLOT * 2 * TILE);     // bit k = key k visible (before the causal rule)
+    __shared__ __attribute__((aligned(16))) char smem[NSLOT * NOPS * TILE + ATT_MAX_S / 8];
+    unsigned* sBits = (unsigned*)(smem + NSLOT * NOPS * TILE);  // bit k = key k visible (before the causal rule)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,27 +112,33 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
         dkc[it] = (HD == 96 ? (c ^ ((r >> 2) & 3)) : HD == 64 ? (c ^ ((r >> 1) & 7)) : (c ^ (r & 15))) * 8;
         dvc[it] = (HD == 96 ? c : HD == 64 ? (c ^ (((r >> 1) & 1) << 2)) : (c ^ ((r & 3) << 2))) * 8;
     }
-    auto issue = [&](int t) {            // tile t (keys kbeg + 64 t ..) -> slot t % 3
+    auto dma = [&](const unsigned short* src, unsigned dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    };
+    auto issue = [&](int t) {            // tile t (keys kbeg + 64 t ..) -> slot t % NSLOT
         const int slot = t % NSLOT;
         const int k0 = kbeg + t * KT;
-        const unsigned dstK = __builtin_amdgcn_readfirstlane(lds_base + slot * 2 * TILE + wave * 1024);
+        const unsigned dstK = __builtin_amdgcn_readfirstlane(lds_base + slot * NOPS * TILE + wave * 1024);
 #pragma unroll
         for (int it = 0; it < NPO; ++it) {
             const size_t key = rowbase + min(k0 + drow[it], S - 1);
             const unsigned short* sk = Kp + key * p.ldq + dkc[it];
             const unsigned short* sv = Vp + key * p.ldq + dvc[it];
-            const unsigned dk = dstK + it * 4096, dv = dk + TILE;
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(sk), "s"(dk) : "memory");
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(sv), "s"(dv) : "memory");
+            const unsigned dk = dstK + it * 4096;
+            dma(sk, dk);
+            dma(sv, dk + TILE);
+            if constexpr (PREC) {
+                dma(sk + p.lo_off, dk + 2 * TILE);
+                dma(sv + p.lo_off, dk + 3 * TILE);
+            }
         }
     };
 
     // ---- prologue: first two tiles in flight, then the key bitmask and the Q fragments ----
     if (ntiles > 0) issue(0);
-    if (ntiles > 1) issue(1);
+    if (PD > 1 && ntiles > 1) issue(1);
     {
         const int w0 = kbeg / KT, w1 = (kend + KT - 1) / KT;
         for (int w = w0 + wave; w < w1; w += 4) {
@@ -144,6 +155,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
         const unsigned short* src = Qp + (rowbase + qrow) * p.ldq + 8 * lh;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = *(const uint4*)(src + 16 * ks);
+    }
+    uint4 qfl[PREC ? KSTEPS : 1];       // residuals of the same Q elements
+    if constexpr (PREC) {
+        const int qrow = min(q0 + lc, S - 1);
+        const unsigned short* src = Qp + (rowbase + qrow) * p.ldq + p.lo_off + 8 * lh;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) qfl[ks] = *(const uint4*)(src + 16 * ks);
     }
     // Retire the ordinary loads HERE (vmcnt(0), expcnt/lgkmcnt untouched).  Otherwise hipcc puts its waits
     // for the Q loads at their first use inside the loop, where a vmcnt(0) would drain the DMA ring on
@@ -182,16 +200,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
 
     for (int t = 0; t < ntiles; ++t) {
         const int k0 = kbeg + t * KT;
-        if (t + 2 < ntiles) {
-            issue(t + 2);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPT) : "memory");
-        } else if (t + 1 < ntiles) {
+        if (t + PD < ntiles) {
+            issue(t + PD);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * NPT) : "memory");
+        } else if (PD > 1 && t + 1 < ntiles) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPT) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();                                  // tile t landed for every wave (and sBits on the first pass)
-        const char* sK = smem + (t % NSLOT) * 2 * TILE;
+        const char* sK = smem + (t % NSLOT) * NOPS * TILE;
         const char* sV = sK + TILE;
 
         // waves whose 32 queries all precede this tile have nothing to do (diagonal workgroup tiles)
@@ -207,6 +225,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
                 for (int ks = 0; ks < KSTEPS; ++ks) {
                     const uint4 kf = *(const uint4*)(sK + koff[kt][ks]);
                     s[kt] = Op<OT>::mfma32(kf, qf[ks], s[kt]);
+                    if constexpr (PREC) {
+                        s[kt] = Op<OT>::mfma32(kf, qfl[ks], s[kt]);
+                        const uint4 kl = *(const uint4*)(sK + 2 * TILE + koff[kt][ks]);
+                        s[kt] = Op<OT>::mfma32(kl, qf[ks], s[kt]);
+                    }
                 }
             }
             // ---- masks only where a tile needs them (wave-uniform) ----
@@ -259,11 +282,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
-                    uint4 pf;
-                    pf.x = pack2_fast<OT>(s[kt][8 * st + 0], s[kt][8 * st + 1]);
-                    pf.y = pack2_fast<OT>(s[kt][8 * st + 2], s[kt][8 * st + 3]);
-                    pf.z = pack2_fast<OT>(s[kt][8 * st + 4], s[kt][8 * st + 5]);
-                    pf.w = pack2_fast<OT>(s[kt][8 * st + 6], s[kt][8 * st + 7]);
+                    uint4 pf, pl;
+                    if constexpr (PREC) {
+                        split2<OT>(s[kt][8 * st + 0], s[kt][8 * st + 1], pf.x, pl.x);
+                        split2<OT>(s[kt][8 * st + 2], s[kt][8 * st + 3], pf.y, pl.y);
+                        split2<OT>(s[kt][8 * st + 4], s[kt][8 * st + 5], pf.z, pl.z);
+                        split2<OT>(s[kt][8 * st + 6], s[kt][8 * st + 7], pf.w, pl.w);
+                    } else {
+                        pf.x = pack2_fast<OT>(s[kt][8 * st + 0], s[kt][8 * st + 1]);
+                        pf.y = pack2_fast<OT>(s[kt][8 * st + 2], s[kt][8 * st + 3]);
+                        pf.z = pack2_fast<OT>(s[kt][8 * st + 4], s[kt][8 * st + 5]);
+                        pf.w = pack2_fast<OT>(s[kt][8 * st + 6], s[kt][8 * st + 7]);
+                    }
 #pragma unroll
                     for (int d = 0; d < DT; ++d) {
                         // keys kt*32 + 16*st + 4h + {0..3} and +8, d columns d*32 + (lane&31)
@@ -274,6 +304,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
                         const uint2 a = __builtin_bit_cast(uint2, v0), c = __builtin_bit_cast(uint2, v1);
                         vf.x = a.x; vf.y = a.y; vf.z = c.x; vf.w = c.y;
                         o[d] = Op<OT>::mfma32(vf, pf, o[d]);
+                        if constexpr (PREC) {
+                            o[d] = Op<OT>::mfma32(vf, pl, o[d]);
+                            const s16x4 w0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 2 * TILE));
+                            const s16x4 w1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 2 * TILE + 8 * ROW));
+                            uint4 vl;
+                            const uint2 a2 = __builtin_bit_cast(uint2, w0), c2 = __builtin_bit_cast(uint2, w1);
+                            vl.x = a2.x; vl.y = a2.y; vl.z = c2.x; vl.w = c2.y;
+                            o[d] = Op<OT>::mfma32(vl, pf, o[d]);
+                        }
                     }
                 }
         }
@@ -288,10 +327,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
         for (int d = 0; d < DT; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                uint2 w;
-                w.x = pack2<OT>(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv);
-                w.y = pack2<OT>(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+                uint2 w, wl;
+                split2<OT>(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv, w.x, wl.x);
+                split2<OT>(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv, w.y, wl.y);
                 *(uint2*)(dst + d * 32 + 8 * g) = w;
+                if (p.o_split > 0) *(uint2*)(dst + p.o_split + d * 32 + 8 * g) = wl;
             }
     }
 }
@@ -299,13 +339,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
 template <typename OT, int HD, bool CAUSAL>
 static void launch_one(const AttnParams& p, int batch, hipStream_t st) {
     const int nqt = p.items ? p.n_items : (p.S + 127) / 128;
-    hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL>), dim3(nqt, p.heads, batch), dim3(256), 0, st, p);
+    if (p.lo_off > 0) hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true>), dim3(nqt, p.heads, batch), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, false>), dim3(nqt, p.heads, batch), dim3(256), 0, st, p);
 }
 
 void launch_attention(const AttnParams& p, int batch, int head_dim, bool causal, int operand_dtype, hipStream_t st) {
     if (batch <= 0) return;
     if (p.ldq % 8 || p.qoff % 8 || p.koff % 8 || p.voff % 8 || p.ldo % 4)
         throw std::runtime_error("attention: operand rows must be 16-byte aligned");
+    if (p.lo_off < 0 || p.lo_off % 8 || p.o_split < 0 || p.o_split % 4) throw std::runtime_error("attention: bad split-operand offsets");
     if (p.items && (causal || p.mask || batch != 1 || p.n_items < 1)) throw std::runtime_error("attention: ragged mode is dense, unmasked, batch 1");
     if (p.S > ATT_MAX_S) throw std::runtime_error("attention: sequence length above 8192 is not supported");
     if (p.kv_group < 1 || p.heads % p.kv_group) throw std::runtime_error("attention: heads must be a multiple of kv_group");

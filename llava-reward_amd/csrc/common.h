@@ -54,6 +54,15 @@ template <typename OT> __device__ __forceinline__ unsigned pack2(float lo, float
     return (unsigned)Op<OT>::from_f32(lo) | ((unsigned)Op<OT>::from_f32(hi) << 16);
 }
 
+// Split-operand ("precise") mode: an fp32 value leaves as hi = round(x) plus lo = round(x - hi), both in the operand type.
+// With f16 the pair carries 22 mantissa bits; weights are bf16-valued and therefore exact in f16, so a GEMM over
+// [A_hi | A_lo] x [W | W] reproduces the fp32 product to ~2^-22 at twice the MFMA work.
+template <typename OT> __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const unsigned short ha = Op<OT>::from_f32(a), hb = Op<OT>::from_f32(b);
+    hi = (unsigned)ha | ((unsigned)hb << 16);
+    lo = pack2<OT>(a - Op<OT>::to_f32(ha), b - Op<OT>::to_f32(hb));
+}
+
 // x * sigmoid(a*x) with the hardware exp2/rcp (1 ulp each; the result is rounded to a 16-bit operand anyway)
 __device__ __forceinline__ float x_sigmoid_fast(float x, float a) {
     const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * a * x);
@@ -97,6 +106,10 @@ struct GemmParams {
     // EPI_ROPE_OP: cos/sin table [M][rope_hd/2][2] and the number of leading columns (q and k sections) to rotate
     const float* rope_cs;
     int rope_cols, rope_hd;
+    // split-operand mode.  kw > 0: W has only kw columns of K and is re-read from column 0 when k reaches kw
+    // (A = [A_hi | A_lo], K = 2 kw).  split > 0: epilogues that emit operands also store the rounding residual of
+    // every element `split` columns to the right of it (C = [C_hi | C_lo], ldc covers both halves).
+    int kw, split;
 };
 
 struct AttnParams {
@@ -117,6 +130,9 @@ struct AttnParams {
     // row items[x].x and is items[x].y rows long; S, mask and kmin are ignored
     const int4* items;
     int n_items;
+    // split-operand mode: lo_off > 0 = Q/K/V rows carry their rounding residuals lo_off columns to the right and the
+    // kernel evaluates hi.hi + hi.lo + lo.hi for both contractions; o_split > 0 = O is stored as [O_hi | O_lo]
+    int lo_off, o_split;
 };
 
 }  // namespace lr

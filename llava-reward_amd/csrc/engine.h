@@ -73,6 +73,7 @@ struct lr_engine {
     int Hq = 0, Hkv = 0, Nqkv = 0;      // decoder projection widths: heads*hd, kv_heads*hd, Hq + 2*Hkv
     bool llava = false, qwen = false;
     int op_dt = DT_BF16;
+    int prec = 0;              // split-operand mode: operand buffers are [hi | lo], twice as wide
 
     // Qwen2.5-VL ViT geometry: head dim vhd stored vhdp wide, MLP width vI stored vIp wide, patch vector vK padded to vKpad
     int vH = 0, vhd = 0, vhdp = 0, vHp = 0, vI = 0, vIp = 0, vK = 0, vKpad = 0, vHm = 0, vunit = 0;
@@ -219,9 +220,23 @@ template <typename F> int guarded(lr_engine* e, F&& f) {
     }
 }
 
+// Split-operand mode: callers pass LOGICAL shapes; here A becomes [A_hi | A_lo] (K doubled, W re-read from column 0) and an
+// operand-typed output becomes [C_hi | C_lo].
+inline void apply_prec(const lr_engine* e, GemmParams& p) {
+    if (!e->prec) return;
+    p.kw = p.K; p.K *= 2; p.lda *= 2;
+    if (p.epi == EPI_OUT_OP || p.epi == EPI_SWIGLU_OP || p.epi == EPI_ROPE_OP) { p.split = p.ldc; p.ldc *= 2; }
+}
+inline void apply_prec(const lr_engine* e, AttnParams& p) {
+    if (!e->prec) return;
+    p.lo_off = p.ldq; p.ldq *= 2;
+    p.o_split = p.ldo; p.ldo *= 2;
+}
+
 inline void gemm(lr_engine* e, hipStream_t st, const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int lda,
           int ldw, int ldc, int epi, int act) {
     GemmParams p{A, W, C, bias, M, N, K, lda, ldw, ldc, epi, act, nullptr, 0, 0};
+    apply_prec(e, p);
     launch_gemm_bt(p, e->op_dt, e->gemm_tile, st);
 }
 

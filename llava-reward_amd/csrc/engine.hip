@@ -166,21 +166,23 @@ void run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_ma
     const int Hq = h->Hq, Hkv = h->Hkv, Nqkv = h->Nqkv;
     for (int l = 0; l < nl; ++l) {
         const DecLayer& L = h->dl[l];
-        launch_norm_rows(h->x, L.ln1, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st);
+        launch_norm_rows(h->x, L.ln1, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st, h->prec);
         {   // qkv projection with RoPE on q,k: fused in the GEMM epilogue when the deep-pipelined kernel runs
             GemmParams gp{h->h, L.qkv_w, h->qkv, L.qkv_b, Rl, Nqkv, D, D, D, Nqkv, EPI_ROPE_OP, ACT_NONE, h->cs, Hq + Hkv, h->hd};
+            apply_prec(h, gp);
             if ((Hq + Hkv) % 256 == 0 && gemm_bt_is_deep(gp, h->gemm_tile)) {
                 launch_gemm_bt(gp, h->op_dt, h->gemm_tile, st);
             } else {
                 gemm(h, st, h->h, L.qkv_w, h->qkv32, L.qkv_b, Rl, Nqkv, D, D, D, Nqkv, EPI_OUT_F32, ACT_NONE);
-                launch_rope_split(h->qkv32, h->cs, h->qkv, Rl, Hq + Hkv, Hkv, h->hd, h->op_dt, st);
+                launch_rope_split(h->qkv32, h->cs, h->qkv, Rl, Hq + Hkv, Hkv, h->hd, h->op_dt, st, h->prec);
             }
         }
         AttnParams ap{h->qkv, h->qkv, h->qkv, h->att, attention_mask, h->tstat + 1, 4, Nqkv, Hq, 0, Hq, Hq + Hkv, S, d.heads, ascale,
                       d.heads / d.kv_heads};
+        apply_prec(h, ap);
         launch_attention(ap, B, h->hd, true, h->op_dt, st);
         gemm(h, st, h->att, L.o_w, h->x, nullptr, Rl, D, Hq, Hq, Hq, D, EPI_RESADD_F32, ACT_NONE);
-        launch_norm_rows(h->x, L.ln2, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st);
+        launch_norm_rows(h->x, L.ln2, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st, h->prec);
         gemm(h, st, h->h, L.gu_w, h->ff, nullptr, Rl, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE);
         gemm(h, st, h->ff, L.down_w, h->x, nullptr, Rl, D, I, I, I, D, EPI_RESADD_F32, ACT_NONE);
     }
@@ -205,6 +207,7 @@ int lr_create(const lr_model_desc* desc, int device, lr_handle* out) {
         e->d = *desc;
         e->device = device;
         e->op_dt = desc->operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16;
+        e->prec = desc->precise ? 1 : 0;
         e->llava = desc->backbone == LR_BACKBONE_LLAVA_NEXT;
         e->qwen = desc->backbone == LR_BACKBONE_QWEN2_5_VL;
         if (!e->qwen) {
@@ -323,17 +326,18 @@ int lr_finalize(lr_handle h) {
         const size_t PAD = 256;
         const size_t NC = B * C, Rc = NC * h->T + PAD, Rp = NC * (h->T - 1) + PAD, SV = B * (size_t)h->Vcap + PAD, Rl = B * S + PAD;
         auto W = [&](size_t bytes) { return h->dalloc(bytes, false); };
-        h->patchA = W(Rp * h->Kpad * 2); h->patch_out = (float*)W(Rp * Hc * 4);
-        h->clip_x = (float*)W(Rc * Hc * 4); h->clip_h = W(Rc * Hc * 2); h->clip_qkv = W(Rc * 3 * Hc * 2);
-        h->clip_att = W(Rc * Hc * 2); h->clip_ff = W(Rc * Mc * 2);
+        const size_t ob = 2 * (size_t)(1 + h->prec);      // bytes per operand element (hi [+ lo])
+        h->patchA = W(Rp * h->Kpad * ob); h->patch_out = (float*)W(Rp * Hc * 4);
+        h->clip_x = (float*)W(Rc * Hc * 4); h->clip_h = W(Rc * Hc * ob); h->clip_qkv = W(Rc * 3 * Hc * ob);
+        h->clip_att = W(Rc * Hc * ob); h->clip_ff = W(Rc * Mc * ob);
         if (h->llava) {       // projector runs on every crop token, packing afterwards
-            h->hdA = W(Rp * Hc * 2); h->proj1 = W(Rp * D * 2); h->pf32 = (float*)W(Rp * D * 4);
+            h->hdA = W(Rp * Hc * ob); h->proj1 = W(Rp * D * ob); h->pf32 = (float*)W(Rp * D * 4);
         } else {              // HD-merged rows go through the projector
-            h->hdA = W(SV * 4 * Hc * 2); h->proj1 = W(SV * D * 2);
+            h->hdA = W(SV * 4 * Hc * ob); h->proj1 = W(SV * D * ob);
         }
         h->ev = (float*)W(SV * D * 4);
-        h->x = (float*)W(Rl * D * 4); h->h = W(Rl * D * 2); h->qkv32 = (float*)W(Rl * h->Nqkv * 4); h->qkv = W(Rl * h->Nqkv * 2);
-        h->att = W(Rl * h->Hq * 2); h->ff = W(Rl * I * 2); h->cs = (float*)W(Rl * h->hd * 4);
+        h->x = (float*)W(Rl * D * 4); h->h = W(Rl * D * ob); h->qkv32 = (float*)W(Rl * h->Nqkv * 4); h->qkv = W(Rl * h->Nqkv * ob);
+        h->att = W(Rl * h->Hq * ob); h->ff = W(Rl * I * ob); h->cs = (float*)W(Rl * h->hd * 4);
         h->pos_ids = (int*)W(Rl * 4); h->img_row = (int*)W(Rl * 4); h->tstat = (int*)W(B * 16);
         h->hL = (float*)W(B * D * 4); h->tq = (float*)W(B * D * 4); h->tkq = (float*)W(B * D * 4);
         h->tsc = (float*)W(B * (size_t)h->Vcap * 4); h->tctx = (float*)W(B * D * 4); h->tao = (float*)W(B * D * 4);
@@ -353,7 +357,7 @@ int lr_set_layer_limits(lr_handle h, int n_clip_layers, int n_layers) {
     return LR_OK;
 }
 int lr_set_gemm_tile(lr_handle h, int tile) {
-    if (!h || tile < -1 || tile > 6) return LR_EINVAL;
+    if (!h || tile < -1 || tile > 15) return LR_EINVAL;
     h->gemm_tile = tile;
     return LR_OK;
 }
@@ -439,30 +443,31 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
 
         // ---- CLIP tower (utils/utils.py:266-273) ----
         const int Rp = NC * (T - 1), Rc = NC * T;
-        launch_im2col(pixel_values, pix_dtype == LR_DT_F32 ? DT_F32 : DT_BF16, d_crop_src, NC, img, d.clip_patch, h->Kpad, h->patchA, h->op_dt, st);
+        launch_im2col(pixel_values, pix_dtype == LR_DT_F32 ? DT_F32 : DT_BF16, d_crop_src, NC, img, d.clip_patch, h->Kpad, h->patchA, h->op_dt, st, h->prec);
         gemm(h, st, h->patchA, h->patch_w, h->patch_out, nullptr, Rp, Hc, h->Kpad, h->Kpad, h->Kpad, Hc, EPI_OUT_F32, ACT_NONE);
         launch_clip_embed(h->patch_out, h->cls, h->pos, h->pre_w, h->pre_b, h->clip_x, NC, T, Hc, d.clip_ln_eps, st);
         const int ncl = h->lim_clip >= 0 && h->lim_clip < d.clip_layers ? h->lim_clip : d.clip_layers;
         for (int l = 0; l < ncl; ++l) {
             const ClipLayer& c = h->cl[l];
-            launch_norm_rows(h->clip_x, c.ln1_w, c.ln1_b, h->clip_h, Rc, Hc, d.clip_ln_eps, h->op_dt, st);
+            launch_norm_rows(h->clip_x, c.ln1_w, c.ln1_b, h->clip_h, Rc, Hc, d.clip_ln_eps, h->op_dt, st, h->prec);
             gemm(h, st, h->clip_h, c.qkv_w, h->clip_qkv, c.qkv_b, Rc, 3 * Hc, Hc, Hc, Hc, 3 * Hc, EPI_OUT_OP, ACT_NONE);
             AttnParams ap{h->clip_qkv, h->clip_qkv, h->clip_qkv, h->clip_att, nullptr, nullptr, 0, 3 * Hc, Hc, 0, Hc, 2 * Hc, T, d.clip_heads, 0.125f, 1};
+            apply_prec(h, ap);
             launch_attention(ap, NC, 64, false, h->op_dt, st);
             gemm(h, st, h->clip_att, c.out_w, h->clip_x, c.out_b, Rc, Hc, Hc, Hc, Hc, Hc, EPI_RESADD_F32, ACT_NONE);
-            launch_norm_rows(h->clip_x, c.ln2_w, c.ln2_b, h->clip_h, Rc, Hc, d.clip_ln_eps, h->op_dt, st);
+            launch_norm_rows(h->clip_x, c.ln2_w, c.ln2_b, h->clip_h, Rc, Hc, d.clip_ln_eps, h->op_dt, st, h->prec);
             gemm(h, st, h->clip_h, c.fc1_w, h->clip_ff, c.fc1_b, Rc, Mc, Hc, Hc, Hc, Mc, EPI_OUT_OP, ACT_QUICK_GELU);
             gemm(h, st, h->clip_ff, c.fc2_w, h->clip_x, c.fc2_b, Rc, Hc, Mc, Mc, Mc, Hc, EPI_RESADD_F32, ACT_NONE);
         }
         if (h->llava) {
             // ---- per-token projector, then anyres packing (modeling_llava_next.py get_image_features/pack_image_features) ----
-            launch_clip_tokens(h->clip_x, h->hdA, NC, T, Hc, h->op_dt, st);
+            launch_clip_tokens(h->clip_x, h->hdA, NC, T, Hc, h->op_dt, st, h->prec);
             gemm(h, st, h->hdA, h->p0_w, h->proj1, h->p0_b, Rp, D, Hc, Hc, Hc, D, EPI_OUT_OP, ACT_GELU_ERF);
             gemm(h, st, h->proj1, h->p2_w, h->pf32, h->p2_b, Rp, D, D, D, D, D, EPI_OUT_F32, ACT_NONE);
             launch_llava_pack(h->pf32, d_lsmp, B, SV, h->G, D, h->newline, h->ev, st);
         } else {
             // ---- HD transform + projector (modeling_phi3_v.py:254-303) ----
-            launch_hd_gather(h->clip_x, d_smp, B, SV, T, Hc, h->sub_gn, h->glb_gn, h->hdA, h->op_dt, st);
+            launch_hd_gather(h->clip_x, d_smp, B, SV, T, Hc, h->sub_gn, h->glb_gn, h->hdA, h->op_dt, st, h->prec);
             gemm(h, st, h->hdA, h->p0_w, h->proj1, h->p0_b, SV, D, 4 * Hc, 4 * Hc, 4 * Hc, D, EPI_OUT_OP, ACT_GELU_ERF);
             gemm(h, st, h->proj1, h->p2_w, h->ev, h->p2_b, SV, D, D, D, D, D, EPI_OUT_F32, ACT_NONE);
         }

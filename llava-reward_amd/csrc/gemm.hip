@@ -84,6 +84,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bt_kernel(GemmParams p) {
         char* sA = smem + buf * STAGE;
         char* sB = sA + A_BYTES;
         const int koff = kt * BK;
+        const int koffw = (p.kw > 0 && koff >= p.kw) ? koff - p.kw : koff;      // split-operand mode: W repeats along K
 #pragma unroll
         for (int it = 0; it < A_LOADS; ++it) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA[it] + koff),
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bt_kernel(GemmParams p) {
         }
 #pragma unroll
         for (int it = 0; it < B_LOADS; ++it) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB[it] + koff),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB[it] + koffw),
                                              (__attribute__((address_space(3))) void*)(sB + (it * NT + wave * 64) * 16),
                                              16, 0, 0);
         }
@@ -169,7 +170,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bt_kernel(GemmParams p) {
                         float g = acc[i][2 * jj][r], u = acc[i][2 * jj + 1][r];
                         if (p.bias) { const int pc = n0 + wn * TN + jj * 64 + lr_; g += p.bias[pc]; u += p.bias[pc + 32]; }
                         const float v = u * (g / (1.f + expf(-g)));
-                        C[(size_t)row * p.ldc + col] = Op<OT>::from_f32(v);
+                        const unsigned short hv = Op<OT>::from_f32(v);
+                        C[(size_t)row * p.ldc + col] = hv;
+                        if (p.split > 0) C[(size_t)row * p.ldc + p.split + col] = Op<OT>::from_f32(v - Op<OT>::to_f32(hv));
                     }
                 }
             }
@@ -191,7 +194,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bt_kernel(GemmParams p) {
                 if (p.epi == EPI_OUT_OP) {
                     if (p.act == ACT_QUICK_GELU) v = v / (1.f + expf(-1.702f * v));
                     else if (p.act == ACT_GELU_ERF) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-                    ((unsigned short*)p.C)[o] = Op<OT>::from_f32(v);
+                    const unsigned short hv = Op<OT>::from_f32(v);
+                    ((unsigned short*)p.C)[o] = hv;
+                    if (p.split > 0) ((unsigned short*)p.C)[o + p.split] = Op<OT>::from_f32(v - Op<OT>::to_f32(hv));
                 } else if (p.epi == EPI_OUT_F32) {
                     ((float*)p.C)[o] = v;
                 } else {
@@ -237,6 +242,8 @@ bool gemm_bt_is_deep(const GemmParams& p, int tile) { return pick_tile(p, tile) 
 void launch_gemm_bt(const GemmParams& p, int operand_dtype, int tile, hipStream_t st) {
     if (p.M <= 0) return;
     if (p.K % 64 != 0) throw std::runtime_error("gemm_bt: K must be a multiple of 64");
+    if (p.kw < 0 || (p.kw > 0 && (p.kw % 64 || p.K != 2 * p.kw))) throw std::runtime_error("gemm_bt: split-operand mode needs K == 2 * kw, kw % 64 == 0");
+    if (p.split < 0 || p.split % 8) throw std::runtime_error("gemm_bt: split must be a non-negative multiple of 8");
     if (p.epi == EPI_SWIGLU_OP && (p.N % 64) != 0) throw std::runtime_error("gemm_bt: SwiGLU needs N % 64 == 0");
     tile = pick_tile(p, tile);
     if (tile >= 3) { launch_gemm_bt8(p, operand_dtype, tile, st); return; }

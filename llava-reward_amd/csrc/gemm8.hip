@@ -31,7 +31,8 @@ namespace lr {
 #define LR_BARRIER() do { asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 // DBG: 0 = product; 1 = every K-tile re-reads K-tile 0 (cache-resident operands; results invalid);
-//      2 = no epilogue (results invalid).  Diagnostics for tools/gemm_bench.py only.
+//      2 = no epilogue; 3 = in-kernel stamps; 4 = LDS-DMA stream alone; 5 = ds_reads + MFMAs alone (results invalid).
+//      Diagnostics for tools/gemm_bench.py / tools/gemm_stamps.py only.
 // EPI is a template parameter so that each instantiation carries ONE epilogue: with all of them
 // unrolled in one kernel the code was ~130 KB and every tile's epilogue ran out of the instruction cache.
 template <typename OT, int PF, int NS, int DBG, int EPI>
@@ -126,18 +127,16 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         // `s_waitcnt vmcnt(0)` in front of every ds_read (it cannot prove the pending DMA does not alias)
         // and drain the ring each phase.  Ordering is ours: counted vmcnt, then a barrier, then the read
         // (cdna_hip_programming.md §5.7 item 1).  M0 is saved/restored inside the statement.
-        auto issue = [&](int j, int kt, int slot) {
-            const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds_base + slot * HT + wave * 1024);
+        auto issue1 = [&](int j, int kt, int slot, int it) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * HT + wave * 1024 + it * 8192);
             const int koff = DBG == 1 ? 0 : kt * BK;
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const unsigned short* src = ((j == 0) ? gA[0][it] : (j == 1) ? gB[0][it] : (j == 2) ? gB[1][it] : gA[1][it]) + koff;
-                const unsigned dst = dst0 + it * 8192;
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-            }
+            const int koffw = (p.kw > 0 && koff >= p.kw) ? koff - p.kw : koff;      // split-operand mode: W repeats along K
+            const unsigned short* src = (j == 0) ? gA[0][it] + koff : (j == 1) ? gB[0][it] + koffw : (j == 2) ? gB[1][it] + koffw : gA[1][it] + koff;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
         };
+        auto issue = [&](int j, int kt, int slot) { issue1(j, kt, slot, 0); issue1(j, kt, slot, 1); };
 
         f32x4 acc[4][4][2];     // [quadrant (0,0) (0,1) (1,1) (1,0)][row tile of 16][col tile of 16]
 #pragma unroll
@@ -157,6 +156,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
             if (g < Gtot) issue(g & 3, g >> 2, islot);
             islot = (islot + 1 == NS) ? 0 : islot + 1;
         }
+        constexpr int WAITN = 2 * (PF - 2);
         if (Gtot > PF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PF - 2)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         LR_BARRIER();
@@ -179,29 +179,24 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
                 if constexpr (DBG == 3) t0 = stamp();
                 // ---------------- LOAD ----------------
+                const bool more = gi < Gtot;
+                if constexpr (DBG != 4)
                 if (ph == 0 || ph == 1 || ph == 3) {
                     const char* sb = (ph == 1) ? sB1 : sB0;
 #pragma unroll
                     for (int f = 0; f < 4; ++f) bf[f] = *(const uint4*)(sb + boff[f]);
                 }
+                if constexpr (DBG != 4)
                 if (ph == 0 || ph == 2) {
                     const char* sa = (ph == 0) ? sA0 : sA1;
 #pragma unroll
                     for (int f = 0; f < 8; ++f) af[f] = *(const uint4*)(sa + aoff[f]);
                 }
-                unsigned long long ta = 0, tb = 0;
-                if constexpr (DBG == 3) ta = stamp();
-                if (gi < Gtot) {
-                    issue((ph + PF) & 3, kt + ((ph + PF) >> 2), islot);
-                    if constexpr (DBG == 3) tb = stamp();
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PF - 2)) : "memory");
+                if (more) {
+                    if constexpr (DBG != 5) issue((ph + PF) & 3, kt + ((ph + PF) >> 2), islot);
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
                 } else {
-                    if constexpr (DBG == 3) tb = stamp();
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                if constexpr (DBG == 3) {
-                    const unsigned long long tc = stamp();
-                    lsegs[0] += (unsigned)(ta - t0); lsegs[1] += (unsigned)(tb - ta); lsegs[2] += (unsigned)(tc - tb);
                 }
                 ++gi;
                 islot = (islot + 1 == NS) ? 0 : islot + 1;
@@ -210,18 +205,21 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 if constexpr (DBG == 3) t2 = stamp();
                 // ---------------- COMPUTE ----------------
                 __builtin_amdgcn_s_setprio(1);
+                if constexpr (DBG != 4)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
+                        for (int j = 0; j < 2; ++j) {
                             acc[ph][i][j] = Op<OT>::mfma16(af[i * 2 + ks], bf[j * 2 + ks], acc[ph][i][j]);
+                        }
                 __builtin_amdgcn_s_setprio(0);
                 if constexpr (DBG == 3) t3 = stamp();
                 LR_BARRIER();
                 if constexpr (DBG == 3) {
                     t4 = stamp();
+                    if (ph == 0) { const unsigned long long t5 = stamp(); lsegs[0] += (unsigned)(t5 - t4); }   // cost of one stamp
                     segs[ph][0] += (unsigned)(t1 - t0); segs[ph][1] += (unsigned)(t2 - t1);
                     segs[ph][2] += (unsigned)(t3 - t2); segs[ph][3] += (unsigned)(t4 - t3);
                 }
@@ -242,7 +240,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 dbg2[0] = lsegs[0]; dbg2[1] = lsegs[1]; dbg2[2] = lsegs[2];
             }
         }
-        if constexpr (DBG >= 2) {   // diagnostic: no epilogue (keep the accumulators live)
+        if constexpr (DBG >= 2) {   // diagnostics 2-5: no epilogue (keep the accumulators live)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -334,12 +332,13 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                     }
                     if (row < p.M && n0 + wcc * 64 + 64 <= p.N) {
                         auto sw = [](float gg, float uu) { return uu * x_sigmoid_fast(gg, 1.f); };
-                        uint4 w;
-                        w.x = pack2<OT>(sw(g0.x, u0.x), sw(g0.y, u0.y));
-                        w.y = pack2<OT>(sw(g0.z, u0.z), sw(g0.w, u0.w));
-                        w.z = pack2<OT>(sw(g1.x, u1.x), sw(g1.y, u1.y));
-                        w.w = pack2<OT>(sw(g1.z, u1.z), sw(g1.w, u1.w));
+                        uint4 w, wl;
+                        split2<OT>(sw(g0.x, u0.x), sw(g0.y, u0.y), w.x, wl.x);
+                        split2<OT>(sw(g0.z, u0.z), sw(g0.w, u0.w), w.y, wl.y);
+                        split2<OT>(sw(g1.x, u1.x), sw(g1.y, u1.y), w.z, wl.z);
+                        split2<OT>(sw(g1.z, u1.z), sw(g1.w, u1.w), w.w, wl.w);
                         *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + ocol) = w;
+                        if (p.split > 0) *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + p.split + ocol) = wl;
                     }
                 }
             } else if constexpr (E_ == EPI_ROPE_OP) {
@@ -364,10 +363,11 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                         v1 = make_float4(x1.x * bq.x - x1.y * bq.y, x1.y * bq.x + x1.x * bq.y, x1.z * bq.z - x1.w * bq.w, x1.w * bq.z + x1.z * bq.w);
                     }
                     if (row < p.M && col < p.N) {
-                        uint4 w;
-                        w.x = pack2<OT>(v0.x, v0.y); w.y = pack2<OT>(v0.z, v0.w);
-                        w.z = pack2<OT>(v1.x, v1.y); w.w = pack2<OT>(v1.z, v1.w);
+                        uint4 w, wl;
+                        split2<OT>(v0.x, v0.y, w.x, wl.x); split2<OT>(v0.z, v0.w, w.y, wl.y);
+                        split2<OT>(v1.x, v1.y, w.z, wl.z); split2<OT>(v1.z, v1.w, w.w, wl.w);
                         *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + col) = w;
+                        if (p.split > 0) *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + p.split + col) = wl;
                     }
                 };
 #pragma unroll
@@ -394,10 +394,11 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                             if (p.act == ACT_QUICK_GELU) v[e] = x_sigmoid_fast(v[e], 1.702f);
                             else if (p.act == ACT_GELU_ERF) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752440f));
                         }
-                        uint4 w;
-                        w.x = pack2<OT>(v[0], v[1]); w.y = pack2<OT>(v[2], v[3]);
-                        w.z = pack2<OT>(v[4], v[5]); w.w = pack2<OT>(v[6], v[7]);
+                        uint4 w, wl;
+                        split2<OT>(v[0], v[1], w.x, wl.x); split2<OT>(v[2], v[3], w.y, wl.y);
+                        split2<OT>(v[4], v[5], w.z, wl.z); split2<OT>(v[6], v[7], w.w, wl.w);
                         *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + col) = w;
+                        if (p.split > 0) *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + p.split + col) = wl;
                     }
                 }
             } else {
@@ -475,6 +476,8 @@ static void launch8_variant(const GemmParams& p, int variant, hipStream_t st) {
         case 7: launch8<OT, 5, 1, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: cache-resident operands
         case 8: launch8<OT, 5, 2, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: no epilogue
         case 9: launch8<OT, 5, 3, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: in-kernel stamps -> `bias` buffer
+        case 14: launch8<OT, 5, 4, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: LDS-DMA stream alone (no ds_read, no MFMA)
+        case 15: launch8<OT, 5, 5, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: ds_reads + MFMA alone (no LDS-DMA in the loop)
         default: throw std::runtime_error("gemm_bt8: unknown variant");
     }
 }
@@ -482,6 +485,7 @@ static void launch8_variant(const GemmParams& p, int variant, hipStream_t st) {
 void launch_gemm_bt8(const GemmParams& p, int operand_dtype, int variant, hipStream_t st) {
     if (p.N % 8 || p.ldc % 8 || ((uintptr_t)p.C & 15) || (p.bias && ((uintptr_t)p.bias & 15)))
         throw std::runtime_error("gemm_bt8: N and ldc must be multiples of 8 and C/bias 16-byte aligned");
+    if (p.kw > 0 && (p.kw % 64 || p.K != 2 * p.kw)) throw std::runtime_error("gemm_bt8: split-operand mode needs K == 2 * kw");
     if (p.epi == EPI_ROPE_OP && (!p.rope_cs || p.rope_hd % 16 || p.rope_cols % 256 || p.rope_cols % p.rope_hd || ((uintptr_t)p.rope_cs & 15)))
         throw std::runtime_error("gemm_bt8: bad RoPE epilogue parameters");
     if (operand_dtype == DT_F16) launch8_variant<F16>(p, variant, st);

@@ -16,11 +16,12 @@ void launch_attention(const AttnParams& p, int batch, int head_dim, bool causal,
 
 // rowops.hip ------------------------------------------------------------------------------------
 // y_op[r][:] = LN(x[r][:]) * w + b   (b == null -> RMSNorm: x * rsqrt(mean x^2 + eps) * w)
+// prec = 1 (every operand producer below): split-operand mode, rows are stored [hi | lo], twice as wide (common.h split2)
 void launch_norm_rows(const float* x, const float* w, const float* b, void* y, int rows, int H, float eps,
-                      int operand_dtype, hipStream_t st);
+                      int operand_dtype, hipStream_t st, int prec = 0, int group = 1);   // group g: g consecutive rows form one output row
 // pixels [B, C, 3, img, img] (fp32/bf16) -> patch matrix [ncrop*g*g, Kpad] operand dtype; crop_src[i] = b*C + c
 void launch_im2col(const void* pixels, int pix_dtype, const int* crop_src, int ncrop, int img, int patch, int Kpad,
-                   void* out, int operand_dtype, hipStream_t st);
+                   void* out, int operand_dtype, hipStream_t st, int prec = 0);
 // x[crop*T + t] = pre_LN( (t ? patch_out[crop*(T-1) + t-1] : cls) + pos[t] )
 void launch_clip_embed(const float* patch_out, const float* cls, const float* pos, const float* lnw, const float* lnb,
                        float* x, int ncrop, int T, int H, float eps, hipStream_t st);
@@ -38,15 +39,15 @@ void launch_rope_table(const int* pos, const int* tstat, int B, int S, const flo
                        const float* inv_freq_long, float scaling, int orig_max_pos, int half, float* cs, hipStream_t st);
 // qkv32 [rows, 3D] fp32 -> qkv operand dtype with RoPE applied to q and k heads (pair-interleaved head dims)
 void launch_rope_split(const float* qkv32, const float* cs, void* out, int rows, int rope_cols, int v_cols, int hd,
-                       int operand_dtype, hipStream_t st);
+                       int operand_dtype, hipStream_t st, int prec = 0);
 // HD transform gather (modeling_phi3_v.py:254-362): rows of [sum V, 4H] from CLIP features x [ncrop*T, H]
 struct HdSample { int hc, wc, crop0, voff; };
 void launch_hd_gather(const float* clipx, const HdSample* samples, int B, int total_rows, int T, int H,
-                      const float* sub_gn, const float* glb_gn, void* out, int operand_dtype, hipStream_t st);
+                      const float* sub_gn, const float* glb_gn, void* out, int operand_dtype, hipStream_t st, int prec = 0);
 
 // LLaVA-1.6 (modeling_llava_next.py get_image_features / pack_image_features) -------------------
 // patch tokens of every crop (CLS dropped) as GEMM operand rows: out[crop*(T-1) + t] = clipx[crop*T + 1 + t]
-void launch_clip_tokens(const float* clipx, void* out, int ncrop, int T, int H, int operand_dtype, hipStream_t st);
+void launch_clip_tokens(const float* clipx, void* out, int ncrop, int T, int H, int operand_dtype, hipStream_t st, int prec = 0);
 struct LlavaSample { int gh, gw, r0, r1, c0, c1, crop0, voff; };
 // ev rows of sample b: [base crop tokens; rows r0..r1 x cols c0..c1 of the hi-res grid, image_newline after each row]
 void launch_llava_pack(const float* proj, const LlavaSample* samples, int B, int total_rows, int g, int D,
@@ -55,7 +56,7 @@ void launch_llava_pack(const float* proj, const LlavaSample* samples, int B, int
 // Qwen2.5-VL (rowops_qwen.hip; transformers modeling_qwen2_5_vl.py) -------------------------------
 // GEMM operand rows of the patch embedding: out[i] = pixels[src[i]][0..K) zero-padded to Kpad (window order)
 void launch_qwen_patch_gather(const void* pixels, int pix_dtype, const int* src, int rows, int K, int Kpad, void* out,
-                              int operand_dtype, hipStream_t st);
+                              int operand_dtype, hipStream_t st, int prec = 0);
 // ViT 2-D rotary table cs[row][half_pad][2]: pair k < quarter rotates by h*inv[k], k < 2*quarter by w*inv[k-quarter], else (1,0)
 void launch_vit_rope_table(const int2* hw, int rows, const float* inv_freq, int quarter, int half_pad, float* cs, hipStream_t st);
 // get_rope_index (still images): rstat[b] = {image runs, tokens == ca_token, 0, 0}; pos3 [3][B*S]; img_row = merger row or -1.

@@ -169,12 +169,13 @@ void finalize_qwen(lr_engine* h) {
     const size_t B = d.max_batch, S = d.max_seq, P = d.max_patches, D = d.hidden, I = d.intermediate;
     const size_t PAD = 256, Rv = P + PAD, Rm = P / h->vunit + PAD, Rl = B * S + PAD;
     auto W = [&](size_t bytes) { return h->dalloc(bytes, false); };
-    h->vA = W(Rv * h->vKpad * 2); h->vx = (float*)W(Rv * h->vH * 4); h->vhn = W(Rv * h->vH * 2);
-    h->vqkv = W(Rv * 3 * h->vHp * 2); h->vqkv32 = (float*)W(Rv * 3 * h->vHp * 4); h->vatt = W(Rv * h->vHp * 2);
-    h->vff = W(Rv * h->vIp * 2); h->vcs = (float*)W(Rv * h->vhdp * 4); h->vm1 = W(Rm * h->vHm * 2);
+    const size_t ob = 2 * (size_t)(1 + h->prec);      // bytes per operand element (hi [+ lo])
+    h->vA = W(Rv * h->vKpad * ob); h->vx = (float*)W(Rv * h->vH * 4); h->vhn = W(Rv * h->vH * ob);
+    h->vqkv = W(Rv * 3 * h->vHp * ob); h->vqkv32 = (float*)W(Rv * 3 * h->vHp * 4); h->vatt = W(Rv * h->vHp * ob);
+    h->vff = W(Rv * h->vIp * ob); h->vcs = (float*)W(Rv * h->vhdp * 4); h->vm1 = W(Rm * h->vHm * ob);
     h->ev = (float*)W(Rm * D * 4);
-    h->x = (float*)W(Rl * D * 4); h->h = W(Rl * D * 2); h->qkv32 = (float*)W(Rl * h->Nqkv * 4); h->qkv = W(Rl * h->Nqkv * 2);
-    h->att = W(Rl * h->Hq * 2); h->ff = W(Rl * I * 2); h->cs = (float*)W(Rl * h->hd * 4);
+    h->x = (float*)W(Rl * D * 4); h->h = W(Rl * D * ob); h->qkv32 = (float*)W(Rl * h->Nqkv * 4); h->qkv = W(Rl * h->Nqkv * ob);
+    h->att = W(Rl * h->Hq * ob); h->ff = W(Rl * I * ob); h->cs = (float*)W(Rl * h->hd * 4);
     h->pos_ids = (int*)W(Rl * 4); h->img_row = (int*)W(Rl * 4); h->pos3 = (int*)W(3 * Rl * 4);
     h->tstat = (int*)W(B * 16); h->rstat = (int*)W(B * 16);
     h->hL = (float*)W(B * D * 4); h->tao = (float*)W(B * D * 4);
@@ -287,7 +288,7 @@ extern "C" int lr_forward_qwen(lr_handle h, const int64_t* input_ids, const int6
         h->lastB = B; h->lastS = S; h->lastP = N; h->lastSV = M;
 
         // ---- ViT (Qwen2_5_VisionTransformerPretrainedModel.forward), window order throughout ----
-        launch_qwen_patch_gather(pixel_values, pix_dtype == LR_DT_F32 ? DT_F32 : DT_BF16, d_src, N, h->vK, h->vKpad, h->vA, h->op_dt, st);
+        launch_qwen_patch_gather(pixel_values, pix_dtype == LR_DT_F32 ? DT_F32 : DT_BF16, d_src, N, h->vK, h->vKpad, h->vA, h->op_dt, st, h->prec);
         gemm(h, st, h->vA, h->vpatch_w, h->vx, nullptr, N, vH, h->vKpad, h->vKpad, h->vKpad, vH, EPI_OUT_F32, ACT_NONE);
         launch_vit_rope_table(d_hw, N, h->vinv, h->vhd / 4, vhdp / 2, h->vcs, st);
         const int nvl = h->lim_clip >= 0 && h->lim_clip < d.vit_depth ? h->lim_clip : d.vit_depth;
@@ -296,26 +297,28 @@ extern "C" int lr_forward_qwen(lr_handle h, const int64_t* input_ids, const int6
             const VitLayer& L = h->vl[l];
             bool full = false;
             for (int i = 0; i < d.vit_n_fullatt; ++i) full = full || d.vit_fullatt[i] == l;
-            launch_norm_rows(h->vx, L.n1, nullptr, h->vhn, N, vH, d.vit_eps, h->op_dt, st);
+            launch_norm_rows(h->vx, L.n1, nullptr, h->vhn, N, vH, d.vit_eps, h->op_dt, st, h->prec);
             {
                 GemmParams gp{h->vhn, L.qkv_w, h->vqkv, L.qkv_b, N, 3 * vHp, vH, vH, vH, 3 * vHp, EPI_ROPE_OP, ACT_NONE, h->vcs, 2 * vHp, vhdp};
+                apply_prec(h, gp);
                 if ((2 * vHp) % 256 == 0 && gemm_bt_is_deep(gp, h->gemm_tile)) {
                     launch_gemm_bt(gp, h->op_dt, h->gemm_tile, st);
                 } else {
                     gemm(h, st, h->vhn, L.qkv_w, h->vqkv32, L.qkv_b, N, 3 * vHp, vH, vH, vH, 3 * vHp, EPI_OUT_F32, ACT_NONE);
-                    launch_rope_split(h->vqkv32, h->vcs, h->vqkv, N, 2 * vHp, vHp, vhdp, h->op_dt, st);
+                    launch_rope_split(h->vqkv32, h->vcs, h->vqkv, N, 2 * vHp, vHp, vhdp, h->op_dt, st, h->prec);
                 }
             }
             AttnParams ap{h->vqkv, h->vqkv, h->vqkv, h->vatt, nullptr, nullptr, 0, 3 * vHp, vHp, 0, vHp, 2 * vHp, max_seg, d.vit_heads,
                           vscale, 1, full ? d_items_full : d_items_win, full ? nfull : nwin};
+            apply_prec(h, ap);
             launch_attention(ap, 1, vhdp, false, h->op_dt, st);
             gemm(h, st, h->vatt, L.proj_w, h->vx, L.proj_b, N, vH, vHp, vHp, vHp, vH, EPI_RESADD_F32, ACT_NONE);
-            launch_norm_rows(h->vx, L.n2, nullptr, h->vhn, N, vH, d.vit_eps, h->op_dt, st);
+            launch_norm_rows(h->vx, L.n2, nullptr, h->vhn, N, vH, d.vit_eps, h->op_dt, st, h->prec);
             gemm(h, st, h->vhn, L.gu_w, h->vff, L.gu_b, N, 2 * vIp, vH, vH, vH, vIp, EPI_SWIGLU_OP, ACT_NONE);
             gemm(h, st, h->vff, L.down_w, h->vx, L.down_b, N, vH, vIp, vIp, vIp, vH, EPI_RESADD_F32, ACT_NONE);
         }
         // ---- merger (Qwen2_5_VLPatchMerger): RMSNorm, 4 consecutive rows = one LLM token, Linear-GELU-Linear ----
-        launch_norm_rows(h->vx, h->vlnq, nullptr, h->vhn, N, vH, 1e-6f, h->op_dt, st);
+        launch_norm_rows(h->vx, h->vlnq, nullptr, h->vhn, N, vH, 1e-6f, h->op_dt, st, h->prec, unit);     // rows of one merged token side by side
         gemm(h, st, h->vhn, h->m0_w, h->vm1, h->m0_b, M, vHm, vHm, vHm, vHm, vHm, EPI_OUT_OP, ACT_GELU_ERF);
         gemm(h, st, h->vm1, h->m2_w, h->ev, h->m2_b, M, D, vHm, vHm, vHm, D, EPI_OUT_F32, ACT_NONE);
 

@@ -15,6 +15,17 @@ template <typename OT> __device__ __forceinline__ void store4(void* base, size_t
     *(uint2*)((unsigned short*)base + elem) = w;
 }
 
+// split-operand mode (prec = 1): an operand row of width W is stored 2W wide, [hi | lo] (common.h split2)
+template <typename OT> __device__ __forceinline__ void store4s(void* base, size_t row, int W, int prec, int col, float a, float b,
+                                                               float c, float d) {
+    unsigned short* dst = (unsigned short*)base + row * (size_t)(W << prec) + col;
+    uint2 h, l;
+    split2<OT>(a, b, h.x, l.x);
+    split2<OT>(c, d, h.y, l.y);
+    *(uint2*)dst = h;
+    if (prec) *(uint2*)(dst + W) = l;
+}
+
 // ------------------------------------------------------------------------------------------ norms
 // modeling_phi3_v.py:377-391 (RMSNorm: w * (x * rsqrt(mean(x^2) + eps))) and CLIP LayerNorm.
 constexpr int NORM_MAXC = 16;   // H <= 4096
@@ -22,7 +33,7 @@ constexpr int NORM_MAXC = 16;   // H <= 4096
 template <typename OT, bool LAYERNORM>
 __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, void* __restrict__ y, int rows,
-                                                        int H, float eps) {
+                                                        int H, float eps, int prec, int group) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -68,23 +79,24 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
                 const float4 bb = ((const float4*)b)[c];
                 o0 += bb.x; o1 += bb.y; o2 += bb.z; o3 += bb.w;
             }
-            store4<OT>(y, (size_t)row * H + 4 * c, o0, o1, o2, o3);
+            store4s<OT>(y, row / group, H * group, prec, (row % group) * H + 4 * c, o0, o1, o2, o3);
         }
     }
 }
 
 void launch_norm_rows(const float* x, const float* w, const float* b, void* y, int rows, int H, float eps,
-                      int operand_dtype, hipStream_t st) {
+                      int operand_dtype, hipStream_t st, int prec, int group) {
     if (rows <= 0) return;
+    if (group < 1 || rows % group) throw std::runtime_error("norm_rows: rows must be a multiple of group");
     if (H % 4 || H > NORM_MAXC * 256) throw std::runtime_error("norm_rows: H must be a multiple of 4 and <= 4096");
     dim3 g(cdiv(rows, 4)), t(256);
     const bool f16 = operand_dtype == DT_F16;
     if (b) {
-        if (f16) hipLaunchKernelGGL((norm_rows_kernel<F16, true>), g, t, 0, st, x, w, b, y, rows, H, eps);
-        else hipLaunchKernelGGL((norm_rows_kernel<BF16, true>), g, t, 0, st, x, w, b, y, rows, H, eps);
+        if (f16) hipLaunchKernelGGL((norm_rows_kernel<F16, true>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group);
+        else hipLaunchKernelGGL((norm_rows_kernel<BF16, true>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group);
     } else {
-        if (f16) hipLaunchKernelGGL((norm_rows_kernel<F16, false>), g, t, 0, st, x, w, b, y, rows, H, eps);
-        else hipLaunchKernelGGL((norm_rows_kernel<BF16, false>), g, t, 0, st, x, w, b, y, rows, H, eps);
+        if (f16) hipLaunchKernelGGL((norm_rows_kernel<F16, false>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group);
+        else hipLaunchKernelGGL((norm_rows_kernel<BF16, false>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group);
     }
 }
 
@@ -93,12 +105,13 @@ void launch_norm_rows(const float* x, const float* w, const float* b, void* y, i
 // padded to Kpad.  One block per (crop, py): reads p pixel rows of each channel, writes g patch rows.
 template <typename OT, typename PT>
 __global__ __launch_bounds__(256) void im2col_kernel(const PT* __restrict__ pix, const int* __restrict__ crop_src,
-                                                     int img, int patch, int Kpad, void* __restrict__ out) {
+                                                     int img, int patch, int Kpad, void* __restrict__ out, int prec) {
     const int g = img / patch;
     const int crop = blockIdx.x / g, py = blockIdx.x % g;
     const PT* src = pix + (size_t)crop_src[crop] * 3 * img * img;
     const int K = 3 * patch * patch;
-    unsigned short* dst = (unsigned short*)out + ((size_t)crop * g * g + (size_t)py * g) * Kpad;
+    const int ld = Kpad << prec;
+    unsigned short* dst = (unsigned short*)out + ((size_t)crop * g * g + (size_t)py * g) * ld;
     for (int idx = threadIdx.x; idx < g * Kpad; idx += 256) {
         const int px = idx / Kpad, k = idx - px * Kpad;
         float v = 0.f;
@@ -107,21 +120,23 @@ __global__ __launch_bounds__(256) void im2col_kernel(const PT* __restrict__ pix,
             const int ky = rem / patch, kx = rem - ky * patch;
             v = (float)src[((size_t)c * img + (py * patch + ky)) * img + px * patch + kx];
         }
-        dst[idx] = Op<OT>::from_f32(v);
+        const unsigned short hv = Op<OT>::from_f32(v);
+        dst[(size_t)px * ld + k] = hv;
+        if (prec) dst[(size_t)px * ld + Kpad + k] = Op<OT>::from_f32(v - Op<OT>::to_f32(hv));
     }
 }
 
 void launch_im2col(const void* pixels, int pix_dtype, const int* crop_src, int ncrop, int img, int patch, int Kpad,
-                   void* out, int operand_dtype, hipStream_t st) {
+                   void* out, int operand_dtype, hipStream_t st, int prec) {
     if (ncrop <= 0) return;
     dim3 g(ncrop * (img / patch)), t(256);
     const bool f16 = operand_dtype == DT_F16;
     if (pix_dtype == DT_F32) {
-        if (f16) hipLaunchKernelGGL((im2col_kernel<F16, float>), g, t, 0, st, (const float*)pixels, crop_src, img, patch, Kpad, out);
-        else hipLaunchKernelGGL((im2col_kernel<BF16, float>), g, t, 0, st, (const float*)pixels, crop_src, img, patch, Kpad, out);
+        if (f16) hipLaunchKernelGGL((im2col_kernel<F16, float>), g, t, 0, st, (const float*)pixels, crop_src, img, patch, Kpad, out, prec);
+        else hipLaunchKernelGGL((im2col_kernel<BF16, float>), g, t, 0, st, (const float*)pixels, crop_src, img, patch, Kpad, out, prec);
     } else if (pix_dtype == DT_BF16) {
-        if (f16) hipLaunchKernelGGL((im2col_kernel<F16, __bf16>), g, t, 0, st, (const __bf16*)pixels, crop_src, img, patch, Kpad, out);
-        else hipLaunchKernelGGL((im2col_kernel<BF16, __bf16>), g, t, 0, st, (const __bf16*)pixels, crop_src, img, patch, Kpad, out);
+        if (f16) hipLaunchKernelGGL((im2col_kernel<F16, __bf16>), g, t, 0, st, (const __bf16*)pixels, crop_src, img, patch, Kpad, out, prec);
+        else hipLaunchKernelGGL((im2col_kernel<BF16, __bf16>), g, t, 0, st, (const __bf16*)pixels, crop_src, img, patch, Kpad, out, prec);
     } else {
         throw std::runtime_error("im2col: pixel dtype must be f32 or bf16");
     }
@@ -302,7 +317,7 @@ void launch_rope_table(const int* pos, const int* tstat, int B, int S, const flo
 // Fallback path for problems too small for the GEMM with the fused RoPE epilogue.
 template <typename OT>
 __global__ __launch_bounds__(256) void rope_split_kernel(const float* __restrict__ qkv, const float* __restrict__ cs,
-                                                         void* __restrict__ out, int rope_cols, int v_cols, int hd) {
+                                                         void* __restrict__ out, int rope_cols, int v_cols, int hd, int prec) {
     const int row = blockIdx.x;
     const int half = hd >> 1, ld = rope_cols + v_cols;
     const float* src = qkv + (size_t)row * ld;
@@ -312,21 +327,21 @@ __global__ __launch_bounds__(256) void rope_split_kernel(const float* __restrict
         const int i0 = (col % hd) >> 1;
         const float4 x = *(const float4*)(src + col);
         const float4 c = t[i0 >> 1];
-        store4<OT>(out, (size_t)row * ld + col, x.x * c.x - x.y * c.y, x.y * c.x + x.x * c.y,
-                   x.z * c.z - x.w * c.w, x.w * c.z + x.z * c.w);
+        store4s<OT>(out, row, ld, prec, col, x.x * c.x - x.y * c.y, x.y * c.x + x.x * c.y,
+                    x.z * c.z - x.w * c.w, x.w * c.z + x.z * c.w);
     }
     for (int c = threadIdx.x; c < (v_cols >> 2); c += 256) {
         const float4 v = *(const float4*)(src + rope_cols + 4 * c);
-        store4<OT>(out, (size_t)row * ld + rope_cols + 4 * c, v.x, v.y, v.z, v.w);
+        store4s<OT>(out, row, ld, prec, rope_cols + 4 * c, v.x, v.y, v.z, v.w);
     }
 }
 
 void launch_rope_split(const float* qkv32, const float* cs, void* out, int rows, int rope_cols, int v_cols, int hd,
-                       int operand_dtype, hipStream_t st) {
+                       int operand_dtype, hipStream_t st, int prec) {
     if (rows <= 0) return;
     if (hd % 8 || rope_cols % hd || v_cols % 4) throw std::runtime_error("rope_split: bad geometry");
-    if (operand_dtype == DT_F16) hipLaunchKernelGGL((rope_split_kernel<F16>), dim3(rows), dim3(256), 0, st, qkv32, cs, out, rope_cols, v_cols, hd);
-    else hipLaunchKernelGGL((rope_split_kernel<BF16>), dim3(rows), dim3(256), 0, st, qkv32, cs, out, rope_cols, v_cols, hd);
+    if (operand_dtype == DT_F16) hipLaunchKernelGGL((rope_split_kernel<F16>), dim3(rows), dim3(256), 0, st, qkv32, cs, out, rope_cols, v_cols, hd, prec);
+    else hipLaunchKernelGGL((rope_split_kernel<BF16>), dim3(rows), dim3(256), 0, st, qkv32, cs, out, rope_cols, v_cols, hd, prec);
 }
 
 // ------------------------------------------------------------------------------------- HD gather
@@ -337,7 +352,7 @@ template <typename OT>
 __global__ __launch_bounds__(256) void hd_gather_kernel(const float* __restrict__ clipx, const HdSample* __restrict__ smp,
                                                         int B, int total_rows, int T, int H, int g,
                                                         const float* __restrict__ sub_gn, const float* __restrict__ glb_gn,
-                                                        void* __restrict__ out) {
+                                                        void* __restrict__ out, int prec) {
     const int R = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (R >= total_rows) return;
@@ -371,23 +386,23 @@ __global__ __launch_bounds__(256) void hd_gather_kernel(const float* __restrict_
             const int t = 1 + (2 * pi + (blk >> 1)) * g + (2 * pj + (blk & 1));
             v = *(const float4*)(clipx + ((size_t)crop * T + t) * H + within);
         }
-        store4<OT>(out, (size_t)R * 4 * H + 4 * c, v.x, v.y, v.z, v.w);
+        store4s<OT>(out, R, 4 * H, prec, 4 * c, v.x, v.y, v.z, v.w);
     }
 }
 
 void launch_hd_gather(const float* clipx, const HdSample* samples, int B, int total_rows, int T, int H,
-                      const float* sub_gn, const float* glb_gn, void* out, int operand_dtype, hipStream_t st) {
+                      const float* sub_gn, const float* glb_gn, void* out, int operand_dtype, hipStream_t st, int prec) {
     if (total_rows <= 0) return;
     int g = 1;
     while (g * g + 1 < T) ++g;
     dim3 gr(cdiv(total_rows, 4)), t(256);
-    if (operand_dtype == DT_F16) hipLaunchKernelGGL((hd_gather_kernel<F16>), gr, t, 0, st, clipx, samples, B, total_rows, T, H, g, sub_gn, glb_gn, out);
-    else hipLaunchKernelGGL((hd_gather_kernel<BF16>), gr, t, 0, st, clipx, samples, B, total_rows, T, H, g, sub_gn, glb_gn, out);
+    if (operand_dtype == DT_F16) hipLaunchKernelGGL((hd_gather_kernel<F16>), gr, t, 0, st, clipx, samples, B, total_rows, T, H, g, sub_gn, glb_gn, out, prec);
+    else hipLaunchKernelGGL((hd_gather_kernel<BF16>), gr, t, 0, st, clipx, samples, B, total_rows, T, H, g, sub_gn, glb_gn, out, prec);
 }
 
 // ------------------------------------------------------------------------------------------ LLaVA
 template <typename OT>
-__global__ __launch_bounds__(256) void clip_tokens_kernel(const float* __restrict__ clipx, void* __restrict__ out, int rows, int T, int H) {
+__global__ __launch_bounds__(256) void clip_tokens_kernel(const float* __restrict__ clipx, void* __restrict__ out, int rows, int T, int H, int prec) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -395,15 +410,15 @@ __global__ __launch_bounds__(256) void clip_tokens_kernel(const float* __restric
     const float4* src = (const float4*)(clipx + ((size_t)crop * T + 1 + t) * H);
     for (int c = lane; c < (H >> 2); c += 64) {
         const float4 v = src[c];
-        store4<OT>(out, (size_t)row * H + 4 * c, v.x, v.y, v.z, v.w);
+        store4s<OT>(out, row, H, prec, 4 * c, v.x, v.y, v.z, v.w);
     }
 }
 
-void launch_clip_tokens(const float* clipx, void* out, int ncrop, int T, int H, int operand_dtype, hipStream_t st) {
+void launch_clip_tokens(const float* clipx, void* out, int ncrop, int T, int H, int operand_dtype, hipStream_t st, int prec) {
     const int rows = ncrop * (T - 1);
     if (rows <= 0) return;
-    if (operand_dtype == DT_F16) hipLaunchKernelGGL((clip_tokens_kernel<F16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, clipx, out, rows, T, H);
-    else hipLaunchKernelGGL((clip_tokens_kernel<BF16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, clipx, out, rows, T, H);
+    if (operand_dtype == DT_F16) hipLaunchKernelGGL((clip_tokens_kernel<F16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, clipx, out, rows, T, H, prec);
+    else hipLaunchKernelGGL((clip_tokens_kernel<BF16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, clipx, out, rows, T, H, prec);
 }
 
 // modeling_llava_next.py:265-335 pack_image_features ("spatial_unpad"): per image [base crop; un-padded grid + newline column]

@@ -8,20 +8,13 @@ namespace lr {
 
 static inline int cdivq(long a, int b) { return (int)((a + b - 1) / b); }
 
-template <typename OT> __device__ __forceinline__ void store4q(void* out, size_t idx, float a, float b, float c, float d) {
-    uint2 w;
-    w.x = pack2<OT>(a, b);
-    w.y = pack2<OT>(c, d);
-    *(uint2*)((unsigned short*)out + idx) = w;
-}
-
 // ------------------------------------------------------------------------------- patch gather
 // Qwen2_5_VisionPatchEmbed is a conv3d whose kernel equals its stride: a linear map over the 1176 values of a patch.
 // Row i of the GEMM operand = patch src[i] (window order, Qwen2_5_VisionTransformerPretrainedModel.forward
 // `hidden_states[window_index]`; the permutation commutes with the per-row linear map), zero-padded to Kpad.
 template <typename OT, typename PT>
 __global__ __launch_bounds__(256) void qwen_patch_gather_kernel(const PT* __restrict__ pix, const int* __restrict__ src, int K,
-                                                                int Kpad, void* __restrict__ out) {
+                                                                int Kpad, void* __restrict__ out, int prec) {
     const int row = blockIdx.x;
     const PT* p = pix + (size_t)src[row] * K;
     for (int c = threadIdx.x * 4; c < Kpad; c += 1024) {
@@ -35,21 +28,26 @@ __global__ __launch_bounds__(256) void qwen_patch_gather_kernel(const PT* __rest
             }
             v[e] = x;
         }
-        store4q<OT>(out, (size_t)row * Kpad + c, v[0], v[1], v[2], v[3]);
+        unsigned short* dst = (unsigned short*)out + (size_t)row * (Kpad << prec) + c;
+        uint2 h, l;
+        split2<OT>(v[0], v[1], h.x, l.x);
+        split2<OT>(v[2], v[3], h.y, l.y);
+        *(uint2*)dst = h;
+        if (prec) *(uint2*)(dst + Kpad) = l;
     }
 }
 
 void launch_qwen_patch_gather(const void* pixels, int pix_dtype, const int* src, int rows, int K, int Kpad, void* out,
-                              int operand_dtype, hipStream_t st) {
+                              int operand_dtype, hipStream_t st, int prec) {
     if (rows <= 0) return;
     if (Kpad % 4 || Kpad < K) throw std::runtime_error("qwen_patch_gather: bad padding");
     const bool f16 = operand_dtype == DT_F16;
     if (pix_dtype == DT_F32) {
-        if (f16) hipLaunchKernelGGL((qwen_patch_gather_kernel<F16, float>), dim3(rows), dim3(256), 0, st, (const float*)pixels, src, K, Kpad, out);
-        else hipLaunchKernelGGL((qwen_patch_gather_kernel<BF16, float>), dim3(rows), dim3(256), 0, st, (const float*)pixels, src, K, Kpad, out);
+        if (f16) hipLaunchKernelGGL((qwen_patch_gather_kernel<F16, float>), dim3(rows), dim3(256), 0, st, (const float*)pixels, src, K, Kpad, out, prec);
+        else hipLaunchKernelGGL((qwen_patch_gather_kernel<BF16, float>), dim3(rows), dim3(256), 0, st, (const float*)pixels, src, K, Kpad, out, prec);
     } else if (pix_dtype == DT_BF16) {
-        if (f16) hipLaunchKernelGGL((qwen_patch_gather_kernel<F16, unsigned short>), dim3(rows), dim3(256), 0, st, (const unsigned short*)pixels, src, K, Kpad, out);
-        else hipLaunchKernelGGL((qwen_patch_gather_kernel<BF16, unsigned short>), dim3(rows), dim3(256), 0, st, (const unsigned short*)pixels, src, K, Kpad, out);
+        if (f16) hipLaunchKernelGGL((qwen_patch_gather_kernel<F16, unsigned short>), dim3(rows), dim3(256), 0, st, (const unsigned short*)pixels, src, K, Kpad, out, prec);
+        else hipLaunchKernelGGL((qwen_patch_gather_kernel<BF16, unsigned short>), dim3(rows), dim3(256), 0, st, (const unsigned short*)pixels, src, K, Kpad, out, prec);
     } else {
         throw std::runtime_error("qwen_patch_gather: pixel dtype must be f32 or bf16");
     }

@@ -43,6 +43,7 @@ class ModelDesc(C.Structure):
         ("vit_rope_theta", C.c_float), ("vit_eps", C.c_float),
         ("mrope_section", C.c_int32 * 3),
         ("ca_token_id", C.c_int32), ("max_patches", C.c_int32),
+        ("precise", C.c_int32),
     ]
 
 
