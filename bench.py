@@ -101,32 +101,73 @@ def qwen_flop_per_row(cfg, grid, S):
     return float(lin + att + patch + merger + dec + datt)
 
 
-def dominant_kernel_probe(dtype_code, tile, steps=5):
-    """HIP-event timing of the dominant kernel (gemm_bt at the gate_up shape) on the launch stream."""
+def dominant_kernel_probe(dtype_code, tile, steps=5, split=False):
+    """HIP-event timing of the dominant kernel (gemm_bt8 at the decoder gate_up shape, SwiGLU epilogue) on the launch stream.
+    split: the split-operand form the parity mode runs (A = [A_hi | A_lo], output [hi | lo]): twice the MFMA work for the
+    same algorithmic FLOPs."""
     import ctypes as C
     from llava_reward_amd import _lib as L
     lib = L.load()
     M, N, K = 32 * 2643, 16384, 3072
     tdt = torch.float16 if dtype_code == L.LR_DT_F16 else torch.bfloat16
+    w = 2 if split else 1
     A = (torch.randn(M, K, device="cuda") * 1.0).to(tdt)
+    if split:
+        A = torch.cat([A, (torch.randn(M, K, device="cuda") * 2.0 ** -12).to(tdt)], dim=1).contiguous()     # [hi | lo]
     W = (torch.randn(N, K, device="cuda") * 0.02).to(tdt)
-    out = torch.empty(M, N // 2, device="cuda", dtype=tdt)
+    out = torch.empty(M, w * N // 2, device="cuda", dtype=tdt)
     st = torch.cuda.current_stream()
-    args = (C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(0), M, N, K, K, K, N // 2,
-            L.EPI_SWIGLU_OP, 0, dtype_code, tile, C.c_void_p(st.cuda_stream))
-    lib.lr_op_gemm_bt(*args)
+    if split:
+        fn, args = lib.lr_op_gemm_bt_split, (C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(0),
+                                             M, N, K, L.EPI_SWIGLU_OP, 0, dtype_code, tile, C.c_void_p(st.cuda_stream))
+    else:
+        fn, args = lib.lr_op_gemm_bt, (C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(0),
+                                       M, N, K, K, K, N // 2, L.EPI_SWIGLU_OP, 0, dtype_code, tile, C.c_void_p(st.cuda_stream))
+    assert fn(*args) == 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(st)
+    e0.record(st)                    # torch's current stream IS the stream the kernel is launched on
     for _ in range(steps):
-        lib.lr_op_gemm_bt(*args)
+        fn(*args)
     e1.record(st)
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    return {"kernel": "gemm_bt8_kernel (gate_up + SwiGLU epilogue)", "shape": [M, N, K], "avg_ms": ms,
-            "tflops": 2.0 * M * N * K / (ms * 1e-3) / 1e12,
-            # PMC passes of this exact launch (profiles/r1_pmc_gemm_gate_up.md): FETCH_SIZE x2 (gfx950) + WRITE_SIZE
-            "traffic_bytes_pmc": 15.2e9, "algorithmic_bytes": 2.0 * (M * K + N * K + M * N // 2),
-            "mfma_busy_frac_pmc": 0.598, "effective_clock_ghz_pmc": 1.81}
+    # PMC passes of these exact launches (profiles/r1_pmc_gemm_gate_up.md): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE
+    pmc = {"traffic": 29.7e9, "mfma_busy": 0.595, "clock_ghz": 1.81} if split else {"traffic": 15.2e9, "mfma_busy": 0.598, "clock_ghz": 1.81}
+    return {"kernel": "gemm_bt8_kernel<SwiGLU> decoder gate_up" + (", split-operand form" if split else ""), "shape": [M, N, K],
+            "avg_ms": ms, "tflops": 2.0 * M * N * K / (ms * 1e-3) / 1e12, "mfma_work_factor": w,
+            "algorithmic_bytes": 2.0 * (w * M * K + N * K + w * M * N // 2), "traffic_bytes_pmc": pmc["traffic"],
+            "mfma_busy_frac_pmc": pmc["mfma_busy"], "effective_clock_ghz_pmc": pmc["clock_ghz"]}
+
+
+def golden_check(model, model_name):
+    """Score the committed full-size golden row of this backbone (produced by the REFERENCE itself, tests/golden/make_goldens.py)
+    with the engine that was just timed -- same synthetic weights (seed 1234) -- and report |reward - reference|."""
+    name = {"phi3v": "ref_full_bt_ca", "llava": "ref_llava_full_bt", "qwen": "ref_qwen_full_bt"}[model_name]
+    path = os.path.join(ROOT, "tests", "golden", name + ".json")
+    if not os.path.exists(path):
+        return None
+    from llava_reward_amd import synth
+    g = json.load(open(path))
+    if g["seed"] != 1234:
+        return None
+    if model_name == "qwen":
+        cfg = synth.QwenConfig.from_json(g["config"])
+        b = synth.qwen_synth_batch(cfg, g["seed"], g["caption_lens"], [tuple(x) for x in g["grids"]])
+    elif model_name == "llava":
+        cfg = synth.LlavaConfig.from_json(g["config"])
+        b = synth.llava_synth_batch(cfg, g["seed"], g["caption_lens"], [tuple(x) for x in g["image_sizes"]], max_crops=g["max_crops"])
+    else:
+        cfg = synth.RewardConfig.from_json(g["config"])
+        b = synth.synth_batch(cfg, g["seed"], g["caption_lens"], tuple(g["grids"]), max_crops=g["max_crops"])
+    tb = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+    if model_name == "phi3v":
+        r, _ = model.custom_forward(tb["input_ids"], tb["attention_mask"], tb["pixel_values"], tb["image_sizes"])
+    else:
+        r, _ = model.custom_forward(inputs_batch=tb)
+    torch.cuda.synchronize()
+    ref = torch.tensor(g["reward"], dtype=torch.float32)
+    return {"golden": name + ".json (reference fp32 CPU custom_forward)", "reference_reward": ref.flatten().tolist(),
+            "reward": r.cpu().flatten().tolist(), "abs_err": (r.cpu().reshape(ref.shape) - ref).abs().max().item(), "tolerance": 1e-3}
 
 
 def main():
@@ -135,7 +176,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=32, help="rows per GPU")
-    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f16x2", "bf16x2"], help="MFMA operand type; x2 = split-operand (parity) mode")
+    ap.add_argument("--dtype", default="f16x2", choices=["f16x2", "f16", "bf16", "bf16x2"],
+                    help="MFMA operands: f16x2 = split-operand parity mode (default, rewards within 1e-3 of the fp32 reference); "
+                         "f16 / bf16 = single-pass fast modes (noise-limited, DESIGN.md §4)")
+    ap.add_argument("--no-fast-mode", action="store_true", help="skip the secondary single-pass f16 measurement")
     ap.add_argument("--tile", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="phi3v", choices=["phi3v", "llava", "qwen"],
@@ -187,20 +231,41 @@ def main():
     S = gb["input_ids"].shape[1]
     ids = torch.from_numpy(gb["input_ids"][rows]).cuda()
     mask = torch.from_numpy(gb["attention_mask"][rows]).cuda()
+    precise = a.dtype.endswith("x2")
     if a.model == "qwen":
         sizes = torch.from_numpy(gb["image_grid_thw"][rows])
         pix = torch.randn(B * 32 * 32, cfg.vision.patch_dim, device="cuda", generator=gen)   # normalised pixel noise, fp32
-        model = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=S, max_patches=B * 32 * 32, operand_dtype=a.dtype)
     else:
         sizes = torch.from_numpy(gb["image_sizes"][rows])
         pix = torch.randn(B, ncrop, 3, 336, 336, device="cuda", generator=gen)      # CLIP-normalised pixel noise, fp32
-        model = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=S, max_crops=max(ncrop, 5 if a.model == 'llava' else 17), operand_dtype=a.dtype)
-    model = model.to(f"cuda:{local}").eval()
-    if a.tile >= 0:
-        model.engine.set_gemm_tile(a.tile)
+
+    def build_model(dtype):
+        if a.model == "qwen":
+            m = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=S, max_patches=B * 32 * 32, operand_dtype=dtype)
+        else:
+            m = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=S, max_crops=max(ncrop, 5 if a.model == 'llava' else 17), operand_dtype=dtype)
+        m = m.to(f"cuda:{local}").eval()
+        if a.tile >= 0:
+            m.engine.set_gemm_tile(a.tile)
+        return m
+
+    def run_forward(m):
+        return m.engine.forward_qwen(ids, mask, pix, sizes) if a.model == "qwen" else m.engine.forward(ids, mask, pix, sizes)
+
+    def timed_steps(fn, warmup, steps):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / steps
+
+    model = build_model(a.dtype)
 
     def step():
-        r = model.engine.forward_qwen(ids, mask, pix, sizes) if a.model == "qwen" else model.engine.forward(ids, mask, pix, sizes)
+        r = run_forward(model)
         if world == 1:
             return r
         if a.backend != "nccl":               # gloo smoke path: collectives on host tensors
@@ -241,13 +306,32 @@ def main():
                        "collective": "all_gather rewards [B,1] fp32" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "achieved": tf_per_gpu, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf_per_gpu / PEAK_TFLOPS, "traffic": None,
-                         "note": "whole pass: pairs/s x %.2f TFLOP algorithmic per pair, per GPU" % (flop_per_pair / 1e12)},
+                         "note": "whole pass: pairs/s x %.2f TFLOP ALGORITHMIC per pair, per GPU%s" % (
+                             flop_per_pair / 1e12, "; the split-operand mode executes 2x (linears) / 3x (attention) that MFMA work" if precise else "")},
         }
-        if world == 1 and a.model == "phi3v":
-            res["roofline"]["dominant_kernel"] = dominant_kernel_probe(L.LR_DT_F16 if a.dtype.startswith("f16") else L.LR_DT_BF16, a.tile)
-            if not a.no_cpu_baseline:
-                del model
+        if world == 1:
+            res["parity_check"] = golden_check(model, a.model)
+            if a.model == "phi3v":
+                dk = dominant_kernel_probe(L.LR_DT_F16 if a.dtype.startswith("f16") else L.LR_DT_BF16, a.tile, split=precise)
+                # the roofline object proper: the dominant kernel, algorithmic FLOPs per launch / its live HIP-event duration
+                res["roofline"].update({"achieved": dk["tflops"], "frac": dk["tflops"] / PEAK_TFLOPS, "traffic": dk["traffic_bytes_pmc"],
+                                        "kernel": dk["kernel"], "dominant_kernel": dk,
+                                        "whole_pass": {"achieved": tf_per_gpu, "frac": tf_per_gpu / PEAK_TFLOPS},
+                                        "note": res["roofline"]["note"] + "; achieved/frac/traffic = the dominant kernel (algorithmic FLOPs per launch / HIP-event "
+                                                "time; traffic = PMC bytes per launch, profiles/r1_pmc_gemm_gate_up.md); whole_pass = the same ratio for the step"})
+            del model
+            torch.cuda.empty_cache()
+            if precise and not a.no_fast_mode:
+                # secondary figure: the single-pass f16 mode of the same workload (noise-limited parity)
+                fm = build_model("f16")
+                ms = timed_steps(lambda: run_forward(fm), a.warmup, a.steps)
+                fv = B * a.steps / (ms * 1e-3 * a.steps)
+                res["fast_mode"] = {"dtype": "f16 single-pass MFMA operands", "value": fv, "unit": "reward-pairs/sec", "ms_per_step": ms,
+                                    "roofline_frac_whole_pass": fv * flop_per_pair / 1e12 / PEAK_TFLOPS,
+                                    "parity_check": golden_check(fm, a.model)}
+                del fm
                 torch.cuda.empty_cache()
+            if a.model == "phi3v" and not a.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -140,6 +140,10 @@ int lr_set_gemm_tile(lr_handle h, int tile);
 /* ---- single-kernel entry points (per-kernel parity tests and microbenchmarks) ---- */
 int lr_op_gemm_bt(const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int lda, int ldw,
                   int ldc, int epi, int act, int operand_dtype, int tile, void* hip_stream);
+/* Split-operand form (lr_model_desc.precise): A is [M, 2K] = [A_hi | A_lo] in the operand type, W stays [N, K]; operand-typed
+ * outputs (EPI_OUT_OP, EPI_SWIGLU_OP) come back as [C_hi | C_lo], twice as wide; fp32 outputs are unchanged. */
+int lr_op_gemm_bt_split(const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int epi, int act,
+                        int operand_dtype, int tile, void* hip_stream);
 /* QKV projection with the fused RoPE epilogue: C_op[m][n] = rotate(A W^T) for n < rope_cols, pairs (2i, 2i+1) of each
  * rope_hd-wide head rotated by cs[m][i] = (cos, sin); weight rows must already be pair-interleaved. */
 int lr_op_gemm_rope(const void* A, const void* W, void* C, const float* bias, const float* cs, int M, int N, int K,
@@ -147,6 +151,11 @@ int lr_op_gemm_rope(const void* A, const void* W, void* C, const float* bias, co
 int lr_op_attention(const void* Q, const void* K, const void* V, void* O, const int64_t* mask, const int* kmin, int ldq,
                     int ldo, int qoff, int koff, int voff, int batch, int S, int heads, int head_dim, int causal,
                     int kv_group, float scale, int operand_dtype, void* hip_stream);   /* kv_group = query heads per K/V head */
+/* Split-operand form: Q/K/V rows carry their residuals lo_off columns to the right (ldq counts both halves); both contractions
+ * are evaluated as hi.hi + hi.lo + lo.hi; O is stored [O_hi | O_lo] when o_split > 0 (ldo counts both halves). */
+int lr_op_attention_split(const void* Q, const void* K, const void* V, void* O, const int64_t* mask, const int* kmin, int ldq,
+                          int ldo, int qoff, int koff, int voff, int lo_off, int o_split, int batch, int S, int heads,
+                          int head_dim, int causal, int kv_group, float scale, int operand_dtype, void* hip_stream);
 /* Block-diagonal (ragged) dense attention: rows [cu[i], cu[i+1]) attend to each other only (the ViT's windows /
  * images, transformers Qwen2_5_VLVisionAttention over cu_seqlens).  cu_seqlens: HOST int32 [n_seg + 1]. */
 int lr_op_attention_segments(const void* Q, const void* K, const void* V, void* O, const int32_t* cu_seqlens_host, int n_seg,

@@ -538,6 +538,16 @@ int lr_op_gemm_bt(const void* A, const void* W, void* C, const float* bias, int 
     });
 }
 
+int lr_op_gemm_bt_split(const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int epi, int act,
+                        int operand_dtype, int tile, void* hip_stream) {
+    return op_guard([&] {
+        const int nout = epi == EPI_SWIGLU_OP ? N / 2 : N;
+        const bool op_out = epi == EPI_OUT_OP || epi == EPI_SWIGLU_OP;
+        GemmParams p{A, W, C, bias, M, N, 2 * K, 2 * K, K, op_out ? 2 * nout : nout, epi, act, nullptr, 0, 0, K, op_out ? nout : 0};
+        launch_gemm_bt(p, operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16, tile, (hipStream_t)hip_stream);
+    });
+}
+
 int lr_op_gemm_rope(const void* A, const void* W, void* C, const float* bias, const float* cs, int M, int N, int K, int rope_cols,
                     int rope_hd, int operand_dtype, int tile, void* hip_stream) {
     return op_guard([&] {
@@ -551,6 +561,15 @@ int lr_op_attention(const void* Q, const void* K, const void* V, void* O, const 
                     int operand_dtype, void* hip_stream) {
     return op_guard([&] {
         AttnParams p{Q, K, V, O, mask, kmin, 1, ldq, ldo, qoff, koff, voff, S, heads, scale, kv_group};
+        launch_attention(p, batch, head_dim, causal != 0, operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16, (hipStream_t)hip_stream);
+    });
+}
+
+int lr_op_attention_split(const void* Q, const void* K, const void* V, void* O, const int64_t* mask, const int* kmin, int ldq,
+                          int ldo, int qoff, int koff, int voff, int lo_off, int o_split, int batch, int S, int heads, int head_dim,
+                          int causal, int kv_group, float scale, int operand_dtype, void* hip_stream) {
+    return op_guard([&] {
+        AttnParams p{Q, K, V, O, mask, kmin, 1, ldq, ldo, qoff, koff, voff, S, heads, scale, kv_group, nullptr, 0, lo_off, o_split};
         launch_attention(p, batch, head_dim, causal != 0, operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16, (hipStream_t)hip_stream);
     });
 }

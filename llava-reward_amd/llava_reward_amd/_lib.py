@@ -68,8 +68,10 @@ _SIGS = {
     "lr_set_layer_limits": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "lr_set_gemm_tile": (C.c_int, [C.c_void_p, C.c_int]),
     "lr_op_gemm_bt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]),
+    "lr_op_gemm_bt_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),
     "lr_op_gemm_rope": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p]),
     "lr_op_attention": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 11 + [C.c_float, C.c_int, C.c_void_p]),
+    "lr_op_attention_split": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 13 + [C.c_float, C.c_int, C.c_void_p]),
     "lr_op_attention_segments": (C.c_int, [C.c_void_p] * 4 + [C.POINTER(C.c_int32)] + [C.c_int] * 8 + [C.c_float, C.c_int, C.c_void_p]),
     "lr_op_norm_rows": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "lr_op_synth_fill": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_char_p, C.c_float, C.c_float, C.c_int, C.c_void_p]),

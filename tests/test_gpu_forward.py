@@ -4,10 +4,12 @@ Checkers: (1) the CPU oracle on the same seeded inputs (small configs); (2) gold
 reference itself (tests/golden/ref_*.json), including the FULL-SIZE Phi-3.5-V case, for which the
 weights are regenerated in HBM by the same integer hash the golden script used.
 
-Tolerance (north star): |reward - reference fp32 CPU reward| <= 1e-3 with f16 MFMA operands (bf16
-weights convert exactly).  bf16 operands cannot meet 1e-3 (an fp32-everything-else emulation in the
-oracle already deviates by 1.4e-3..3.9e-3); they are held to 8e-3 and to
-2e-3 against that emulation.  Preference ordering / batch invariance: bit-exact."""
+Tolerance (north star): |reward - reference fp32 CPU reward| <= 1e-3.  The default, split-operand mode
+("f16x2": activations as f16 hi + lo, bf16-valued weights exact in f16) is held to 1e-4 everywhere,
+full-size rows included (measured <= 1.5e-5).  The single-pass fast modes are noise-limited: "f16"
+meets 1e-3 on the small configs and lands within 1e-3 in the assert_close sense (atol = rtol) on the
+full-size rows; "bf16" (the reference's own GPU dtype) is held to 8e-3.
+Preference ordering / batch invariance: bit-exact in every mode."""
 import glob
 import json
 import os
@@ -24,6 +26,7 @@ from oracle import phi3v_reward_oracle as orc
 pytestmark = pytest.mark.gpu
 
 TOL_F16 = 1e-3
+TOL_X2 = 1e-4
 TOL_BF16 = 8e-3
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -45,7 +48,7 @@ def _fwd(m, batch, rows=None):
     return r.cpu()
 
 
-@pytest.mark.parametrize("dtype,tol", [("f16", TOL_F16), ("bf16", TOL_BF16)])
+@pytest.mark.parametrize("dtype,tol", [("f16x2", TOL_X2), ("f16", TOL_F16), ("bf16", TOL_BF16)])
 @pytest.mark.parametrize("variant", ["bt_ca", "gpm2_ca", "bt_noca"])
 def test_tiny_vs_oracle(dtype, tol, variant):
     kw = dict(bt_ca={}, gpm2_ca=dict(is_general_preference=True, value_head_dim=2), bt_noca=dict(add_cross_attention=False))[variant]
@@ -62,9 +65,10 @@ def test_tiny_vs_oracle(dtype, tol, variant):
     assert err < tol
     # against the oracle run with the same operand rounding the kernels apply: only summation order,
     # exp2/rsqrt implementations and the point of rounding differ
-    emu = orc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"],
-                             opr=orc.f16_round if dtype == "f16" else orc.bf16_round)
-    assert (got - emu).abs().max().item() < (5e-4 if dtype == "f16" else 3e-3)
+    if dtype != "f16x2":
+        emu = orc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"],
+                                 opr=orc.f16_round if dtype == "f16" else orc.bf16_round)
+        assert (got - emu).abs().max().item() < (5e-4 if dtype == "f16" else 3e-3)
     # device-side synthetic weights == uploaded numpy weights, bit for bit
     m2 = _model(cfg, seed, dtype, upload=False)
     assert torch.equal(_fwd(m2, batch), got)
@@ -94,12 +98,13 @@ def test_stage_taps_tiny():
     assert np.abs(x - ref_x)[valid].max() < 2e-2 * np.abs(ref_x[valid]).max()
 
 
-def test_batch_invariance_and_preference_order_bit_exact():
+@pytest.mark.parametrize("dtype", ["f16x2", "f16"])
+def test_batch_invariance_and_preference_order_bit_exact(dtype):
     """A row's reward must not depend on what else is in the batch (fixed reduction order, no atomics),
     so preference ordering is bit-exact however rows are sharded across GPUs."""
     cfg = synth.tiny_config(is_general_preference=True, value_head_dim=2)
     batch = synth.synth_batch(cfg, 21, [5, 5, 5, 5], (1, 1))
-    m = _model(cfg, 21, "f16", upload=False)
+    m = _model(cfg, 21, dtype, upload=False)
     full = _fwd(m, batch)
     for b in range(4):
         one = _fwd(m, batch, rows=slice(b, b + 1))
@@ -137,8 +142,9 @@ def test_training_flag_and_errors():
 CASES = sorted(glob.glob(os.path.join(GOLD, "ref_small_*.json")))
 
 
+@pytest.mark.parametrize("dtype,tol", [("f16x2", TOL_X2), ("f16", TOL_F16)])
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-5] for p in CASES])
-def test_reference_goldens_small(path):
+def test_reference_goldens_small(path, dtype, tol):
     """Rewards produced by the reference itself (fp32 CPU) on full CLIP ViT-L + a 2-layer decoder."""
     g = json.load(open(path))
     cfg = synth.RewardConfig.from_json(g["config"])
@@ -146,18 +152,19 @@ def test_reference_goldens_small(path):
     grids = tuple(grids) if isinstance(grids[0], int) else [tuple(x) for x in grids]
     batch = synth.synth_batch(cfg, g["seed"], g["caption_lens"], grids, max_crops=g["max_crops"])
     ref = torch.tensor(g["reward"], dtype=torch.float32)
-    m = _model(cfg, g["seed"], "f16", upload=False, max_batch=2, max_seq=1024, max_crops=5)
+    m = _model(cfg, g["seed"], dtype, upload=False, max_batch=2, max_seq=1024, max_crops=5)
     got = _fwd(m, batch).reshape(ref.shape)
     err = (got - ref).abs().max().item()
-    print(f"[{g['name']}] max |reward err| vs reference = {err:.3e}")
-    assert err < TOL_F16
+    print(f"[{g['name']} {dtype}] max |reward err| vs reference = {err:.3e}")
+    assert err < tol
 
 
 FULL = sorted(glob.glob(os.path.join(GOLD, "ref_full_*.json")))
 
 
+@pytest.mark.parametrize("dtype", ["f16x2", "f16"])
 @pytest.mark.parametrize("path", FULL, ids=[os.path.basename(p)[:-5] for p in FULL])
-def test_reference_golden_full_size(path):
+def test_reference_golden_full_size(path, dtype):
     """Full Phi-3.5-V shapes (32 layers, D=3072, 17 crops, V=2509, S=2643): reward of the reference's
     fp32 CPU custom_forward vs the HIP path with weights regenerated in HBM."""
     g = json.load(open(path))
@@ -167,14 +174,17 @@ def test_reference_golden_full_size(path):
     batch = synth.synth_batch(cfg, g["seed"], g["caption_lens"], grids, max_crops=g["max_crops"])
     ref = torch.tensor(g["reward"], dtype=torch.float32)
     S = batch["input_ids"].shape[1]
-    m = _model(cfg, g["seed"], "f16", upload=False, max_batch=2, max_seq=S, max_crops=17)
+    m = _model(cfg, g["seed"], dtype, upload=False, max_batch=2, max_seq=S, max_crops=17)
     got = _fwd(m, batch).reshape(ref.shape)
     err = (got - ref).abs().max().item()
-    print(f"[{g['name']}] reward hip={got.flatten().tolist()} ref={ref.flatten().tolist()} err={err:.3e}")
-    # 1e-3 in the assert_close sense (atol = rtol = 1e-3).  At full depth (23 + 32 layers) numerically
-    # equivalent builds of the single-pass f16 path land anywhere within about +-1e-3 of the reference on
-    # this row (sigma ~ 7e-4 at |r| = 1.3, tools/noise_probe.py; bf16 operands: +-8e-3), see DESIGN.md §4.
-    assert (((got - ref).abs() <= TOL_F16 + TOL_F16 * ref.abs()).all())
+    print(f"[{g['name']} {dtype}] reward hip={got.flatten().tolist()} ref={ref.flatten().tolist()} err={err:.3e}")
+    if dtype == "f16x2":
+        assert err < TOL_X2                      # parity mode: measured 2.6e-6 / 5.5e-6
+    else:
+        # single-pass f16: 1e-3 in the assert_close sense (atol = rtol = 1e-3).  At full depth (23 + 32 layers) numerically
+        # equivalent builds land anywhere within about +-1e-3 of the reference on this row (sigma ~ 7e-4 at |r| = 1.3,
+        # tools/noise_probe.py; bf16 operands: +-8e-3), see DESIGN.md §4.
+        assert (((got - ref).abs() <= TOL_F16 + TOL_F16 * ref.abs()).all())
     # same row twice in one batch: bit-identical rewards
     dup = {k: np.concatenate([v, v]) for k, v in batch.items()}
     r2 = _fwd(m, dup)

@@ -269,3 +269,86 @@ def test_attention_ragged_segments(lib, dt, hd):
     err = (out.float().view(N, H, hd) - ref).abs()
     # P is rounded to the operand dtype before the PV product, the output once more: error ~ ulp * |v|max
     assert err.max().item() < 3 * ulp * f[:, 2].abs().max().item(), err.max().item()
+
+
+def _split(x, tdt):
+    """hi = round(x), lo = round(x - hi) in the operand type (csrc/common.h split2)."""
+    hi = x.to(tdt)
+    lo = (x - hi.float()).to(tdt)
+    return hi, lo
+
+
+@pytest.mark.parametrize("tile", [0, 5, 6])
+def test_gemm_split_operand_matches_fp32(lib, tile):
+    """Split-operand GEMM (parity mode): A = A_hi + A_lo (f16), W bf16-valued hence exact in f16 -> the fp32 product to ~2^-22;
+    operand-typed outputs come back as [hi | lo] whose sum again carries ~22 bits."""
+    code, tdt = L.LR_DT_F16, torch.float16
+    M, N, K = 700, 512, 384
+    A32 = rnd((M, K), 61)
+    W = rnd((N, K), 62, 0.05).to(torch.bfloat16).to(tdt)            # bf16-valued weights, stored as f16 (exact)
+    bias = rnd((N,), 63)
+    hi, lo = _split(A32, tdt)
+    A2 = torch.cat([hi, lo], dim=1).contiguous()
+    ref = (A32.double() @ W.double().t() + bias.double()).float()
+    out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    assert lib.lr_op_gemm_bt_split(P(A2), P(W), P(out), P(bias), M, N, K, L.EPI_OUT_F32, 0, code, tile, stream()) == 0
+    scale = ref.abs().max().item()
+    assert (out - ref).abs().max().item() < 2e-6 * scale
+    single = torch.empty(M, N, device="cuda", dtype=torch.float32)      # same problem, single-pass operands: ~2^-11
+    assert lib.lr_op_gemm_bt(P(hi), P(W), P(single), P(bias), M, N, K, K, K, N, L.EPI_OUT_F32, 0, code, tile, stream()) == 0
+    assert (single - ref).abs().max().item() > 20 * (out - ref).abs().max().item()
+    # operand-typed output with GELU: [hi | lo]
+    o2 = torch.zeros(M, 2 * N, device="cuda", dtype=tdt)
+    assert lib.lr_op_gemm_bt_split(P(A2), P(W), P(o2), P(bias), M, N, K, L.EPI_OUT_OP, L.ACT_GELU_ERF, code, tile, stream()) == 0
+    g = torch.nn.functional.gelu(ref)
+    got = o2[:, :N].float() + o2[:, N:].float()
+    assert (got - g).abs().max().item() < 4e-6 * g.abs().max().item()
+    assert torch.equal(o2[:, :N], got.to(tdt)) or (o2[:, :N].float() - g).abs().max().item() < 2.0 ** -10 * g.abs().max().item()
+    # SwiGLU
+    I = N // 2
+    gidx = torch.arange(I)
+    perm = torch.empty(N, dtype=torch.long)
+    perm[(gidx // 32) * 64 + gidx % 32] = gidx
+    perm[(gidx // 32) * 64 + 32 + gidx % 32] = I + gidx
+    Wp = W[perm.cuda()].contiguous()
+    gu = (A32.double() @ W.double().t()).float()
+    sref = gu[:, I:] * torch.nn.functional.silu(gu[:, :I])
+    o3 = torch.zeros(M, 2 * I, device="cuda", dtype=tdt)
+    assert lib.lr_op_gemm_bt_split(P(A2), P(Wp), P(o3), P(None), M, N, K, L.EPI_SWIGLU_OP, 0, code, tile, stream()) == 0
+    got = o3[:, :I].float() + o3[:, I:].float()
+    assert (got - sref).abs().max().item() < 4e-6 * sref.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("hd,causal,group", [(96, True, 1), (64, False, 1), (128, True, 4), (96, False, 1)])
+def test_attention_split_operand_matches_fp32(lib, hd, causal, group):
+    """3-pass attention (hi.hi + hi.lo + lo.hi for QK^T and PV) against fp64 softmax attention on the un-rounded q, k, v."""
+    code, tdt = L.LR_DT_F16, torch.float16
+    B, H, S = 2, 4, 333
+    Hkv = H // group
+    wq, wkv = H * hd, Hkv * hd
+    W = wq + 2 * wkv
+    qkv32 = rnd((B * S, W), 71, 0.8)
+    hi, lo = _split(qkv32, tdt)
+    qkv2 = torch.cat([hi, lo], dim=1).contiguous()                    # [B*S, 2W]
+    mask = torch.ones(B, S, dtype=torch.int64, device="cuda")
+    mask[1, :37] = 0                                                  # left padding
+    kmin = torch.tensor([0, 37], dtype=torch.int32, device="cuda")
+    out = torch.zeros(B * S, 2 * wq, device="cuda", dtype=tdt)
+    scale = hd ** -0.5
+    rc = lib.lr_op_attention_split(P(qkv2), P(qkv2), P(qkv2), P(out), P(mask if causal else None), P(kmin if causal else None),
+                                   2 * W, 2 * wq, 0, wq, wq + wkv, W, wq, B, S, H, hd, 1 if causal else 0, group, scale, code, stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    f = qkv32.double().view(B, S, W)
+    q = f[..., :wq].view(B, S, H, hd).transpose(1, 2)
+    k = f[..., wq:wq + wkv].view(B, S, Hkv, hd).transpose(1, 2).repeat_interleave(group, dim=1)
+    v = f[..., wq + wkv:].view(B, S, Hkv, hd).transpose(1, 2).repeat_interleave(group, dim=1)
+    s = q @ k.transpose(2, 3) * scale
+    if causal:
+        ok = torch.tril(torch.ones(S, S, dtype=torch.bool, device="cuda"))[None, None] & (mask[:, None, None, :] != 0)
+        s = s.masked_fill(~ok, float("-inf"))
+    ref = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B * S, wq).float()
+    got = out[:, :wq].float() + out[:, wq:].float()
+    valid = (mask.reshape(-1) != 0) if causal else torch.ones(B * S, dtype=torch.bool, device="cuda")
+    err = (got - ref).abs()[valid].max().item()
+    assert err < 5e-6 * ref[valid].abs().max().item(), err
