@@ -99,7 +99,9 @@ def test_llava_geometry_kats():
     assert synth.select_best_resolution((512, 640), synth.LLAVA_PINPOINTS) == (672, 672)
 
 
-QWEN_CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref_qwen_*.json")))
+# the full-size row (ref_qwen_full_bt: 6 minutes and 35 GB on CPU; the oracle reproduced it within TOL when it was generated)
+# is exercised by the GPU tests only
+QWEN_CASES = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref_qwen_*.json")) if "_full_" not in p)
 
 
 @pytest.mark.parametrize("path", QWEN_CASES, ids=[os.path.basename(p)[:-5] for p in QWEN_CASES])
