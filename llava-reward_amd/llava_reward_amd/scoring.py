@@ -1,7 +1,7 @@
 """Batch scoring loop and its multi-GPU sharding.
 
-Counterpart of the reference's eval/batch_inference_rm_phi.py:79-152 (pairwise and non-pairwise
-modes), which runs on one GPU (DistributedSampler(num_replicas=1, rank=0), :50-57).  Here rows are
+Counterpart of the reference's eval/batch_inference_rm_phi.py:79-152, batch_inference_rm_qwen.py:76-133 and
+batch_inference_rm_llava.py (pairwise and non-pairwise modes), which run on one GPU (DistributedSampler(num_replicas=1, rank=0), :50-57).  Here rows are
 independent units (custom_forward has no cross-sample op), so a global batch is cut into contiguous
 per-rank shards and the only collective is one all-gather of the fp32 rewards per batch
 (SURVEY.md §8e).  A preference pair's chosen and rejected rows go to the same rank.
@@ -59,6 +59,42 @@ def _squeeze(b: Dict[str, torch.Tensor], rows: slice, device) -> Tuple[torch.Ten
     return f("input_ids"), f("attention_mask"), f("pixel_values"), f("image_sizes")
 
 
+def shard_qwen_batch(b: Dict[str, torch.Tensor], rows: slice, image_token_id: int, merge_unit: int) -> Dict[str, torch.Tensor]:
+    """Rows [rows] of a Qwen2.5-VL BatchFeature: pixel_values [sum t*h*w, 1176] and image_grid_thw [n_images, 3] are
+    concatenated over the batch in row order, so the images of a row are found by consuming its image-slot count."""
+    ids = b["input_ids"]
+    grid = torch.as_tensor(b["image_grid_thw"]).cpu().long()
+    slots = (ids == image_token_id).sum(dim=1).cpu().tolist()
+    per_img = (grid.prod(dim=1) // merge_unit).tolist()
+    first, k = [], 0
+    for n in slots:                                   # first image of every row
+        first.append(k)
+        while n > 0:
+            if k >= len(per_img) or per_img[k] > n:
+                raise ValueError("Image features and image tokens do not match")
+            n -= per_img[k]
+            k += 1
+    first.append(k)
+    lo, hi = rows.start, rows.stop
+    patches = grid.prod(dim=1)
+    p0, p1 = int(patches[: first[lo]].sum()), int(patches[: first[hi]].sum())
+    return {"input_ids": ids[lo:hi], "attention_mask": b["attention_mask"][lo:hi], "pixel_values": b["pixel_values"][p0:p1],
+            "image_grid_thw": grid[first[lo]: first[hi]]}
+
+
+def _forward_rows(model, b, rows: slice, device):
+    """custom_forward on rows [rows] of a collated batch, whichever backbone the model is (rw_model:343-375)."""
+    mt = getattr(model, "model_type", "phi3v")
+    if mt == "phi3v":
+        return model.custom_forward(*_squeeze(b, rows, device))[0]
+    if mt == "qwen":
+        sb = shard_qwen_batch(b, rows, model.config.image_token_id, model.config.vision.merge_unit)
+    else:
+        sb = {k: b[k][rows] for k in ("input_ids", "attention_mask", "pixel_values", "image_sizes")}
+    sb = {k: (v.to(device) if k != "image_grid_thw" else v) for k, v in sb.items()}
+    return model.custom_forward(inputs_batch=sb)[0]
+
+
 @torch.no_grad()
 def score_pairwise(model, args, batches: Iterable, device=None) -> Dict[str, object]:
     """batches yields (inputs_c, inputs_r, c_rates, r_rates) as the reference's DataLoader does.
@@ -71,8 +107,8 @@ def score_pairwise(model, args, batches: Iterable, device=None) -> Dict[str, obj
     for inputs_c, inputs_r, *_ in batches:
         n = inputs_c["input_ids"].shape[0]
         rows = shard_rows(n, rank, ws)
-        c, _ = model.custom_forward(*_squeeze(inputs_c, rows, device))
-        r, _ = model.custom_forward(*_squeeze(inputs_r, rows, device))
+        c = _forward_rows(model, inputs_c, rows, device)
+        r = _forward_rows(model, inputs_r, rows, device)
         c, r = gather_rewards(c, n), gather_rewards(r, n)
         if not args.is_general_preference:
             chosen_list.extend(c.squeeze(-1).tolist())
@@ -99,7 +135,7 @@ def score_single(model, args, batches: Iterable, cls_based: bool = False, device
     for inputs, lab in batches:
         n = inputs["input_ids"].shape[0]
         rows = shard_rows(n, rank, ws)
-        r, _ = model.custom_forward(*_squeeze(inputs, rows, device))
+        r = _forward_rows(model, inputs, rows, device)
         rewards.extend(gather_rewards(r, n).squeeze(-1).tolist())
         labels.extend(torch.as_tensor(lab).tolist())
     out: Dict[str, object] = {"rewards": rewards, "labels": labels}

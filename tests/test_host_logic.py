@@ -306,3 +306,23 @@ def test_load_reward_adaptor_qwen(tmp_path):
     assert torch.equal(model._weights["visual.merger.ln_q.weight"], W["visual.merger.ln_q.weight"] + 1.0)      # ft_projector wins
     with pytest.raises(RuntimeError):                # no GPU here: the product path refuses, it does not fall back
         model.custom_forward(inputs_batch={})
+
+
+def test_shard_qwen_batch_rows_and_images():
+    """Row sharding of a Qwen2.5-VL BatchFeature (eval/batch_inference_rm_qwen.py:76-80): pixel_values / image_grid_thw are
+    concatenated over the batch, rows may carry different grids (and, in general, several images)."""
+    from llava_reward_amd.scoring import shard_qwen_batch, shard_rows
+    cfg = synth.qwen_tiny_config()
+    b = synth.qwen_synth_batch(cfg, 3, [4, 2, 6, 3, 5], [(8, 8), (4, 12), (6, 4), (8, 8), (10, 6)])
+    tb = {k: torch.from_numpy(v) for k, v in b.items()}
+    pieces = [shard_qwen_batch(tb, shard_rows(5, r, 3), cfg.image_token_id, cfg.vision.merge_unit) for r in range(3)]
+    assert [p["input_ids"].shape[0] for p in pieces] == [2, 2, 1]
+    assert torch.equal(torch.cat([p["pixel_values"] for p in pieces]), tb["pixel_values"])
+    assert torch.equal(torch.cat([p["image_grid_thw"] for p in pieces]), tb["image_grid_thw"])
+    for p in pieces:
+        assert int(p["image_grid_thw"].prod(dim=1).sum()) == p["pixel_values"].shape[0]
+        assert int((p["input_ids"] == cfg.image_token_id).sum()) * cfg.vision.merge_unit == p["pixel_values"].shape[0]
+    bad = dict(tb)
+    bad["image_grid_thw"] = tb["image_grid_thw"][:-1]
+    with pytest.raises(ValueError, match="do not match"):
+        shard_qwen_batch(bad, slice(0, 5), cfg.image_token_id, cfg.vision.merge_unit)
