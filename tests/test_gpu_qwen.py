@@ -205,3 +205,41 @@ def test_qwen_reference_golden_full_size(path, dtype):
                pixel_values=np.concatenate([batch["pixel_values"]] * 2), image_grid_thw=np.concatenate([batch["image_grid_thw"]] * 2))
     r2 = _fwd(m, dup)
     assert torch.equal(r2[0], r2[1]) and torch.equal(r2[0], got.reshape(r2[0].shape))
+
+
+def test_scoring_loop_all_backbones():
+    """llava_reward_amd.scoring.score_pairwise (eval/batch_inference_rm_{phi,qwen,llava}.py loops) on collated batches of
+    every backbone: rewards equal those of direct custom_forward calls, bit for bit, whatever the row shard."""
+    import types
+    from llava_reward_amd.scoring import score_pairwise, shard_qwen_batch
+    args = types.SimpleNamespace(is_general_preference=False, value_head_dim=1, general_preference_tau=0.1)
+    # qwen
+    cfg = synth.qwen_tiny_config()
+    m = _model(cfg, 9, "f16x2", upload=False)
+    bc = synth.qwen_synth_batch(cfg, 9, [4, 2, 6], [(8, 8), (4, 12), (6, 4)])
+    br = synth.qwen_synth_batch(cfg, 10, [3, 5, 2], [(8, 8), (8, 8), (10, 6)])
+    tc, tr = ({k: torch.from_numpy(v) for k, v in b.items()} for b in (bc, br))
+    out = score_pairwise(m, args, [(tc, tr, None, None)])
+    direct_c, direct_r = _fwd(m, bc), _fwd(m, br)
+    assert out["chosen_rewards"] == direct_c.squeeze(-1).tolist() and out["reject_rewards"] == direct_r.squeeze(-1).tolist()
+    assert len(out["probs"]) == 3 and 0.0 <= out["proportion"] <= 1.0
+    one = shard_qwen_batch(tc, slice(1, 2), cfg.image_token_id, cfg.vision.merge_unit)
+    r1, _ = m.custom_forward(inputs_batch={k: (v.cuda() if k != "image_grid_thw" else v) for k, v in one.items()})
+    assert torch.equal(r1.cpu()[0], direct_c[1])
+    # llava
+    lcfg = synth.llava_tiny_config()
+    lm = RewardModel(lcfg, synth_seed=4, max_batch=3, max_seq=4096, max_crops=5).to("cuda").eval()
+    lc = {k: torch.from_numpy(v) for k, v in synth.llava_synth_batch(lcfg, 4, [4, 6], [(336, 336), (512, 640)], max_crops=5).items()}
+    lr_ = {k: torch.from_numpy(v) for k, v in synth.llava_synth_batch(lcfg, 5, [2, 3], [(336, 336), (336, 336)], max_crops=5).items()}
+    lo = score_pairwise(lm, args, [(lc, lr_, None, None)])
+    d, _ = lm.custom_forward(inputs_batch={k: v.cuda() for k, v in lc.items()})
+    assert lo["chosen_rewards"] == d.cpu().squeeze(-1).tolist()
+    # phi3v (the collate adds a singleton dim, eval/batch_inference_rm_phi.py:82-90)
+    pcfg = synth.tiny_config(add_cross_attention=True)
+    pm = RewardModel(pcfg, synth_seed=6, max_batch=2, max_seq=512, max_crops=3).to("cuda").eval()
+    pb = {k: torch.from_numpy(v) for k, v in synth.synth_batch(pcfg, 6, [5, 3], (1, 1)).items()}
+    pb1 = {"input_ids": pb["input_ids"][:, None], "attention_mask": pb["attention_mask"][:, None],
+           "pixel_values": pb["pixel_values"][:, None], "image_sizes": pb["image_sizes"][:, None]}
+    po = score_pairwise(pm, args, [(pb1, pb1, None, None)])
+    d, _ = pm.custom_forward(pb["input_ids"].cuda(), pb["attention_mask"].cuda(), pb["pixel_values"].cuda(), pb["image_sizes"].cuda())
+    assert po["chosen_rewards"] == d.cpu().squeeze(-1).tolist() and po["probs"] == [0.5, 0.5]
