@@ -39,7 +39,9 @@ extern "C" {
 enum { LR_OK = 0, LR_EINVAL = 1, LR_EHIP = 2, LR_ESTATE = 3, LR_ENOTFOUND = 4, LR_ENOMEM = 5 };
 enum { LR_DT_BF16 = 0, LR_DT_F16 = 1, LR_DT_F32 = 2 };
 /* lr_forward flags */
-enum { LR_FWD_TRAINING_LAST_TOKEN = 1 };   /* self.training reward selection (rw_model:410-415,429-434) */
+enum { LR_FWD_TRAINING_LAST_TOKEN = 1,     /* self.training reward selection (rw_model:410-415,429-434) */
+       LR_FWD_NO_FINAL_NORM = 2 };         /* with lr_set_layer_limits(-1, k), k < layers: hidden_states[k] = the residual stream
+                                              entering layer k, which the reference takes when layer_id != 32 (rw_model:349-352) */
 
 #define LR_MAX_HALF_HEAD 64
 #define LR_MAX_PINPOINTS 8

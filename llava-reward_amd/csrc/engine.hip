@@ -479,7 +479,8 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
         launch_rope_table(h->pos_ids, h->tstat, B, S, h->inv_s, h->inv_l, d.rope_scaling, d.orig_max_pos, h->half, h->cs, st);
         run_decoder_stack(h, st, attention_mask, B, S);
         // ---- tail: final norm of the gathered row, SkipCA, value head (rw_model:376-448) ----
-        launch_gather_norm_rows(h->x, h->tstat, S, (flags & LR_FWD_TRAINING_LAST_TOKEN) ? 1 : 0, h->norm_w, d.rms_eps, h->hL, B, D, st);
+        launch_gather_norm_rows(h->x, h->tstat, S, (flags & LR_FWD_TRAINING_LAST_TOKEN) ? 1 : 0,
+                                (flags & LR_FWD_NO_FINAL_NORM) ? nullptr : h->norm_w, d.rms_eps, h->hL, B, D, st);
         const float* ao = nullptr;
         if (d.add_cross_attention) {
             launch_rowvec_linear(h->hL, h->Wq, h->tq, B, D, D, st);

@@ -465,6 +465,10 @@ __global__ __launch_bounds__(256) void gather_norm_kernel(const float* __restric
     if (b >= B) return;
     const int idx = use_last_pos ? S - 1 : tstat[b * 4 + 0];
     const float* xr = x + ((size_t)b * S + idx) * D;
+    if (!w) {          // hidden_states[layer_id] of an inner layer: the residual stream itself, no final norm (rw_model:351-352)
+        for (int c = lane; c < D; c += 64) y[(size_t)b * D + c] = xr[c];
+        return;
+    }
     float s = 0.f;
     for (int c = lane; c < D; c += 64) s += xr[c] * xr[c];
     const float rstd = rsqrtf(wave_sum(s) / D + eps);

@@ -8,6 +8,7 @@ from ._build import LIB_PATH
 
 LR_DT_BF16, LR_DT_F16, LR_DT_F32 = 0, 1, 2
 LR_FWD_TRAINING_LAST_TOKEN = 1
+LR_FWD_NO_FINAL_NORM = 2
 LR_MAX_HALF_HEAD = 64
 LR_MAX_PINPOINTS = 8
 LR_MAX_FULLATT = 8

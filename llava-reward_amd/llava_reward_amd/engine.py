@@ -152,7 +152,7 @@ class RewardEngine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, pixel_values: torch.Tensor,
-                image_sizes, training: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                image_sizes, training: bool = False, out: Optional[torch.Tensor] = None, no_final_norm: bool = False) -> torch.Tensor:
         dev = torch.device("cuda", self.device)
         ids = input_ids.to(dev, torch.int64).contiguous()
         mask = attention_mask.to(dev, torch.int64).contiguous()
@@ -170,8 +170,8 @@ class RewardEngine:
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = self.lib.lr_forward(self.h, C.c_void_p(ids.data_ptr()), C.c_void_p(mask.data_ptr()), C.c_void_p(pix.data_ptr()),
                                  pdt, C.cast(sizes.data_ptr(), C.POINTER(C.c_int64)), B, S, pix.shape[1],
-                                 L.LR_FWD_TRAINING_LAST_TOKEN if training else 0, C.c_void_p(out.data_ptr()),
-                                 C.c_void_p(stream))
+                                 (L.LR_FWD_TRAINING_LAST_TOKEN if training else 0) | (L.LR_FWD_NO_FINAL_NORM if no_final_norm else 0),
+                                 C.c_void_p(out.data_ptr()), C.c_void_p(stream))
         L.check(self.lib, rc, self.h, "lr_forward")
         # keep inputs alive until the stream has consumed them
         for t in (ids, mask, pix):

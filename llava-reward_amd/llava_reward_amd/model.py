@@ -24,14 +24,17 @@ class RewardModel:
             raise ValueError("RewardModel needs weights or a synth_seed")
         if mean_hidden_state:
             raise NotImplementedError("mean_hidden_state pooling (rw_model:398-406) is not on the accelerated path yet")
-        if layer_id not in (32, cfg.layers):
-            raise NotImplementedError("only the last-layer hidden state (layer_id == 32) is implemented")
+        # rw_model:349-352: layer_id == 32 (the literal) -> last_hidden_state, else hidden_states[layer_id] = the input of decoder
+        # layer `layer_id` (un-normed residual stream; index `layers` is the final-norm output again).  phi3v branch only.
+        if not (layer_id == 32 or 0 <= layer_id <= cfg.layers):
+            raise IndexError("tuple index out of range (hidden_states[layer_id])")
         self.config = cfg
         self.model_type = "qwen" if isinstance(cfg, QwenConfig) else "llava" if isinstance(cfg, LlavaConfig) else "phi3v"
         self._weights = weights
         self._synth_seed = synth_seed
         self._opts = dict(max_batch=max_batch, max_seq=max_seq, max_crops=max_crops, operand_dtype=operand_dtype,
                           max_patches=max_patches)
+        self.layer_id = layer_id
         self.engine = None
         self.training = False
         self.device = torch.device("cpu")
@@ -109,7 +112,9 @@ class RewardModel:
             if not torch.equal(n_slots.long(), expect):
                 raise RuntimeError(f"shape mismatch: image slots per row {n_slots.tolist()} != projected image tokens "
                                    f"{expect.tolist()} (modeling_phi3_v.py:247 index_put)")
-        reward = self.engine.forward(input_ids, attention_mask, pixel_values, sz, training=self.training)
+        inner = self.model_type == "phi3v" and self.layer_id != 32 and self.layer_id < self.config.layers
+        self.engine.set_layer_limits(-1, self.layer_id if inner else -1)
+        reward = self.engine.forward(input_ids, attention_mask, pixel_values, sz, training=self.training, no_final_norm=inner)
         if return_output:
             B, D = reward.shape[0], self.config.hidden
             hl = torch.from_numpy(self.engine.read_tap("hL", B * D).reshape(B, D).copy())

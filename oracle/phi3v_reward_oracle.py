@@ -183,9 +183,10 @@ def decoder_layer(W, l: int, x, mask4d, cos, sin, cfg, opr=Ident):
 # ------------------------------------------------------------------------------------ full path
 @torch.no_grad()
 def custom_forward(W: Dict[str, torch.Tensor], cfg, input_ids, attention_mask, pixel_values, image_sizes,
-                   training: bool = False, opr: Callable = Ident, taps: Optional[dict] = None) -> torch.Tensor:
-    """RW:334-448 CustomRewardModel.custom_forward, phi3v branch, layer_id == 32,
-    mean_hidden_state unset.  Returns reward [B,1] (BT) or [B,d] (GPM), fp32.
+                   training: bool = False, opr: Callable = Ident, taps: Optional[dict] = None, layer_id: int = 32) -> torch.Tensor:
+    """RW:334-448 CustomRewardModel.custom_forward, phi3v branch; layer_id == 32 -> last_hidden_state, else
+    hidden_states[layer_id] (RW:349-352; PHI:1467-1505: entry k < L is the input of decoder layer k, entry L the final-norm
+    output); mean_hidden_state unset.  Returns reward [B,1] (BT) or [B,d] (GPM), fp32.
     `taps`, if given, receives intermediate tensors keyed by stage name."""
     input_ids = torch.as_tensor(input_ids)
     attention_mask = torch.as_tensor(attention_mask)
@@ -217,11 +218,16 @@ def custom_forward(W: Dict[str, torch.Tensor], cfg, input_ids, attention_mask, p
     # PHI:1468-1500 decoder stack + final norm
     mask4d = causal_padding_mask(attention_mask)
     cos, sin = su_rope_cos_sin(position_ids, cfg)
+    states = []
     for l in range(cfg.layers):
+        states.append(x)
         x = decoder_layer(W, l, x, mask4d, cos, sin, cfg, opr)
         if taps is not None:
             taps[f"layer{l}"] = x.clone()
     h = rms_norm(x, W["model.norm.weight"], cfg.rms_eps)
+    states.append(h)
+    if layer_id != 32:
+        h = states[layer_id]
     # RW:376-386 SkipCA (zero-padded vision rows take part un-masked)
     if cfg.add_cross_attention:
         Q = F.linear(h, W["W_q.weight"])

@@ -54,7 +54,7 @@ def import_reference():
     return _get_reward_model, Phi3RMSNorm, Phi3VModel, Phi3VForCausalLM, Phi3VConfig
 
 
-def build_reference_model(ref, cfg: synth.RewardConfig, seed: int):
+def build_reference_model(ref, cfg: synth.RewardConfig, seed: int, layer_id: int = 32):
     _get_reward_model, Phi3RMSNorm, Phi3VModel, Phi3VForCausalLM, Phi3VConfig = ref
     assert cfg.clip == synth.ClipConfig(), "the reference hard-wires CLIP ViT-L/14-336"
     hcfg = Phi3VConfig(
@@ -72,7 +72,7 @@ def build_reference_model(ref, cfg: synth.RewardConfig, seed: int):
     hcfg._attn_implementation = "eager"
     cls = _get_reward_model(Phi3VForCausalLM, Phi3VModel, RMSNorm_class=Phi3RMSNorm, RMSNorm_class_eps=cfg.ca_eps,
                             is_general_preference=cfg.is_general_preference,
-                            add_cross_attention=cfg.add_cross_attention, value_head_dim=cfg.value_head_dim)
+                            add_cross_attention=cfg.add_cross_attention, value_head_dim=cfg.value_head_dim, layer_id=layer_id)
     t0 = time.time()
     # meta-device construction skips the reference's random init of parameters we overwrite anyway
     model = cls(hcfg)
@@ -105,9 +105,9 @@ def fingerprint(t: torch.Tensor, n: int = 16):
             "vals": [float(v) for v in f[idx]]}
 
 
-def run_case(ref, name, cfg, seed, caption_lens, grids, max_crops, taps=True):
+def run_case(ref, name, cfg, seed, caption_lens, grids, max_crops, taps=True, layer_id=32):
     print(f"[{name}] building", flush=True)
-    model = build_reference_model(ref, cfg, seed)
+    model = build_reference_model(ref, cfg, seed, layer_id)
     batch = synth.synth_batch(cfg, seed, caption_lens, grids, max_crops=max_crops)
     tb = {k: torch.from_numpy(v) for k, v in batch.items()}
     t0 = time.time()
@@ -118,7 +118,7 @@ def run_case(ref, name, cfg, seed, caption_lens, grids, max_crops, taps=True):
     print(f"[{name}] reference custom_forward {dt:.1f}s reward={reward.flatten().tolist()}", flush=True)
     out = {"name": name, "config": cfg.to_json(), "seed": seed, "caption_lens": caption_lens,
            "grids": [list(g) for g in grids] if not isinstance(grids[0], int) else list(grids),
-           "max_crops": max_crops, "reward": reward.float().tolist(),
+           "max_crops": max_crops, "reward": reward.float().tolist(), "layer_id": layer_id,
            "reference_forward_seconds": dt, "threads": torch.get_num_threads(),
            "torch": torch.__version__, "dtype": "float32"}
     if taps:
@@ -291,6 +291,9 @@ def main():
         run_llava_case("ref_llava_tiny_gpm2", C(is_general_preference=True, value_head_dim=2), 12, [5, 9], [(512, 640), (336, 336)], 5)
         run_llava_case("ref_llava_tiny_wide", C(), 13, [4], [(300, 900)], None)
         run_llava_case("ref_llava_tiny_tall", C(layers=3), 14, [2, 7], [(400, 300), (672, 672)], 5)
+    elif which == "layer_id":
+        # rw_model:349-352 with layer_id != 32: hidden_states[1] = the residual stream entering decoder layer 1 (no final norm)
+        run_case(ref, "ref_small_layer1_bt_ca", synth.ref_small_config(), 77, [4, 7], (1, 1), None, layer_id=1)
     elif which == "qwen":
         C, Q = synth.qwen_tiny_config, synth.qwen_quirk_config
         run_qwen_case("ref_qwen_tiny_bt", C(), 21, [6, 3], [(16, 16), (16, 16)])

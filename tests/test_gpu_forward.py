@@ -31,12 +31,13 @@ TOL_BF16 = 8e-3
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _model(cfg, seed, dtype, upload, max_batch=4, max_seq=1024, max_crops=5):
+def _model(cfg, seed, dtype, upload, max_batch=4, max_seq=1024, max_crops=5, layer_id=32):
     if upload:
         W = {k: torch.from_numpy(v) for k, v in synth.make_weights(cfg, seed).items()}
-        m = RewardModel(cfg, weights=W, max_batch=max_batch, max_seq=max_seq, max_crops=max_crops, operand_dtype=dtype)
+        m = RewardModel(cfg, weights=W, max_batch=max_batch, max_seq=max_seq, max_crops=max_crops, operand_dtype=dtype, layer_id=layer_id)
     else:
-        m = RewardModel(cfg, synth_seed=seed, max_batch=max_batch, max_seq=max_seq, max_crops=max_crops, operand_dtype=dtype)
+        m = RewardModel(cfg, synth_seed=seed, max_batch=max_batch, max_seq=max_seq, max_crops=max_crops, operand_dtype=dtype,
+                        layer_id=layer_id)
     return m.to("cuda").eval()
 
 
@@ -152,11 +153,16 @@ def test_reference_goldens_small(path, dtype, tol):
     grids = tuple(grids) if isinstance(grids[0], int) else [tuple(x) for x in grids]
     batch = synth.synth_batch(cfg, g["seed"], g["caption_lens"], grids, max_crops=g["max_crops"])
     ref = torch.tensor(g["reward"], dtype=torch.float32)
-    m = _model(cfg, g["seed"], dtype, upload=False, max_batch=2, max_seq=1024, max_crops=5)
+    m = _model(cfg, g["seed"], dtype, upload=False, max_batch=2, max_seq=1024, max_crops=5, layer_id=g.get("layer_id", 32))
     got = _fwd(m, batch).reshape(ref.shape)
     err = (got - ref).abs().max().item()
     print(f"[{g['name']} {dtype}] max |reward err| vs reference = {err:.3e}")
     assert err < tol
+    if g.get("layer_id", 32) != 32:      # the same engine gives the last-layer reward again once layer_id is the literal 32
+        m.layer_id = 32
+        W = orc.weights_to_torch(synth.make_weights(cfg, g["seed"]))
+        full = orc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"])
+        assert (_fwd(m, batch) - full).abs().max().item() < tol
 
 
 FULL = sorted(glob.glob(os.path.join(GOLD, "ref_full_*.json")))

@@ -33,7 +33,7 @@ def test_oracle_matches_reference(path):
     batch = synth.synth_batch(cfg, g["seed"], g["caption_lens"], grids, max_crops=g["max_crops"])
     taps = {}
     r = orc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"],
-                           batch["image_sizes"], taps=taps)
+                           batch["image_sizes"], taps=taps, layer_id=g.get("layer_id", 32))
     ref = np.array(g["reward"], dtype=np.float32).reshape(r.shape)
     assert np.abs(r.numpy() - ref).max() < TOL, (r, ref)
     # stage fingerprints localise any divergence; only valid (non-pad) rows are comparable
