@@ -91,6 +91,9 @@ typedef struct lr_model_desc {
      * operand type (f16: 22 mantissa bits), weights stay single (bf16 checkpoints are exact in f16); every contraction
      * costs 2x (linears) / 3x (attention) the MFMA work.  0 = single-pass operands (default). */
     int32_t precise;
+    /* rw_model_general_preference.py:398-406 `mean_hidden_state`: the SkipCA block + its RMSNorm are applied to every token and
+     * the value head reads the attention-mask-weighted mean (fp32 path; rewards are [B, value_head_dim] in train and eval). */
+    int32_t mean_hidden_state;
 } lr_model_desc;
 
 int lr_abi_version(void);

@@ -110,6 +110,7 @@ struct lr_engine {
     float *x = nullptr, *qkv32 = nullptr, *cs = nullptr;
     void *h = nullptr, *qkv = nullptr, *att = nullptr, *ff = nullptr;
     int *pos_ids = nullptr, *img_row = nullptr, *tstat = nullptr;
+    float *mh_h = nullptr, *mh_t1 = nullptr, *mh_t2 = nullptr, *mh_sc = nullptr;   // mean-pooling head (fp32, all tokens)
     float *hL = nullptr, *tq = nullptr, *tkq = nullptr, *tsc = nullptr, *tctx = nullptr, *tao = nullptr;
     // per-forward tables (ring of pinned host slots + device mirrors)
     static constexpr int NSLOT = 4;
@@ -243,6 +244,11 @@ inline void gemm(lr_engine* e, hipStream_t st, const void* A, const void* W, voi
 
 // engine.hip: pre-norm decoder stack shared by the three backbones (x, cs, tstat prepared by the caller)
 void run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_mask, int B, int S);
+// engine.hip: rw_model:398-406 -- SkipCA for every token (o: per-token term, u: per-sample term, either may be null), masked mean
+// pooling into h->hL, value head.  Vb / voff: image rows of every sample in h->ev (host), Vmax = their maximum.
+void run_mean_pool_head(lr_engine* h, hipStream_t st, const int64_t* attention_mask, int B, int S, const int* voff_host, int Vmax,
+                        const float* u, bool final_norm, float* rewards_out);
+void alloc_mean_pool(lr_engine* h, size_t rows, size_t vcap);
 // qwen.hip
 void build_weight_table_qwen(lr_engine* e);
 void validate_desc_qwen(const lr_model_desc& d);

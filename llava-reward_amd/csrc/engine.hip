@@ -188,6 +188,44 @@ void run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_ma
     }
 }
 
+void alloc_mean_pool(lr_engine* h, size_t rows, size_t vcap) {
+    const size_t D = h->d.hidden;
+    h->mh_h = (float*)h->dalloc(rows * D * 4, false);
+    if (h->d.add_cross_attention && !h->qwen) {
+        h->mh_t1 = (float*)h->dalloc(rows * D * 4, false);
+        h->mh_t2 = (float*)h->dalloc(rows * D * 4, false);
+        h->mh_sc = (float*)h->dalloc(((size_t)h->d.max_seq + 256) * vcap * 4, false);
+    }
+}
+
+void run_mean_pool_head(lr_engine* h, hipStream_t st, const int64_t* attention_mask, int B, int S, const int* voff_host, int Vmax,
+                        const float* u, bool final_norm, float* rewards_out) {
+    const lr_model_desc& d = h->d;
+    const int D = d.hidden, Rl = B * S;
+    if (final_norm) launch_rms_rows_f32(h->x, h->norm_w, d.rms_eps, h->mh_h, Rl, D, st);
+    else LR_HIP_CHECK(hipMemcpyAsync(h->mh_h, h->x, (size_t)Rl * D * 4, hipMemcpyDeviceToDevice, st));
+    const float* o = nullptr;
+    if (d.add_cross_attention && !h->qwen) {
+        // SkipCA for every token (rw_model:376-386), folded as in the gathered-row tail: score = (W_k^T W_q h) . e_j, out = W_v sum_j p_j e_j
+        launch_gemm_f32(h->mh_h, h->Wq, 1, 1, h->mh_t1, Rl, D, D, D, D, D, 1.f, st);
+        launch_gemm_f32(h->mh_t1, h->WkT, 1, 1, h->mh_t2, Rl, D, D, D, D, D, 1.f, st);
+        const int ldsc = h->Vcap;
+        for (int b = 0; b < B; ++b) {
+            const int vb = voff_host[b + 1] - voff_host[b];
+            const float* evb = h->ev + (size_t)voff_host[b] * D;
+            float* ctx = h->mh_t1 + (size_t)b * S * D;
+            launch_gemm_f32(h->mh_t2 + (size_t)b * S * D, evb, 0, 1, h->mh_sc, S, vb, D, D, D, ldsc, 1.0f / std::sqrt((float)D), st);
+            launch_ca_softmax_pad(h->mh_sc, S, ldsc, vb, Vmax, st);
+            launch_gemm_f32(h->mh_sc, evb, 0, 0, ctx, S, D, vb, ldsc, D, D, 1.f, st);
+        }
+        launch_gemm_f32(h->mh_t1, h->Wv, 1, 1, h->mh_t2, Rl, D, D, D, D, D, 1.f, st);
+        o = h->mh_t2;
+    }
+    const bool ca = d.add_cross_attention != 0;
+    launch_ca_pool(h->mh_h, o, ca ? u : nullptr, ca ? h->ca_w : nullptr, d.ca_eps, attention_mask, h->hL, B, S, D, st);
+    launch_reward_head(h->hL, nullptr, nullptr, 0.f, h->vh, d.value_head_dim, rewards_out, B, D, st);
+}
+
 extern "C" {
 
 int lr_abi_version(void) { return LR_ABI_VERSION; }
@@ -341,6 +379,7 @@ int lr_finalize(lr_handle h) {
         h->pos_ids = (int*)W(Rl * 4); h->img_row = (int*)W(Rl * 4); h->tstat = (int*)W(B * 16);
         h->hL = (float*)W(B * D * 4); h->tq = (float*)W(B * D * 4); h->tkq = (float*)W(B * D * 4);
         h->tsc = (float*)W(B * (size_t)h->Vcap * 4); h->tctx = (float*)W(B * D * 4); h->tao = (float*)W(B * D * 4);
+        if (d.mean_hidden_state) alloc_mean_pool(h, Rl, (size_t)h->Vcap);
         // tables: crop_src[NC] | per-sample geometry [B] (HdSample or LlavaSample) | voff[B+1]
         h->tab_bytes = ((NC * 4 + B * sizeof(LlavaSample) + (B + 1) * 4) + 255) & ~(size_t)255;
         LR_HIP_CHECK(hipHostMalloc((void**)&h->tab_host, h->tab_bytes * lr_engine::NSLOT));
@@ -478,6 +517,11 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
         launch_embed(input_ids, h->img_row, h->wte, h->ev, h->x, Rl, D, d.vocab_size, st);
         launch_rope_table(h->pos_ids, h->tstat, B, S, h->inv_s, h->inv_l, d.rope_scaling, d.orig_max_pos, h->half, h->cs, st);
         run_decoder_stack(h, st, attention_mask, B, S);
+        if (d.mean_hidden_state) {      // rw_model:398-406: SkipCA + norm on every token, masked mean, value head
+            run_mean_pool_head(h, st, attention_mask, B, S, voff, Vmax, nullptr, !(flags & LR_FWD_NO_FINAL_NORM), rewards_out);
+            LR_HIP_CHECK(hipGetLastError());
+            return;
+        }
         // ---- tail: final norm of the gathered row, SkipCA, value head (rw_model:376-448) ----
         launch_gather_norm_rows(h->x, h->tstat, S, (flags & LR_FWD_TRAINING_LAST_TOKEN) ? 1 : 0,
                                 (flags & LR_FWD_NO_FINAL_NORM) ? nullptr : h->norm_w, d.rms_eps, h->hL, B, D, st);

@@ -81,6 +81,17 @@ void launch_ca_context(const float* ev, const float* pr, const int* voff, int B,
 void launch_reward_head(const float* hL, const float* attn_o, const float* ca_w, float ca_eps, const float* vh, int d,
                         float* out, int B, int D, hipStream_t st);
 
+// mean-pooling reward head (rw_model:398-406), fp32 -------------------------------------------------
+// gemm_f32.hip: C = alpha * A op(B), fp32 MFMA (32x32x2); B [N,K] (b_nt) or [K,N]; B elements fp32 or bf16 bits
+void launch_gemm_f32(const float* A, const void* B, int b_is_bf16, int b_nt, float* C, int M, int N, int K, int lda, int ldb,
+                     int ldc, float alpha, hipStream_t st);
+void launch_rms_rows_f32(const float* x, const float* w, float eps, float* y, int rows, int D, hipStream_t st);
+// in-place softmax of rows of `ld` floats: vb real scores + (Vmax - vb) implicit zero scores in the denominator
+void launch_ca_softmax_pad(float* sc, int rows, int ld, int vb, int Vmax, hipStream_t st);
+// pooled[b] = masked mean over tokens of (ca ? ca_w * rmsnorm(h + o + u[b]) : h); o, u, ca_w may be null
+void launch_ca_pool(const float* h, const float* o, const float* u, const float* ca_w, float ca_eps, const int64_t* mask,
+                    float* pooled, int B, int S, int D, hipStream_t st);
+
 // weights ---------------------------------------------------------------------------------------
 void launch_synth_fill(float* out, size_t n, uint64_t tseed, float scale, float offset, int bf16_round, hipStream_t st);
 enum : int { PACK_PLAIN = 0, PACK_SWIGLU = 1, PACK_TRANSPOSE = 2, PACK_ROPE_QKV = 3, PACK_SWIGLU_GATE = 4, PACK_SWIGLU_UP = 5,

@@ -624,6 +624,101 @@ void launch_reward_head(const float* hL, const float* attn_o, const float* ca_w,
     hipLaunchKernelGGL(reward_head_kernel, dim3(B), dim3(256), 0, st, hL, attn_o, ca_w, ca_eps, vh, d, out, D);
 }
 
+// ------------------------------------------------------------------------- mean-pooling reward head
+// rw_model_general_preference.py:398-406 (`mean_hidden_state`): the SkipCA block and its RMSNorm are applied to EVERY token
+// and the value head reads the mask-weighted mean.  All fp32; fixed summation order (no atomics).
+// y[r] = w * x[r] * rsqrt(mean(x[r]^2) + eps), fp32 in and out (hidden_states[-1] for every token)
+__global__ __launch_bounds__(256) void rms_rows_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, float eps,
+                                                           float* __restrict__ y, int rows, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * D;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += xr[c] * xr[c];
+    const float rstd = rsqrtf(wave_sum(s) / D + eps);
+    for (int c = lane; c < D; c += 64) y[(size_t)row * D + c] = w[c] * (xr[c] * rstd);
+}
+
+void launch_rms_rows_f32(const float* x, const float* w, float eps, float* y, int rows, int D, hipStream_t st) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(rms_rows_f32_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, w, eps, y, rows, D);
+}
+
+// softmax over Vmax columns of which only the first vb hold scores; the other Vmax - vb are the zero-padded image rows of
+// the batch (score exactly 0, value rows 0: they only enter the denominator).  In place, one block per row.
+__global__ __launch_bounds__(256) void ca_softmax_pad_kernel(float* __restrict__ sc, int ld, int vb, int Vmax) {
+    __shared__ float sh[4];
+    float* r = sc + (size_t)blockIdx.x * ld;
+    const int npad = Vmax - vb;
+    float mx = npad > 0 ? 0.f : -INFINITY;
+    for (int j = threadIdx.x; j < vb; j += 256) mx = fmaxf(mx, r[j]);
+    mx = block_reduce(mx, true, sh);
+    float s = 0.f;
+    for (int j = threadIdx.x; j < vb; j += 256) s += expf(r[j] - mx);
+    s = block_reduce(s, false, sh) + (float)npad * expf(-mx);
+    const float inv = 1.f / s;
+    for (int j = threadIdx.x; j < vb; j += 256) r[j] = expf(r[j] - mx) * inv;
+}
+
+void launch_ca_softmax_pad(float* sc, int rows, int ld, int vb, int Vmax, hipStream_t st) {
+    if (rows <= 0 || vb <= 0) return;
+    hipLaunchKernelGGL(ca_softmax_pad_kernel, dim3(rows), dim3(256), 0, st, sc, ld, vb, Vmax);
+}
+
+// pooled[b] = sum_s mask[b,s] * f(h[b,s]) / max(sum_s mask[b,s], 1e-8),  f(h) = ca_w * rmsnorm(h + o[b,s] + u[b]) when a SkipCA
+// term is present (o per token: Phi-3-V; u per sample: Qwen2.5-VL's as-written block), else f(h) = h.  One block per sample.
+__global__ __launch_bounds__(256) void ca_pool_kernel(const float* __restrict__ h, const float* __restrict__ o, const float* __restrict__ u,
+                                                      const float* __restrict__ ca_w, float ca_eps, const int64_t* __restrict__ mask,
+                                                      float* __restrict__ pooled, int S, int D) {
+    constexpr int MAXC = 16;                 // D <= 4096
+    __shared__ float sh[4];
+    const int b = blockIdx.x;
+    float acc[MAXC], uu[MAXC], ww[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        acc[i] = 0.f;
+        uu[i] = (u && c < D) ? u[(size_t)b * D + c] : 0.f;
+        ww[i] = (ca_w && c < D) ? ca_w[c] : 1.f;
+    }
+    const bool ca = o != nullptr || u != nullptr;
+    float cnt = 0.f;
+    for (int s = 0; s < S; ++s) {
+        if (mask[(size_t)b * S + s] == 0) continue;          // block-uniform
+        cnt += 1.f;
+        const size_t base = ((size_t)b * S + s) * D;
+        float v[MAXC], sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = threadIdx.x + 256 * i;
+            v[i] = 0.f;
+            if (c < D) {
+                v[i] = h[base + c] + uu[i];
+                if (o) v[i] += o[base + c];
+                sq += v[i] * v[i];
+            }
+        }
+        float rstd = 1.f;
+        if (ca) rstd = rsqrtf(block_reduce(sq, false, sh) / D + ca_eps);
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) acc[i] += ca ? ww[i] * (v[i] * rstd) : v[i];
+    }
+    const float inv = 1.f / fmaxf(cnt, 1e-8f);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < D) pooled[(size_t)b * D + c] = acc[i] * inv;
+    }
+}
+
+void launch_ca_pool(const float* h, const float* o, const float* u, const float* ca_w, float ca_eps, const int64_t* mask,
+                    float* pooled, int B, int S, int D, hipStream_t st) {
+    if (B <= 0) return;
+    if (D > 4096) throw std::runtime_error("ca_pool: D above 4096 is not supported");
+    hipLaunchKernelGGL(ca_pool_kernel, dim3(B), dim3(256), 0, st, h, o, u, ca_w, ca_eps, mask, pooled, S, D);
+}
+
 // --------------------------------------------------------------------------------------- weights
 // Bit-identical to llava_reward_amd.synth.gen_tensor (splitmix64 counter hash, one fp32 multiply).
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {

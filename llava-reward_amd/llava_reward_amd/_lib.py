@@ -45,6 +45,7 @@ class ModelDesc(C.Structure):
         ("mrope_section", C.c_int32 * 3),
         ("ca_token_id", C.c_int32), ("max_patches", C.c_int32),
         ("precise", C.c_int32),
+        ("mean_hidden_state", C.c_int32),
     ]
 
 

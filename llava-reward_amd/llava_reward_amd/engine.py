@@ -23,7 +23,8 @@ def rope_inv_freq(factors, head_dim: int, theta: float) -> torch.Tensor:
     return 1.0 / (ext * theta ** inv_shape)
 
 
-def make_desc(cfg, max_batch: int, max_seq: int, max_crops: int, operand_dtype: str, max_patches: int = 0) -> L.ModelDesc:
+def make_desc(cfg, max_batch: int, max_seq: int, max_crops: int, operand_dtype: str, max_patches: int = 0,
+              mean_hidden_state: bool = False) -> L.ModelDesc:
     d = L.ModelDesc()
     d.struct_size = C.sizeof(L.ModelDesc)
     d.vocab_size, d.hidden, d.intermediate = cfg.vocab_size, cfg.hidden, cfg.intermediate
@@ -85,6 +86,7 @@ def make_desc(cfg, max_batch: int, max_seq: int, max_crops: int, operand_dtype: 
     d.max_batch, d.max_seq, d.max_crops = max_batch, max_seq, max_crops
     d.operand_dtype = _DT[operand_dtype]
     d.precise = 1 if operand_dtype in _PRECISE else 0
+    d.mean_hidden_state = 1 if mean_hidden_state else 0
     return d
 
 
@@ -92,7 +94,7 @@ class RewardEngine:
     """Owns one lr_handle (one GPU).  Not thread-safe; forward() enqueues on the current torch stream."""
 
     def __init__(self, cfg, device: int = 0, max_batch: int = 32, max_seq: int = 2816,
-                 max_crops: int = 17, operand_dtype: str = "f16x2", max_patches: int = 0):
+                 max_crops: int = 17, operand_dtype: str = "f16x2", max_patches: int = 0, mean_hidden_state: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("RewardEngine needs a HIP device (torch.cuda.is_available() is False); "
                                "the scoring path has no CPU fallback")
@@ -106,7 +108,7 @@ class RewardEngine:
         if isinstance(cfg, QwenConfig) and max_patches <= 0:
             max_patches = max_batch * 1280 * cfg.vision.merge_unit      # the reference's max_pixels = 1280 * 28^2 (utils/utils.py:36)
         self.max_patches = max_patches
-        self._desc = make_desc(cfg, max_batch, max_seq, max_crops, operand_dtype, max_patches)
+        self._desc = make_desc(cfg, max_batch, max_seq, max_crops, operand_dtype, max_patches, mean_hidden_state)
         h = C.c_void_p()
         L.check(self.lib, self.lib.lr_create(C.byref(self._desc), self.device, C.byref(h)), None, "lr_create")
         self.h = h

@@ -22,8 +22,6 @@ class RewardModel:
                  layer_id: int = 32, mean_hidden_state=None, max_patches: int = 0):
         if weights is None and synth_seed is None:
             raise ValueError("RewardModel needs weights or a synth_seed")
-        if mean_hidden_state:
-            raise NotImplementedError("mean_hidden_state pooling (rw_model:398-406) is not on the accelerated path yet")
         # rw_model:349-352: layer_id == 32 (the literal) -> last_hidden_state, else hidden_states[layer_id] = the input of decoder
         # layer `layer_id` (un-normed residual stream; index `layers` is the final-norm output again).  phi3v branch only.
         if not (layer_id == 32 or 0 <= layer_id <= cfg.layers):
@@ -32,8 +30,11 @@ class RewardModel:
         self.model_type = "qwen" if isinstance(cfg, QwenConfig) else "llava" if isinstance(cfg, LlavaConfig) else "phi3v"
         self._weights = weights
         self._synth_seed = synth_seed
+        self.mean_hidden_state = bool(mean_hidden_state)      # rw_model:398-406: masked mean of the (SkipCA'd) hidden states
+        if self.mean_hidden_state and layer_id != 32 and layer_id < cfg.layers:
+            raise NotImplementedError("mean_hidden_state together with an inner layer_id is not implemented")
         self._opts = dict(max_batch=max_batch, max_seq=max_seq, max_crops=max_crops, operand_dtype=operand_dtype,
-                          max_patches=max_patches)
+                          max_patches=max_patches, mean_hidden_state=self.mean_hidden_state)
         self.layer_id = layer_id
         self.engine = None
         self.training = False

@@ -84,7 +84,8 @@ def decoder_layer(W, l, x, mask4d, cos, sin, cfg, opr=Ident):
 
 @torch.no_grad()
 def custom_forward(W: Dict[str, torch.Tensor], cfg, input_ids, attention_mask, pixel_values, image_sizes,
-                   training: bool = False, opr: Callable = Ident, taps: Optional[dict] = None) -> torch.Tensor:
+                   training: bool = False, opr: Callable = Ident, taps: Optional[dict] = None,
+                   mean_hidden_state: bool = False) -> torch.Tensor:
     input_ids = torch.as_tensor(input_ids)
     attention_mask = torch.as_tensor(attention_mask)
     pixel_values = torch.as_tensor(pixel_values, dtype=torch.float32)
@@ -105,6 +106,8 @@ def custom_forward(W: Dict[str, torch.Tensor], cfg, input_ids, attention_mask, p
         if taps is not None:
             taps[f"layer{l}"] = x.clone()
     h = po.rms_norm(x, W["language_model.model.norm.weight"], cfg.rms_eps)      # hidden_states[-1]
+    if mean_hidden_state:                                    # rw_model:398-406
+        return F.linear(po.mean_pool(h, attention_mask), W["value_head.weight"])
     values = F.linear(h, W["value_head.weight"])
     if training:
         return values[:, -1, :]

@@ -183,7 +183,8 @@ def decoder_layer(W, l: int, x, mask4d, cos, sin, cfg, opr=Ident):
 # ------------------------------------------------------------------------------------ full path
 @torch.no_grad()
 def custom_forward(W: Dict[str, torch.Tensor], cfg, input_ids, attention_mask, pixel_values, image_sizes,
-                   training: bool = False, opr: Callable = Ident, taps: Optional[dict] = None, layer_id: int = 32) -> torch.Tensor:
+                   training: bool = False, opr: Callable = Ident, taps: Optional[dict] = None, layer_id: int = 32,
+                   mean_hidden_state: bool = False) -> torch.Tensor:
     """RW:334-448 CustomRewardModel.custom_forward, phi3v branch; layer_id == 32 -> last_hidden_state, else
     hidden_states[layer_id] (RW:349-352; PHI:1467-1505: entry k < L is the input of decoder layer k, entry L the final-norm
     output); mean_hidden_state unset.  Returns reward [B,1] (BT) or [B,d] (GPM), fp32.
@@ -237,11 +238,19 @@ def custom_forward(W: Dict[str, torch.Tensor], cfg, input_ids, attention_mask, p
         h = rms_norm(h + torch.bmm(torch.softmax(sc, dim=-1), Vv), W["ca_layernorm.weight"], cfg.ca_eps)
     if taps is not None:
         taps["final_hidden"] = h.clone()
+    if mean_hidden_state:
+        return F.linear(mean_pool(h, attention_mask), W["value_head.weight"])
     values = F.linear(h, W["value_head.weight"])          # RW:408 / :427  [B,S,d]
     if training:                                          # RW:410-415 / :429-434
         return values[:, -1, :]
     eos = S - 1 - attention_mask.long().fliplr().argmax(dim=1)      # RW:420 / :439
     return values[torch.arange(B), eos, :]
+
+
+def mean_pool(h: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+    """RW:398-406 (`mean_hidden_state`): mask-weighted mean over tokens; reward = value_head(pooled) in train and eval."""
+    m = attention_mask.to(h.dtype).unsqueeze(-1)
+    return (h * m).sum(dim=1) / m.sum(dim=1).clamp(min=1e-8)
 
 
 def preference_compute(cfg, chosen: torch.Tensor, reject: torch.Tensor):

@@ -144,7 +144,8 @@ def skip_ca(W, cfg, last: torch.Tensor, embeds: torch.Tensor, input_ids: torch.T
 
 @torch.no_grad()
 def custom_forward(W: Dict[str, torch.Tensor], cfg, input_ids, attention_mask, pixel_values, image_grid_thw,
-                   training: bool = False, opr: Callable = Ident, taps: Optional[dict] = None) -> torch.Tensor:
+                   training: bool = False, opr: Callable = Ident, taps: Optional[dict] = None,
+                   mean_hidden_state: bool = False) -> torch.Tensor:
     from llava_reward_amd.synth import qwen_rope_index
     input_ids = torch.as_tensor(input_ids)
     attention_mask = torch.as_tensor(attention_mask)
@@ -169,6 +170,8 @@ def custom_forward(W: Dict[str, torch.Tensor], cfg, input_ids, attention_mask, p
     h = po.rms_norm(x, W["model.norm.weight"], cfg.rms_eps)                                    # hidden_states[-1]
     if cfg.add_cross_attention:
         h = skip_ca(W, cfg, h, embeds, input_ids)
+    if mean_hidden_state:                                    # rw_model:398-406
+        return F.linear(po.mean_pool(h, attention_mask), W["value_head.weight"])
     values = F.linear(h, W["value_head.weight"])
     if training:
         return values[:, -1, :]

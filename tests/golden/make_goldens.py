@@ -54,7 +54,7 @@ def import_reference():
     return _get_reward_model, Phi3RMSNorm, Phi3VModel, Phi3VForCausalLM, Phi3VConfig
 
 
-def build_reference_model(ref, cfg: synth.RewardConfig, seed: int, layer_id: int = 32):
+def build_reference_model(ref, cfg: synth.RewardConfig, seed: int, layer_id: int = 32, mean_hidden_state=None):
     _get_reward_model, Phi3RMSNorm, Phi3VModel, Phi3VForCausalLM, Phi3VConfig = ref
     assert cfg.clip == synth.ClipConfig(), "the reference hard-wires CLIP ViT-L/14-336"
     hcfg = Phi3VConfig(
@@ -72,7 +72,8 @@ def build_reference_model(ref, cfg: synth.RewardConfig, seed: int, layer_id: int
     hcfg._attn_implementation = "eager"
     cls = _get_reward_model(Phi3VForCausalLM, Phi3VModel, RMSNorm_class=Phi3RMSNorm, RMSNorm_class_eps=cfg.ca_eps,
                             is_general_preference=cfg.is_general_preference,
-                            add_cross_attention=cfg.add_cross_attention, value_head_dim=cfg.value_head_dim, layer_id=layer_id)
+                            add_cross_attention=cfg.add_cross_attention, value_head_dim=cfg.value_head_dim, layer_id=layer_id,
+                            mean_hidden_state=mean_hidden_state)
     t0 = time.time()
     # meta-device construction skips the reference's random init of parameters we overwrite anyway
     model = cls(hcfg)
@@ -105,9 +106,9 @@ def fingerprint(t: torch.Tensor, n: int = 16):
             "vals": [float(v) for v in f[idx]]}
 
 
-def run_case(ref, name, cfg, seed, caption_lens, grids, max_crops, taps=True, layer_id=32):
+def run_case(ref, name, cfg, seed, caption_lens, grids, max_crops, taps=True, layer_id=32, mean_hidden_state=None):
     print(f"[{name}] building", flush=True)
-    model = build_reference_model(ref, cfg, seed, layer_id)
+    model = build_reference_model(ref, cfg, seed, layer_id, mean_hidden_state)
     batch = synth.synth_batch(cfg, seed, caption_lens, grids, max_crops=max_crops)
     tb = {k: torch.from_numpy(v) for k, v in batch.items()}
     t0 = time.time()
@@ -119,6 +120,7 @@ def run_case(ref, name, cfg, seed, caption_lens, grids, max_crops, taps=True, la
     out = {"name": name, "config": cfg.to_json(), "seed": seed, "caption_lens": caption_lens,
            "grids": [list(g) for g in grids] if not isinstance(grids[0], int) else list(grids),
            "max_crops": max_crops, "reward": reward.float().tolist(), "layer_id": layer_id,
+           "mean_hidden_state": bool(mean_hidden_state),
            "reference_forward_seconds": dt, "threads": torch.get_num_threads(),
            "torch": torch.__version__, "dtype": "float32"}
     if taps:
@@ -149,7 +151,7 @@ def canon_llava_name(name: str) -> str:
     return n
 
 
-def run_llava_case(name, cfg, seed, caption_lens, image_sizes, max_crops):
+def run_llava_case(name, cfg, seed, caption_lens, image_sizes, max_crops, mean_hidden_state=None):
     """Reference custom_forward, model_type='llava' (rw_model_general_preference.py:372-375,407-448)."""
     import transformers
     from transformers import CLIPVisionConfig, LlavaNextConfig, LlavaNextForConditionalGeneration, MistralConfig
@@ -169,7 +171,8 @@ def run_llava_case(name, cfg, seed, caption_lens, image_sizes, max_crops):
     hcfg._attn_implementation = "eager"
     cls = _get_reward_model(LlavaNextForConditionalGeneration, LlavaNextForConditionalGeneration, RMSNorm_class=LlamaRMSNorm,
                             RMSNorm_class_eps=1e-5, is_general_preference=cfg.is_general_preference,
-                            add_cross_attention=False, value_head_dim=cfg.value_head_dim, model_type="llava")
+                            add_cross_attention=False, value_head_dim=cfg.value_head_dim, model_type="llava",
+                            mean_hidden_state=mean_hidden_state)
     model = cls(hcfg)
     model.eval()
     specs = {n: (sh, std, off) for n, sh, std, off in synth.llava_weight_specs(cfg)}
@@ -193,6 +196,7 @@ def run_llava_case(name, cfg, seed, caption_lens, image_sizes, max_crops):
     print(f"[{name}] reference llava custom_forward {dt:.1f}s reward={reward.flatten().tolist()}", flush=True)
     out = {"name": name, "backbone": "llava", "config": cfg.to_json(), "seed": seed, "caption_lens": caption_lens,
            "image_sizes": [list(x) for x in image_sizes], "max_crops": max_crops, "reward": reward.float().tolist(),
+           "mean_hidden_state": bool(mean_hidden_state),
            "transformers": transformers.__version__, "torch": torch.__version__, "dtype": "float32"}
     with open(os.path.join(HERE, f"{name}.json"), "w") as f:
         json.dump(out, f, indent=1)
@@ -209,7 +213,7 @@ def canon_qwen_name(name: str) -> str:
     return n
 
 
-def run_qwen_case(name, cfg, seed, caption_lens, grids):
+def run_qwen_case(name, cfg, seed, caption_lens, grids, mean_hidden_state=None):
     """Reference custom_forward, model_type='qwen' (rw_model_general_preference.py:354-371,387-397,407-448).
 
     Shims for running the 4.50-era reference code on transformers 5.x:
@@ -238,7 +242,8 @@ def run_qwen_case(name, cfg, seed, caption_lens, grids):
     hcfg.hidden_size = hcfg.text_config.hidden_size                                      # shim 1
     cls = _get_reward_model(Qwen2_5_VLForConditionalGeneration, Qwen2_5_VLModel, RMSNorm_class=Qwen2RMSNorm,
                             RMSNorm_class_eps=1e-6, is_general_preference=cfg.is_general_preference,
-                            add_cross_attention=cfg.add_cross_attention, value_head_dim=cfg.value_head_dim)
+                            add_cross_attention=cfg.add_cross_attention, value_head_dim=cfg.value_head_dim,
+                            mean_hidden_state=mean_hidden_state)
     model = cls(hcfg)
     model.model_type = "qwen"                                                            # reward_adaptor_loader.py:79
     model.__dict__["visual"] = model.model.visual                                        # shim 2
@@ -266,7 +271,7 @@ def run_qwen_case(name, cfg, seed, caption_lens, grids):
     dt = time.time() - t0
     print(f"[{name}] reference qwen custom_forward {dt:.1f}s reward={reward.flatten().tolist()}", flush=True)
     out = {"name": name, "backbone": "qwen", "config": cfg.to_json(), "seed": seed, "caption_lens": caption_lens,
-           "grids": [list(g) for g in grids], "reward": reward.float().tolist(),
+           "grids": [list(g) for g in grids], "reward": reward.float().tolist(), "mean_hidden_state": bool(mean_hidden_state),
            "n_ca_rows": (tb["input_ids"] == synth.QWEN_CA_TOKEN_ID).sum(dim=1).tolist(),
            "transformers": transformers.__version__, "torch": torch.__version__, "dtype": "float32"}
     with open(os.path.join(HERE, f"{name}.json"), "w") as f:
@@ -291,6 +296,13 @@ def main():
         run_llava_case("ref_llava_tiny_gpm2", C(is_general_preference=True, value_head_dim=2), 12, [5, 9], [(512, 640), (336, 336)], 5)
         run_llava_case("ref_llava_tiny_wide", C(), 13, [4], [(300, 900)], None)
         run_llava_case("ref_llava_tiny_tall", C(layers=3), 14, [2, 7], [(400, 300), (672, 672)], 5)
+    elif which == "mean":
+        # rw_model:398-406 `mean_hidden_state=True` (a training-script option; SkipCA + norm on every token, masked mean)
+        run_case(ref, "ref_small_mean_bt_ca", synth.ref_small_config(), 78, [5, 9], [(1, 1), (1, 2)], 3, taps=False, mean_hidden_state=True)
+        run_case(ref, "ref_small_mean_gpm2_noca", synth.ref_small_config(is_general_preference=True, value_head_dim=2, add_cross_attention=False),
+                 79, [3, 6], (1, 1), None, taps=False, mean_hidden_state=True)
+        run_llava_case("ref_llava_tiny_mean_bt", synth.llava_tiny_config(), 15, [6, 3], [(336, 336), (512, 640)], 5, mean_hidden_state=True)
+        run_qwen_case("ref_qwen_quirk_mean_bt", synth.qwen_quirk_config(), 26, [2, 7, 4], [(8, 8), (12, 16), (8, 8)], mean_hidden_state=True)
     elif which == "layer_id":
         # rw_model:349-352 with layer_id != 32: hidden_states[1] = the residual stream entering decoder layer 1 (no final norm)
         run_case(ref, "ref_small_layer1_bt_ca", synth.ref_small_config(), 77, [4, 7], (1, 1), None, layer_id=1)

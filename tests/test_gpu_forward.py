@@ -31,13 +31,14 @@ TOL_BF16 = 8e-3
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _model(cfg, seed, dtype, upload, max_batch=4, max_seq=1024, max_crops=5, layer_id=32):
+def _model(cfg, seed, dtype, upload, max_batch=4, max_seq=1024, max_crops=5, layer_id=32, mean=False):
     if upload:
         W = {k: torch.from_numpy(v) for k, v in synth.make_weights(cfg, seed).items()}
-        m = RewardModel(cfg, weights=W, max_batch=max_batch, max_seq=max_seq, max_crops=max_crops, operand_dtype=dtype, layer_id=layer_id)
+        m = RewardModel(cfg, weights=W, max_batch=max_batch, max_seq=max_seq, max_crops=max_crops, operand_dtype=dtype, layer_id=layer_id,
+                        mean_hidden_state=mean)
     else:
         m = RewardModel(cfg, synth_seed=seed, max_batch=max_batch, max_seq=max_seq, max_crops=max_crops, operand_dtype=dtype,
-                        layer_id=layer_id)
+                        layer_id=layer_id, mean_hidden_state=mean)
     return m.to("cuda").eval()
 
 
@@ -153,7 +154,8 @@ def test_reference_goldens_small(path, dtype, tol):
     grids = tuple(grids) if isinstance(grids[0], int) else [tuple(x) for x in grids]
     batch = synth.synth_batch(cfg, g["seed"], g["caption_lens"], grids, max_crops=g["max_crops"])
     ref = torch.tensor(g["reward"], dtype=torch.float32)
-    m = _model(cfg, g["seed"], dtype, upload=False, max_batch=2, max_seq=1024, max_crops=5, layer_id=g.get("layer_id", 32))
+    m = _model(cfg, g["seed"], dtype, upload=False, max_batch=2, max_seq=1024, max_crops=5, layer_id=g.get("layer_id", 32),
+               mean=g.get("mean_hidden_state", False))
     got = _fwd(m, batch).reshape(ref.shape)
     err = (got - ref).abs().max().item()
     print(f"[{g['name']} {dtype}] max |reward err| vs reference = {err:.3e}")

@@ -19,12 +19,12 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _model(cfg, seed, dtype, upload, max_seq=4096):
+def _model(cfg, seed, dtype, upload, max_seq=4096, mean=False):
     if upload:
         W = {k: torch.from_numpy(v) for k, v in synth.llava_make_weights(cfg, seed).items()}
-        m = RewardModel(cfg, weights=W, max_batch=3, max_seq=max_seq, max_crops=5, operand_dtype=dtype)
+        m = RewardModel(cfg, weights=W, max_batch=3, max_seq=max_seq, max_crops=5, operand_dtype=dtype, mean_hidden_state=mean)
     else:
-        m = RewardModel(cfg, synth_seed=seed, max_batch=3, max_seq=max_seq, max_crops=5, operand_dtype=dtype)
+        m = RewardModel(cfg, synth_seed=seed, max_batch=3, max_seq=max_seq, max_crops=5, operand_dtype=dtype, mean_hidden_state=mean)
     return m.to("cuda").eval()
 
 
@@ -65,7 +65,7 @@ def test_llava_reference_goldens(path, dtype):
     cfg = synth.LlavaConfig.from_json(g["config"])
     batch = synth.llava_synth_batch(cfg, g["seed"], g["caption_lens"], [tuple(x) for x in g["image_sizes"]], max_crops=g["max_crops"])
     ref = torch.tensor(g["reward"], dtype=torch.float32)
-    m = _model(cfg, g["seed"], dtype, upload=False)
+    m = _model(cfg, g["seed"], dtype, upload=False, mean=g.get("mean_hidden_state", False))
     got = _fwd(m, batch).reshape(ref.shape)
     err = (got - ref).abs().max().item()
     print(f"[{g['name']} {dtype}] max |reward err| vs reference = {err:.3e}")

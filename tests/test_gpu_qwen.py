@@ -23,12 +23,14 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _model(cfg, seed, dtype, upload, max_batch=4, max_seq=1024, max_patches=4096):
+def _model(cfg, seed, dtype, upload, max_batch=4, max_seq=1024, max_patches=4096, mean=False):
     if upload:
         W = {k: torch.from_numpy(v) for k, v in synth.qwen_make_weights(cfg, seed).items()}
-        m = RewardModel(cfg, weights=W, max_batch=max_batch, max_seq=max_seq, operand_dtype=dtype, max_patches=max_patches)
+        m = RewardModel(cfg, weights=W, max_batch=max_batch, max_seq=max_seq, operand_dtype=dtype, max_patches=max_patches,
+                        mean_hidden_state=mean)
     else:
-        m = RewardModel(cfg, synth_seed=seed, max_batch=max_batch, max_seq=max_seq, operand_dtype=dtype, max_patches=max_patches)
+        m = RewardModel(cfg, synth_seed=seed, max_batch=max_batch, max_seq=max_seq, operand_dtype=dtype, max_patches=max_patches,
+                        mean_hidden_state=mean)
     return m.to("cuda").eval()
 
 
@@ -176,7 +178,7 @@ def test_qwen_reference_goldens(path, dtype):
     cfg = synth.QwenConfig.from_json(g["config"])
     batch = synth.qwen_synth_batch(cfg, g["seed"], g["caption_lens"], [tuple(x) for x in g["grids"]])
     ref = torch.tensor(g["reward"], dtype=torch.float32)
-    m = _model(cfg, g["seed"], dtype, upload=False)
+    m = _model(cfg, g["seed"], dtype, upload=False, mean=g.get("mean_hidden_state", False))
     got = _fwd(m, batch).reshape(ref.shape)
     err = (got - ref).abs().max().item()
     print(f"[{g['name']} {dtype}] max |reward err| vs reference = {err:.3e}")

@@ -213,8 +213,7 @@ def test_score_single_metrics():
 def test_reward_model_requires_weights_or_seed():
     with pytest.raises(ValueError):
         RewardModel(synth.tiny_config())
-    with pytest.raises(NotImplementedError):
-        RewardModel(synth.tiny_config(), synth_seed=1, mean_hidden_state=True)
+    assert RewardModel(synth.tiny_config(), synth_seed=1, mean_hidden_state=True).mean_hidden_state is True      # rw_model:398-406
     assert RewardModel(synth.tiny_config(), synth_seed=1, layer_id=1).layer_id == 1       # hidden_states[1] (rw_model:351-352)
     with pytest.raises(IndexError):
         RewardModel(synth.tiny_config(), synth_seed=1, layer_id=7)
