@@ -110,6 +110,9 @@ struct GemmParams {
     // (A = [A_hi | A_lo], K = 2 kw).  split > 0: epilogues that emit operands also store the rounding residual of
     // every element `split` columns to the right of it (C = [C_hi | C_lo], ldc covers both halves).
     int kw, split;
+    // split-operand mode with weights that are NOT exact in the operand type (e.g. LoRA-merged fp32 weights): Wlo holds the
+    // rounding residuals of W (same layout) and K = 3 kw runs A = [hi | lo | hi] against [W | W | Wlo]
+    const void* Wlo;
 };
 
 struct AttnParams {

@@ -40,6 +40,8 @@ struct Slot {
     int ld_dst, cols_dst, dst_dtype, mode;
     double std_, offset;       // synthetic init (llava_reward_amd.synth.weight_specs)
     int aux_d = 0, aux_hd = 0, aux_hdp = 0; // PACK_ROPE_QKV: rows of a section, head width, stored head width
+    void* lo_dst = nullptr;    // split-operand mode: where the rounding residual of this tensor goes (same layout as dst)
+    int wid = -1;              // index of the operand-weight buffer that holds dst
     bool provided = false;
 };
 
@@ -65,6 +67,12 @@ struct lr_engine {
     std::vector<void*> allocs;
     std::vector<Slot> slots;
     std::unordered_map<std::string, int> index;
+    // split-operand mode: every operand-typed weight buffer has a residual twin; a buffer is "inexact" once any residual is non-zero
+    struct WBuf { char* hi; char* lo; size_t bytes; };
+    std::vector<WBuf> wbufs;
+    std::unordered_map<const void*, int> wbuf_of;      // hi base pointer -> index
+    int* inexact_dev = nullptr;
+    std::vector<int> inexact;
     size_t ws_bytes = 0, weight_bytes = 0;
     int gemm_tile = -1, lim_clip = -1, lim_layers = -1;
 
@@ -94,7 +102,7 @@ struct lr_engine {
     unsigned short* wte = nullptr;
     std::vector<DecLayer> dl;
     float* norm_w = nullptr;
-    unsigned short *Wq = nullptr, *WkT = nullptr, *Wv = nullptr;
+    float *Wq = nullptr, *WkT = nullptr, *Wv = nullptr;      // SkipCA projections for the fp32 tail, kept in fp32
     float *ca_w = nullptr, *vh = nullptr;
     float *inv_s = nullptr, *inv_l = nullptr;
 
@@ -141,12 +149,26 @@ inline void add_slot(lr_engine* e, const std::string& name, std::vector<int64_t>
     else { s.rows = (int)shape[0]; int64_t c = 1; for (size_t i = 1; i < shape.size(); ++i) c *= shape[i]; s.cols = (int)c; }
     s.dst = dst; s.ld_dst = ld_dst; s.cols_dst = cols_dst; s.dst_dtype = dst_dtype; s.mode = mode;
     s.std_ = std_; s.offset = offset;
+    if (e->prec && (dst_dtype == DT_F16 || dst_dtype == DT_BF16)) {
+        for (size_t i = 0; i < e->wbufs.size(); ++i) {
+            const lr_engine::WBuf& w = e->wbufs[i];
+            if ((char*)dst >= w.hi && (char*)dst < w.hi + w.bytes) { s.lo_dst = w.lo + ((char*)dst - w.hi); s.wid = (int)i; break; }
+        }
+    }
     e->index[name] = (int)e->slots.size();
     e->slots.push_back(s);
 }
 
 inline float* falloc(lr_engine* e, size_t n) { return (float*)e->dalloc(n * 4, true); }
-inline void* oalloc(lr_engine* e, size_t n) { return e->dalloc(n * 2, true); }
+inline void* oalloc(lr_engine* e, size_t n) {
+    void* hi = e->dalloc(n * 2, true);
+    if (e->prec) {
+        void* lo = e->dalloc(n * 2, true);
+        e->wbuf_of[hi] = (int)e->wbufs.size();
+        e->wbufs.push_back({(char*)hi, (char*)lo, n * 2});
+    }
+    return hi;
+}
 
 inline void vec_slot(lr_engine* e, const std::string& name, std::vector<int64_t> shape, float* dst, double std_, double off) {
     int64_t n = 1; for (auto v : shape) n *= v;
@@ -226,6 +248,11 @@ template <typename F> int guarded(lr_engine* e, F&& f) {
 inline void apply_prec(const lr_engine* e, GemmParams& p) {
     if (!e->prec) return;
     p.kw = p.K; p.K *= 2; p.lda *= 2;
+    auto it = e->wbuf_of.find(p.W);
+    if (it != e->wbuf_of.end() && !e->inexact.empty() && e->inexact[it->second]) {     // weights not exact in the operand type
+        p.Wlo = e->wbufs[it->second].lo;
+        p.K = 3 * p.kw;
+    }
     if (p.epi == EPI_OUT_OP || p.epi == EPI_SWIGLU_OP || p.epi == EPI_ROPE_OP) { p.split = p.ldc; p.ldc *= 2; }
 }
 inline void apply_prec(const lr_engine* e, AttnParams& p) {

@@ -11,7 +11,7 @@ void build_weight_table_phi(lr_engine* e) {
     const int Hc = d.clip_hidden, D = d.hidden, I = d.intermediate;
     const int od = e->op_dt;
     const std::string ep = "model.vision_embed_tokens.";
-    e->wte = (unsigned short*)oalloc(e, (size_t)d.vocab_size * D);
+    e->wte = (unsigned short*)e->dalloc((size_t)d.vocab_size * D * 2, true);      // bf16 embedding table (not an MFMA operand)
     add_slot(e, "model.embed_tokens.weight", {d.vocab_size, D}, e->wte, D, D, DT_BF16, PACK_PLAIN, 0.02, 0);
     register_clip(e, "model.vision_embed_tokens.img_processor.vision_model.");
     e->glb_gn = falloc(e, 4 * Hc); e->sub_gn = falloc(e, 4 * Hc);
@@ -41,13 +41,13 @@ void build_weight_table_phi(lr_engine* e) {
     e->norm_w = falloc(e, D);
     vec_slot(e, "model.norm.weight", {D}, e->norm_w, 0.05, 1.0);
     if (d.add_cross_attention) {
-        e->Wq = (unsigned short*)oalloc(e, (size_t)D * D);
-        e->WkT = (unsigned short*)oalloc(e, (size_t)D * D);
-        e->Wv = (unsigned short*)oalloc(e, (size_t)D * D);
+        e->Wq = falloc(e, (size_t)D * D);
+        e->WkT = falloc(e, (size_t)D * D);
+        e->Wv = falloc(e, (size_t)D * D);
         e->ca_w = falloc(e, D);
-        add_slot(e, "W_q.weight", {D, D}, e->Wq, D, D, DT_BF16, PACK_PLAIN, 0.02, 0);
-        add_slot(e, "W_k.weight", {D, D}, e->WkT, D, D, DT_BF16, PACK_TRANSPOSE, 0.02, 0);
-        add_slot(e, "W_v.weight", {D, D}, e->Wv, D, D, DT_BF16, PACK_PLAIN, 0.02, 0);
+        add_slot(e, "W_q.weight", {D, D}, e->Wq, D, D, DT_F32, PACK_PLAIN, 0.02, 0);
+        add_slot(e, "W_k.weight", {D, D}, e->WkT, D, D, DT_F32, PACK_TRANSPOSE, 0.02, 0);
+        add_slot(e, "W_v.weight", {D, D}, e->Wv, D, D, DT_F32, PACK_PLAIN, 0.02, 0);
         vec_slot(e, "ca_layernorm.weight", {D}, e->ca_w, 0.05, 1.0);
     }
     e->vh = falloc(e, (size_t)d.value_head_dim * D);
@@ -60,7 +60,7 @@ void build_weight_table_llava(lr_engine* e) {
     const lr_model_desc& d = e->d;
     const int Hc = d.clip_hidden, D = d.hidden, I = d.intermediate, hd = e->hd, Hq = e->Hq, Hkv = e->Hkv;
     const int od = e->op_dt;
-    e->wte = (unsigned short*)oalloc(e, (size_t)d.vocab_size * D);
+    e->wte = (unsigned short*)e->dalloc((size_t)d.vocab_size * D * 2, true);      // bf16 embedding table (not an MFMA operand)
     add_slot(e, "language_model.model.embed_tokens.weight", {d.vocab_size, D}, e->wte, D, D, DT_BF16, PACK_PLAIN, 0.02, 0);
     register_clip(e, "vision_tower.vision_model.");
     e->p0_w = oalloc(e, (size_t)D * Hc); e->p0_b = falloc(e, D);
@@ -112,8 +112,12 @@ void ensure_stage(lr_engine* e, size_t raw_bytes, size_t n_f32) {
 }
 
 void pack_slot(lr_engine* e, Slot& s, const float* src_f32) {
+    if (s.lo_dst && !e->inexact_dev) {
+        LR_HIP_CHECK(hipMalloc((void**)&e->inexact_dev, e->wbufs.size() * sizeof(int)));
+        LR_HIP_CHECK(hipMemset(e->inexact_dev, 0, e->wbufs.size() * sizeof(int)));
+    }
     launch_pack(src_f32, s.dst, s.rows, s.cols, s.ld_dst, s.mode == PACK_TRANSPOSE ? s.cols : s.cols_dst, s.dst_dtype, s.mode, 0,
-                s.aux_d, s.aux_hd, s.aux_hdp);
+                s.aux_d, s.aux_hd, s.aux_hdp, s.lo_dst, s.lo_dst ? e->inexact_dev + s.wid : nullptr);
     s.provided = true;
 }
 
@@ -207,8 +211,8 @@ void run_mean_pool_head(lr_engine* h, hipStream_t st, const int64_t* attention_m
     const float* o = nullptr;
     if (d.add_cross_attention && !h->qwen) {
         // SkipCA for every token (rw_model:376-386), folded as in the gathered-row tail: score = (W_k^T W_q h) . e_j, out = W_v sum_j p_j e_j
-        launch_gemm_f32(h->mh_h, h->Wq, 1, 1, h->mh_t1, Rl, D, D, D, D, D, 1.f, st);
-        launch_gemm_f32(h->mh_t1, h->WkT, 1, 1, h->mh_t2, Rl, D, D, D, D, D, 1.f, st);
+        launch_gemm_f32(h->mh_h, h->Wq, 0, 1, h->mh_t1, Rl, D, D, D, D, D, 1.f, st);
+        launch_gemm_f32(h->mh_t1, h->WkT, 0, 1, h->mh_t2, Rl, D, D, D, D, D, 1.f, st);
         const int ldsc = h->Vcap;
         for (int b = 0; b < B; ++b) {
             const int vb = voff_host[b + 1] - voff_host[b];
@@ -218,7 +222,7 @@ void run_mean_pool_head(lr_engine* h, hipStream_t st, const int64_t* attention_m
             launch_ca_softmax_pad(h->mh_sc, S, ldsc, vb, Vmax, st);
             launch_gemm_f32(h->mh_sc, evb, 0, 0, ctx, S, D, vb, ldsc, D, D, 1.f, st);
         }
-        launch_gemm_f32(h->mh_t1, h->Wv, 1, 1, h->mh_t2, Rl, D, D, D, D, D, 1.f, st);
+        launch_gemm_f32(h->mh_t1, h->Wv, 0, 1, h->mh_t2, Rl, D, D, D, D, D, 1.f, st);
         o = h->mh_t2;
     }
     const bool ca = d.add_cross_attention != 0;
@@ -291,6 +295,7 @@ int lr_destroy(lr_handle h) {
     for (void* p : h->allocs) hipFree(p);
     if (h->stage_raw) hipFree(h->stage_raw);
     if (h->stage_f32) hipFree(h->stage_f32);
+    if (h->inexact_dev) hipFree(h->inexact_dev);
     if (h->tab_host) hipHostFree(h->tab_host);
     for (int i = 0; i < lr_engine::NSLOT; ++i) if (h->tab_ev[i]) hipEventDestroy(h->tab_ev[i]);
     delete h;
@@ -355,6 +360,10 @@ int lr_finalize(lr_handle h) {
         if (h->finalized) return;
         for (const Slot& s : h->slots)
             if (!s.provided) throw std::logic_error("lr_finalize: tensor never provided: " + s.name);
+        if (h->inexact_dev) {           // which operand-weight buffers carry non-zero rounding residuals (split-operand mode)
+            h->inexact.assign(h->wbufs.size(), 0);
+            LR_HIP_CHECK(hipMemcpy(h->inexact.data(), h->inexact_dev, h->wbufs.size() * sizeof(int), hipMemcpyDeviceToHost));
+        }
         if (h->stage_raw) { LR_HIP_CHECK(hipFree(h->stage_raw)); h->stage_raw = nullptr; h->stage_raw_cap = 0; }
         if (h->stage_f32) { LR_HIP_CHECK(hipFree(h->stage_f32)); h->stage_f32 = nullptr; h->stage_f32_cap = 0; }
         if (h->qwen) { finalize_qwen(h); h->finalized = true; return; }

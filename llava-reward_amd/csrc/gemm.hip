@@ -83,8 +83,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bt_kernel(GemmParams p) {
     auto stage = [&](int buf, int kt) {
         char* sA = smem + buf * STAGE;
         char* sB = sA + A_BYTES;
-        const int koff = kt * BK;
-        const int koffw = (p.kw > 0 && koff >= p.kw) ? koff - p.kw : koff;      // split-operand mode: W repeats along K
+        int koff = kt * BK, koffw = koff;
+        ptrdiff_t wsel = 0;
+        if (p.kw > 0) {                          // split-operand mode: A = [hi | lo (| hi)], W repeats along K (, then its residuals)
+            if (koff >= 2 * p.kw) { koff -= 2 * p.kw; koffw = koff; wsel = (const unsigned short*)p.Wlo - (const unsigned short*)p.W; }
+            else if (koff >= p.kw) koffw = koff - p.kw;
+        }
 #pragma unroll
         for (int it = 0; it < A_LOADS; ++it) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA[it] + koff),
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bt_kernel(GemmParams p) {
         }
 #pragma unroll
         for (int it = 0; it < B_LOADS; ++it) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB[it] + koffw),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB[it] + koffw + wsel),
                                              (__attribute__((address_space(3))) void*)(sB + (it * NT + wave * 64) * 16),
                                              16, 0, 0);
         }
@@ -242,7 +246,8 @@ bool gemm_bt_is_deep(const GemmParams& p, int tile) { return pick_tile(p, tile) 
 void launch_gemm_bt(const GemmParams& p, int operand_dtype, int tile, hipStream_t st) {
     if (p.M <= 0) return;
     if (p.K % 64 != 0) throw std::runtime_error("gemm_bt: K must be a multiple of 64");
-    if (p.kw < 0 || (p.kw > 0 && (p.kw % 64 || p.K != 2 * p.kw))) throw std::runtime_error("gemm_bt: split-operand mode needs K == 2 * kw, kw % 64 == 0");
+    if (p.kw < 0 || (p.kw > 0 && (p.kw % 64 || p.K != (p.Wlo ? 3 : 2) * p.kw)))
+        throw std::runtime_error("gemm_bt: split-operand mode needs K == 2 kw (3 kw with Wlo), kw % 64 == 0");
     if (p.split < 0 || p.split % 8) throw std::runtime_error("gemm_bt: split must be a non-negative multiple of 8");
     if (p.epi == EPI_SWIGLU_OP && (p.N % 64) != 0) throw std::runtime_error("gemm_bt: SwiGLU needs N % 64 == 0");
     tile = pick_tile(p, tile);

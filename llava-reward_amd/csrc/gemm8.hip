@@ -57,6 +57,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
     const int Gtot = 4 * nk;
     typedef __attribute__((address_space(3))) char lds_char;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_char*)smem;
+    const ptrdiff_t wlo_delta = p.Wlo ? (const unsigned short*)p.Wlo - (const unsigned short*)p.W : 0;
 
     // ---- fragment read offsets inside a half-tile image: 8 A reads + 4 B reads per phase ----
     // 16x16x32: lane (r = lane&15, q = lane>>4) reads row r, 16-byte chunk 4*ks + q   (ks = 0..1)
@@ -129,9 +130,14 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         // (cdna_hip_programming.md §5.7 item 1).  M0 is saved/restored inside the statement.
         auto issue1 = [&](int j, int kt, int slot, int it) {
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * HT + wave * 1024 + it * 8192);
-            const int koff = DBG == 1 ? 0 : kt * BK;
-            const int koffw = (p.kw > 0 && koff >= p.kw) ? koff - p.kw : koff;      // split-operand mode: W repeats along K
-            const unsigned short* src = (j == 0) ? gA[0][it] + koff : (j == 1) ? gB[0][it] + koffw : (j == 2) ? gB[1][it] + koffw : gA[1][it] + koff;
+            int koff = DBG == 1 ? 0 : kt * BK, koffw = koff;
+            ptrdiff_t wsel = 0;
+            if (p.kw > 0) {                      // split-operand mode: A = [hi | lo (| hi)], W repeats along K (, then its residuals)
+                if (koff >= 2 * p.kw) { koff -= 2 * p.kw; koffw = koff; wsel = wlo_delta; }
+                else if (koff >= p.kw) koffw = koff - p.kw;
+            }
+            const unsigned short* src = (j == 0) ? gA[0][it] + koff : (j == 1) ? gB[0][it] + koffw + wsel : (j == 2) ? gB[1][it] + koffw + wsel
+                                                                                                            : gA[1][it] + koff;
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
@@ -485,7 +491,7 @@ static void launch8_variant(const GemmParams& p, int variant, hipStream_t st) {
 void launch_gemm_bt8(const GemmParams& p, int operand_dtype, int variant, hipStream_t st) {
     if (p.N % 8 || p.ldc % 8 || ((uintptr_t)p.C & 15) || (p.bias && ((uintptr_t)p.bias & 15)))
         throw std::runtime_error("gemm_bt8: N and ldc must be multiples of 8 and C/bias 16-byte aligned");
-    if (p.kw > 0 && (p.kw % 64 || p.K != 2 * p.kw)) throw std::runtime_error("gemm_bt8: split-operand mode needs K == 2 * kw");
+    if (p.kw > 0 && (p.kw % 64 || p.K != (p.Wlo ? 3 : 2) * p.kw)) throw std::runtime_error("gemm_bt8: split-operand mode needs K == 2 kw (3 kw with Wlo)");
     if (p.epi == EPI_ROPE_OP && (!p.rope_cs || p.rope_hd % 16 || p.rope_cols % 256 || p.rope_cols % p.rope_hd || ((uintptr_t)p.rope_cs & 15)))
         throw std::runtime_error("gemm_bt8: bad RoPE epilogue parameters");
     if (operand_dtype == DT_F16) launch8_variant<F16>(p, variant, st);

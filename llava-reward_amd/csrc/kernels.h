@@ -72,7 +72,7 @@ void launch_qwen_ca_vec(const int* rstat, const float* u, int B, int D, float* o
 // y[b] = RMSNorm(x[b*S + (use_last_pos ? S-1 : tstat[b].last_valid)])
 void launch_gather_norm_rows(const float* x, const int* tstat, int S, int use_last_pos, const float* w, float eps,
                              float* y, int B, int D, hipStream_t st);
-void launch_rowvec_linear(const float* x, const unsigned short* W_bf16, float* y, int B, int N, int K, hipStream_t st);
+void launch_rowvec_linear(const float* x, const float* W, float* y, int B, int N, int K, hipStream_t st);      // y[b] = W x[b], fp32
 void launch_ca_scores(const float* ev, const float* kq, const int* voff, int B, int Vmax, int D, float scale, float* sc,
                       hipStream_t st);
 void launch_ca_softmax(float* sc, int B, int Vmax, hipStream_t st);
@@ -102,7 +102,8 @@ enum : int { PACK_PLAIN = 0, PACK_SWIGLU = 1, PACK_TRANSPOSE = 2, PACK_ROPE_QKV 
 // aux_hdp > aux_hd every head is stored aux_hdp wide (destination pre-zeroed).  PACK_SWIGLU_GATE/UP accept any row
 // count (destination rows rounded up to 32 and pre-zeroed).  PACK_HEADPAD_COLS pads the heads along the columns.
 void launch_pack(const float* src, void* dst, int rows, int cols, int ld_dst, int cols_dst, int dst_dtype, int mode,
-                 hipStream_t st, int aux_d = 0, int aux_hd = 0, int aux_hdp = 0);
+                 hipStream_t st, int aux_d = 0, int aux_hd = 0, int aux_hdp = 0, void* lo_dst = nullptr, int* inexact = nullptr);
+// lo_dst (operand-typed destinations only): also store round(w - round(w)) in the same layout and set *inexact if any is non-zero
 void launch_cvt_to_f32(const void* src, int src_dtype, float* dst, size_t n, hipStream_t st);
 
 }  // namespace lr

@@ -72,7 +72,7 @@ void build_weight_table_qwen(lr_engine* e) {
     e->vHm = e->vH * e->vunit;
     const int vH = e->vH, vhd = e->vhd, vhdp = e->vhdp, vHp = e->vHp, vI = e->vI, vIp = e->vIp, vHm = e->vHm;
 
-    e->wte = (unsigned short*)oalloc(e, (size_t)d.vocab_size * D);
+    e->wte = (unsigned short*)e->dalloc((size_t)d.vocab_size * D * 2, true);      // bf16 embedding table (not an MFMA operand)
     add_slot(e, "model.embed_tokens.weight", {d.vocab_size, D}, e->wte, D, D, DT_BF16, PACK_PLAIN, 0.02, 0);
     e->vpatch_w = oalloc(e, (size_t)vH * e->vKpad);
     add_slot(e, "visual.patch_embed.proj.weight", {vH, d.vit_in_ch, d.vit_temporal_patch, d.vit_patch, d.vit_patch}, e->vpatch_w,
@@ -144,14 +144,14 @@ void build_weight_table_qwen(lr_engine* e) {
     if (d.add_cross_attention) {
         // W_q and W_k are accepted (they are in the checkpoint, reward_adaptor_loader.py:84-91) but cannot influence the
         // reward: all un-masked K rows are identical, so the softmax is uniform whatever the scores are (rw_model:387-395).
-        e->Wq = (unsigned short*)oalloc(e, (size_t)D * D);
-        e->WkT = (unsigned short*)oalloc(e, (size_t)D * D);
-        e->Wv = (unsigned short*)oalloc(e, (size_t)D * D);
+        e->Wq = falloc(e, (size_t)D * D);
+        e->WkT = falloc(e, (size_t)D * D);
+        e->Wv = falloc(e, (size_t)D * D);
         e->ca_w = falloc(e, D);
         e->ca_u = falloc(e, D);
-        add_slot(e, "W_q.weight", {D, D}, e->Wq, D, D, DT_BF16, PACK_PLAIN, 0.02, 0);
-        add_slot(e, "W_k.weight", {D, D}, e->WkT, D, D, DT_BF16, PACK_PLAIN, 0.02, 0);
-        add_slot(e, "W_v.weight", {D, D}, e->Wv, D, D, DT_BF16, PACK_PLAIN, 0.02, 0);
+        add_slot(e, "W_q.weight", {D, D}, e->Wq, D, D, DT_F32, PACK_PLAIN, 0.02, 0);
+        add_slot(e, "W_k.weight", {D, D}, e->WkT, D, D, DT_F32, PACK_PLAIN, 0.02, 0);
+        add_slot(e, "W_v.weight", {D, D}, e->Wv, D, D, DT_F32, PACK_PLAIN, 0.02, 0);
         vec_slot(e, "ca_layernorm.weight", {D}, e->ca_w, 0.05, 1.0);
     }
     e->vh = falloc(e, (size_t)d.value_head_dim * D);

@@ -481,30 +481,26 @@ void launch_gather_norm_rows(const float* x, const int* tstat, int S, int use_la
     hipLaunchKernelGGL(gather_norm_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, x, tstat, S, use_last_pos, w, eps, y, B, D);
 }
 
-__global__ __launch_bounds__(256) void rowvec_linear_kernel(const float* __restrict__ x, const unsigned short* __restrict__ W,
+__global__ __launch_bounds__(256) void rowvec_linear_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                             float* __restrict__ y, int N, int K) {
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     if (n >= N) return;
-    const float* xr = x + (size_t)b * K;
-    const uint4* wr = (const uint4*)(W + (size_t)n * K);
+    const float4* xr = (const float4*)(x + (size_t)b * K);
+    const float4* wr = (const float4*)(W + (size_t)n * K);
     float s = 0.f;
-    for (int c = lane; c < (K >> 3); c += 64) {
-        const uint4 u = wr[c];
-        const float4 a = *(const float4*)(xr + 8 * c), d = *(const float4*)(xr + 8 * c + 4);
-        s += a.x * bf16_bits_to_f32(u.x & 0xFFFF) + a.y * bf16_bits_to_f32(u.x >> 16) +
-             a.z * bf16_bits_to_f32(u.y & 0xFFFF) + a.w * bf16_bits_to_f32(u.y >> 16) +
-             d.x * bf16_bits_to_f32(u.z & 0xFFFF) + d.y * bf16_bits_to_f32(u.z >> 16) +
-             d.z * bf16_bits_to_f32(u.w & 0xFFFF) + d.w * bf16_bits_to_f32(u.w >> 16);
+    for (int c = lane; c < (K >> 2); c += 64) {
+        const float4 a = xr[c], w = wr[c];
+        s += a.x * w.x + a.y * w.y + a.z * w.z + a.w * w.w;
     }
     s = wave_sum(s);
     if (lane == 0) y[(size_t)b * N + n] = s;
 }
 
-void launch_rowvec_linear(const float* x, const unsigned short* W_bf16, float* y, int B, int N, int K, hipStream_t st) {
+void launch_rowvec_linear(const float* x, const float* W, float* y, int B, int N, int K, hipStream_t st) {
     if (B <= 0) return;
-    if (K % 8) throw std::runtime_error("rowvec_linear: K must be a multiple of 8");
-    hipLaunchKernelGGL(rowvec_linear_kernel, dim3(cdiv(N, 4), B), dim3(256), 0, st, x, W_bf16, y, N, K);
+    if (K % 4) throw std::runtime_error("rowvec_linear: K must be a multiple of 4");
+    hipLaunchKernelGGL(rowvec_linear_kernel, dim3(cdiv(N, 4), B), dim3(256), 0, st, x, W, y, N, K);
 }
 
 // scores over the zero-padded vision rows: rows j >= V_b are all-zero keys -> score 0 (rw_model:381-385
@@ -759,7 +755,7 @@ __device__ __forceinline__ void store_elem(void* dst, size_t i, float v, int dt)
 
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, void* __restrict__ dst, int rows, int cols,
                                                    int ld_dst, int cols_dst, int dst_dtype, int mode, int aux_d, int aux_hd,
-                                                   int aux_hdp) {
+                                                   int aux_hdp, void* __restrict__ lo_dst, int* __restrict__ inexact) {
     const size_t total = (size_t)rows * cols_dst;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int r = (int)(i / cols_dst), c = (int)(i - (size_t)r * cols_dst);
@@ -789,11 +785,18 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
             o = (size_t)r * ld_dst + c;
         }
         store_elem(dst, o, v, dst_dtype);
+        if (lo_dst) {          // rounding residual of the weight in the operand type (same layout); non-zero anywhere = inexact weight
+            float r;
+            if (dst_dtype == DT_F16) r = v - Op<F16>::to_f32(Op<F16>::from_f32(v));
+            else r = v - Op<BF16>::to_f32(Op<BF16>::from_f32(v));
+            store_elem(lo_dst, o, r, dst_dtype);
+            if (r != 0.f && inexact) *inexact = 1;         // benign race: every writer stores 1
+        }
     }
 }
 
 void launch_pack(const float* src, void* dst, int rows, int cols, int ld_dst, int cols_dst, int dst_dtype, int mode,
-                 hipStream_t st, int aux_d, int aux_hd, int aux_hdp) {
+                 hipStream_t st, int aux_d, int aux_hd, int aux_hdp, void* lo_dst, int* inexact) {
     const size_t total = (size_t)rows * cols_dst;
     if (!total) return;
     if (mode == PACK_SWIGLU && ((rows >> 1) % 32)) throw std::runtime_error("pack: SwiGLU interleave needs I % 32 == 0");
@@ -801,7 +804,7 @@ void launch_pack(const float* src, void* dst, int rows, int cols, int ld_dst, in
     if (mode == PACK_ROPE_QKV && (aux_hd < 2 || aux_d % aux_hd)) throw std::runtime_error("pack: bad RoPE section geometry");
     if (aux_hdp <= 0) aux_hdp = aux_hd;
     const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
-    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, st, src, dst, rows, cols, ld_dst, cols_dst, dst_dtype, mode, aux_d, aux_hd, aux_hdp);
+    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, st, src, dst, rows, cols, ld_dst, cols_dst, dst_dtype, mode, aux_d, aux_hd, aux_hdp, lo_dst, inexact);
 }
 
 __global__ __launch_bounds__(256) void cvt_to_f32_kernel(const void* __restrict__ src, int dt, float* __restrict__ dst, size_t n) {

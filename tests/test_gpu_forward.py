@@ -197,3 +197,42 @@ def test_reference_golden_full_size(path, dtype):
     dup = {k: np.concatenate([v, v]) for k, v in batch.items()}
     r2 = _fwd(m, dup)
     assert torch.equal(r2[0], r2[1]) and torch.equal(r2[0], got.reshape(r2[0].shape))
+
+
+@pytest.mark.parametrize("backbone", ["phi3v", "qwen"])
+def test_parity_mode_with_inexact_weights(backbone):
+    """Weights that are NOT bf16-valued (what a LoRA merge W + (alpha/r) B A leaves behind): the split-operand mode carries
+    the weights' rounding residuals as a third K segment, [x_hi | x_lo | x_hi] x [W | W | W_lo], and still matches the fp32
+    oracle run on the same fp32 weights; the single-pass f16 mode shows the extra weight-rounding error."""
+    if backbone == "phi3v":
+        cfg = synth.tiny_config()
+        Wn = synth.make_weights(cfg, 17)
+        batch = synth.synth_batch(cfg, 17, [7, 3, 5], [(1, 1), (1, 2), (2, 1)], max_crops=4)
+    else:
+        cfg = synth.qwen_tiny_config()
+        Wn = synth.qwen_make_weights(cfg, 17)
+        batch = synth.qwen_synth_batch(cfg, 17, [7, 3, 5], [(16, 16), (10, 6), (18, 22)])
+    g = torch.Generator().manual_seed(5)
+    W = {}
+    for k, v in Wn.items():
+        t = torch.from_numpy(v)
+        if t.dim() >= 2 and "embed_tokens" not in k:          # every matrix gets an fp32 perturbation below its bf16 ulp
+            t = t * (1.0 + 2.0 ** -10 * (torch.rand(t.shape, generator=g) - 0.5))
+        W[k] = t.float()
+    if backbone == "phi3v":
+        ref = orc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"])
+    else:
+        from oracle import qwen2_5_vl_reward_oracle as qorc
+        ref = qorc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_grid_thw"])
+    errs = {}
+    for dtype in ("f16x2", "f16"):
+        m = RewardModel(cfg, weights=W, max_batch=4, max_seq=1024, max_crops=5, max_patches=4096, operand_dtype=dtype).to("cuda").eval()
+        tb = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
+        if backbone == "phi3v":
+            r, _ = m.custom_forward(tb["input_ids"], tb["attention_mask"], tb["pixel_values"], tb["image_sizes"])
+        else:
+            r, _ = m.custom_forward(inputs_batch=tb)
+        torch.cuda.synchronize()
+        errs[dtype] = (r.cpu() - ref).abs().max().item()
+    print(f"[inexact weights, {backbone}] f16x2 err {errs['f16x2']:.2e}   f16 err {errs['f16']:.2e}")
+    assert errs["f16x2"] < TOL_X2 and errs["f16"] < 3e-3
