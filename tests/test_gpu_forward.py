@@ -236,3 +236,27 @@ def test_parity_mode_with_inexact_weights(backbone):
         errs[dtype] = (r.cpu() - ref).abs().max().item()
     print(f"[inexact weights, {backbone}] f16x2 err {errs['f16x2']:.2e}   f16 err {errs['f16']:.2e}")
     assert errs["f16x2"] < TOL_X2 and errs["f16"] < 3e-3
+
+
+def test_right_padding_single_row_and_all_padding_row():
+    """Edge cases of the EOS gather (rw_model:420: S-1-argmax(flip(mask))): right padding, a batch of one, and a row whose
+    mask is all zero (argmax of zeros = 0 -> index S-1; the reference scores garbage there without failing, so must we)."""
+    cfg = synth.tiny_config(is_general_preference=True, value_head_dim=2)
+    seed = 23
+    b = synth.synth_batch(cfg, seed, [6, 2], (1, 1))
+    S = b["input_ids"].shape[1]
+    ids, mask = b["input_ids"].copy(), b["attention_mask"].copy()
+    n1 = int(mask[1].sum())
+    ids[1] = np.concatenate([b["input_ids"][1][S - n1:], np.full(S - n1, b["input_ids"][1][0])])      # row 1: right padded
+    mask[1] = np.concatenate([np.ones(n1, dtype=np.int64), np.zeros(S - n1, dtype=np.int64)])
+    batch = dict(b, input_ids=ids, attention_mask=mask)
+    W = orc.weights_to_torch(synth.make_weights(cfg, seed))
+    ref = orc.custom_forward(W, cfg, ids, mask, b["pixel_values"], b["image_sizes"])
+    m = _model(cfg, seed, "f16x2", upload=False)
+    got = _fwd(m, batch)
+    assert (got - ref).abs().max().item() < TOL_X2
+    one = _fwd(m, batch, rows=slice(1, 2))                        # B = 1
+    assert torch.equal(one[0], got[1])
+    dead = dict(batch, attention_mask=np.concatenate([mask[:1], np.zeros((1, S), dtype=np.int64)]))
+    r = _fwd(m, dead)                                             # row 1 fully masked: finite-or-not, row 0 must be untouched
+    assert torch.equal(r[0], got[0]) and r.shape == got.shape

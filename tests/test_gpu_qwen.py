@@ -245,3 +245,33 @@ def test_scoring_loop_all_backbones():
     po = score_pairwise(pm, args, [(pb1, pb1, None, None)])
     d, _ = pm.custom_forward(pb["input_ids"].cuda(), pb["attention_mask"].cuda(), pb["pixel_values"].cuda(), pb["image_sizes"].cuda())
     assert po["chosen_rewards"] == d.cpu().squeeze(-1).tolist() and po["probs"] == [0.5, 0.5]
+
+
+def test_qwen_two_images_in_one_row_and_right_padding():
+    """Rows are not limited to one image: image_grid_thw lists the images in slot order (row-major) and every image run
+    advances the 3-D positions by max(h, w) / merge (get_rope_index).  Row 0 carries two images, row 1 one image and RIGHT
+    padding (the reward is read at the last valid token, rw_model:420)."""
+    cfg = synth.qwen_tiny_config()
+    seed = 51
+    one = synth.qwen_synth_batch(cfg, seed, [3, 4], [(8, 8), (6, 4)])
+    extra = synth.qwen_synth_batch(cfg, seed + 1, [2], [(4, 12)])
+    im = cfg.image_token_id
+    row0 = np.concatenate([one["input_ids"][0][one["attention_mask"][0] == 1][:-1], [7], np.full(12, im), [8, 9]])
+    row1 = one["input_ids"][1][one["attention_mask"][1] == 1]
+    S = max(len(row0), len(row1)) + 3
+    ids = np.full((2, S), cfg.pad_token_id, dtype=np.int64)
+    mask = np.zeros((2, S), dtype=np.int64)
+    ids[0, S - len(row0):] = row0; mask[0, S - len(row0):] = 1            # left padding
+    ids[1, :len(row1)] = row1; mask[1, :len(row1)] = 1                    # right padding
+    n0 = 8 * 8
+    pix = np.concatenate([one["pixel_values"][:n0], extra["pixel_values"], one["pixel_values"][n0:]])
+    grid = np.array([[1, 8, 8], [1, 4, 12], [1, 6, 4]], dtype=np.int64)
+    batch = dict(input_ids=ids, attention_mask=mask, pixel_values=pix, image_grid_thw=grid)
+    ref = _oracle(cfg, seed, batch)
+    m = _model(cfg, seed, "f16x2", upload=False)
+    got = _fwd(m, batch)
+    err = (got - ref).abs().max().item()
+    print(f"[qwen 2 images / right padding] max |reward err| = {err:.3e}")
+    assert err < 1e-4
+    pos = m.engine.read_tap("pos3", 3 * 2 * S).reshape(3, 2, S).astype(np.int64)
+    assert np.array_equal(pos, synth.qwen_rope_index(ids, mask, grid.tolist(), cfg))
