@@ -81,7 +81,7 @@ typedef struct lr_model_desc {
      * patches merged per LLM token.  Decoder: GQA with q/k/v bias, multimodal RoPE (inv_freq_short = 1/theta^(2i/hd);
      * frequency i follows the temporal / height / width position for i < s0, < s0+s1, < s0+s1+s2).  SkipCA as written
      * in the reference: K/V rows are the embedding rows of the tokens equal to ca_token_id (151643, rw_model:358).
-     * Capacity: max_patches = ViT tokens (rows of pixel_values) per lr_forward_qwen call, at most max_batch images. */
+     * Capacity: max_patches = ViT tokens (rows of pixel_values) per lr_forward_qwen call, at most 4 * max_batch images. */
     int32_t vit_depth, vit_hidden, vit_heads, vit_intermediate, vit_patch, vit_temporal_patch, vit_merge, vit_window, vit_in_ch;
     int32_t vit_n_fullatt, vit_fullatt[LR_MAX_FULLATT];
     float vit_rope_theta, vit_eps;

@@ -13,12 +13,14 @@
 
 namespace {
 
+constexpr int LR_QWEN_IMAGES_PER_ROW = 4;      // capacity of the per-call image table: 4 images per row on average
+
 struct QwenTables {       // byte offsets inside one slot of the per-forward table ring
     size_t src, hw, slot2row, items_win, items_full, imgs, total;
 };
 
 QwenTables qwen_table_layout(const lr_model_desc& d) {
-    const size_t P = d.max_patches, M = P / (size_t)(d.vit_merge * d.vit_merge), NI = d.max_batch;
+    const size_t P = d.max_patches, M = P / (size_t)(d.vit_merge * d.vit_merge), NI = (size_t)LR_QWEN_IMAGES_PER_ROW * d.max_batch;
     QwenTables t;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
@@ -216,7 +218,8 @@ extern "C" int lr_forward_qwen(lr_handle h, const int64_t* input_ids, const int6
         const lr_model_desc& d = h->d;
         if (B < 1 || B > d.max_batch) throw std::invalid_argument("lr_forward_qwen: batch exceeds max_batch");
         if (S < 1 || S > d.max_seq) throw std::invalid_argument("lr_forward_qwen: sequence exceeds max_seq");
-        if (n_images < 1 || n_images > d.max_batch) throw std::invalid_argument("lr_forward_qwen: n_images must be in [1, max_batch]");
+        if (n_images < 1 || n_images > LR_QWEN_IMAGES_PER_ROW * d.max_batch)
+            throw std::invalid_argument("lr_forward_qwen: n_images must be in [1, 4 * max_batch]");
         if (pix_dtype != LR_DT_F32 && pix_dtype != LR_DT_BF16) throw std::invalid_argument("lr_forward_qwen: pixel dtype must be F32 or BF16");
         hipStream_t st = (hipStream_t)hip_stream;
         const int D = d.hidden, m = d.vit_merge, unit = h->vunit;
