@@ -17,6 +17,9 @@
 // phase <= g+2 of the lagging wave group (WAR) => NS - PF >= 4.  NS = 10 slots = all 160 KB of LDS.
 // Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA segment while
 // its partner issues LDS reads / DMA.
+// PB = 1 (product): the LOAD segments are the critical path (~300-350 cycles against 256 of MFMA), so the B fragments are
+// kept in two register sets -- B0 for the whole K-tile (read once instead of twice), B1 -- and requested from inside the
+// previous COMPUTE segment; LOAD keeps only the 8 A reads of phases 0 and 2.  +12 VGPRs, 2-5 % on every shape.
 // Measured (MI355X, random data): main loop 1.16-1.28 PFLOP/s on every shape of the path; direct
 // stores from the C/D layout cost 30 % of all GEMM time and a per-tile relaunch exposes the store
 // acknowledgements, hence the staged epilogue and the persistent tile loop.
@@ -35,7 +38,7 @@ namespace lr {
 //      Diagnostics for tools/gemm_bench.py / tools/gemm_stamps.py only.
 // EPI is a template parameter so that each instantiation carries ONE epilogue: with all of them
 // unrolled in one kernel the code was ~130 KB and every tile's epilogue ran out of the instruction cache.
-template <typename OT, int PF, int NS, int DBG, int EPI>
+template <typename OT, int PF, int NS, int DBG, int EPI, int PB>
 __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
     constexpr int E_ = EPI & 15;          // epilogue selector; bit 4 = bias present (SwiGLU / RoPE epilogues)
     constexpr bool BIAS_ = (EPI & 16) != 0;
@@ -162,13 +165,24 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
             if (g < Gtot) issue(g & 3, g >> 2, islot);
             islot = (islot + 1 == NS) ? 0 : islot + 1;
         }
-        constexpr int WAITN = 2 * (PF - 2);
-        if (Gtot > PF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PF - 2)) : "memory");
+        // PB = 0: at the wait of LOAD(P) everything up to half-tile P+2 has landed (this wave's pieces); a half-tile is first read
+        // at phase >= g-1, i.e. after the OTHER wave group's LOAD(P-1) wait as well.  PB = 1 reads half-tile P+2 inside COMPUTE(P),
+        // while the lagging group is still in ITS LOAD(P): its last completed wait is LOAD(P-1), which therefore has to retire
+        // up to (P-1)+3 -- one half-tile more per wait, paid for with one more half-tile of prefetch (PF 6 instead of 5).
+        constexpr int WAITN = PB ? 2 * (PF - 3) : 2 * (PF - 2);
+        if (Gtot > PF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         LR_BARRIER();
         if (wr == 1) LR_BARRIER();                      // stagger the second wave group by one barrier
 
-        uint4 af[8], bf[4];
+        // PB = 1: two B fragment sets.  bf holds B0 for the whole K-tile (phases 0 and 3, read once), bg holds B1 (phases 1, 2); both
+        // are requested from inside the preceding COMPUTE segment (bg during phase 0, the next K-tile's bf after phase 3's last
+        // MFMA), so the LOAD segments of phases 1 and 3 carry no LDS reads and those of phases 0 and 2 only the 8 A reads.
+        uint4 af[8], bf[4], bg[PB ? 4 : 1];
+        if constexpr (PB == 1 && DBG != 4) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) bf[f] = *(const uint4*)(smem + 1 * HT + boff[f]);      // B0 of K-tile 0 (slot 1)
+        }
         int rslot = 0;         // ring slot of half-tile A0 of the current K-tile
         int gi = PF;           // index of the next half-tile to issue
 
@@ -186,7 +200,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 if constexpr (DBG == 3) t0 = stamp();
                 // ---------------- LOAD ----------------
                 const bool more = gi < Gtot;
-                if constexpr (DBG != 4)
+                if constexpr (DBG != 4 && PB == 0)
                 if (ph == 0 || ph == 1 || ph == 3) {
                     const char* sb = (ph == 1) ? sB1 : sB0;
 #pragma unroll
@@ -211,6 +225,12 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 if constexpr (DBG == 3) t2 = stamp();
                 // ---------------- COMPUTE ----------------
                 __builtin_amdgcn_s_setprio(1);
+                if constexpr (PB == 1 && DBG != 4) {
+                    if (ph == 0) {                   // B1 of this K-tile: landed with the wait of LOAD(ph 0), first used in phase 1
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) bg[f] = *(const uint4*)(sB1 + boff[f]);
+                    }
+                }
                 if constexpr (DBG != 4)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
@@ -218,8 +238,20 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            acc[ph][i][j] = Op<OT>::mfma16(af[i * 2 + ks], bf[j * 2 + ks], acc[ph][i][j]);
+                            if constexpr (PB == 1) {
+                                const uint4 bb = (ph == 1 || ph == 2) ? bg[j * 2 + ks] : bf[j * 2 + ks];
+                                acc[ph][i][j] = Op<OT>::mfma16(af[i * 2 + ks], bb, acc[ph][i][j]);
+                            } else {
+                                acc[ph][i][j] = Op<OT>::mfma16(af[i * 2 + ks], bf[j * 2 + ks], acc[ph][i][j]);
+                            }
                         }
+                if constexpr (PB == 1 && DBG != 4) {
+                    if (ph == 3 && kt + 1 < nk) {    // B0 of the next K-tile (half-tile P + 2: landed with the wait of LOAD(ph 3))
+                        int sn = rslot + 5; sn = sn >= NS ? sn - NS : sn;
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) bf[f] = *(const uint4*)(smem + sn * HT + boff[f]);
+                    }
+                }
                 __builtin_amdgcn_s_setprio(0);
                 if constexpr (DBG == 3) t3 = stamp();
                 LR_BARRIER();
@@ -440,12 +472,12 @@ static int num_cus() {
     return n;
 }
 
-template <typename OT, int PF, int DBG, int EPI>
+template <typename OT, int PF, int DBG, int EPI, int PB = 0>
 static void launch8(const GemmParams& p, bool persistent, hipStream_t st) {
     constexpr int NS = 10;
     constexpr int smem = NS * 16384;
     static bool attr_set = false;
-    auto kfn = gemm_bt8_kernel<OT, PF, NS, DBG, EPI>;
+    auto kfn = gemm_bt8_kernel<OT, PF, NS, DBG, EPI, PB>;
     if (!attr_set) {
         LR_HIP_CHECK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
@@ -456,19 +488,19 @@ static void launch8(const GemmParams& p, bool persistent, hipStream_t st) {
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), smem, st, p);
 }
 
-template <typename OT, int PF, int DBG>
+template <typename OT, int PF, int DBG, int PB = 0>
 static void launch8_epi(const GemmParams& p, bool persistent, hipStream_t st) {
     switch (p.epi) {
-        case EPI_OUT_OP: launch8<OT, PF, DBG, EPI_OUT_OP>(p, persistent, st); break;
-        case EPI_OUT_F32: launch8<OT, PF, DBG, EPI_OUT_F32>(p, persistent, st); break;
-        case EPI_RESADD_F32: launch8<OT, PF, DBG, EPI_RESADD_F32>(p, persistent, st); break;
+        case EPI_OUT_OP: launch8<OT, PF, DBG, EPI_OUT_OP, PB>(p, persistent, st); break;
+        case EPI_OUT_F32: launch8<OT, PF, DBG, EPI_OUT_F32, PB>(p, persistent, st); break;
+        case EPI_RESADD_F32: launch8<OT, PF, DBG, EPI_RESADD_F32, PB>(p, persistent, st); break;
         case EPI_SWIGLU_OP:
-            if (p.bias) launch8<OT, PF, DBG, EPI_SWIGLU_OP | 16>(p, persistent, st);
-            else launch8<OT, PF, DBG, EPI_SWIGLU_OP>(p, persistent, st);
+            if (p.bias) launch8<OT, PF, DBG, EPI_SWIGLU_OP | 16, PB>(p, persistent, st);
+            else launch8<OT, PF, DBG, EPI_SWIGLU_OP, PB>(p, persistent, st);
             break;
         case EPI_ROPE_OP:
-            if (p.bias) launch8<OT, PF, DBG, EPI_ROPE_OP | 16>(p, persistent, st);
-            else launch8<OT, PF, DBG, EPI_ROPE_OP>(p, persistent, st);
+            if (p.bias) launch8<OT, PF, DBG, EPI_ROPE_OP | 16, PB>(p, persistent, st);
+            else launch8<OT, PF, DBG, EPI_ROPE_OP, PB>(p, persistent, st);
             break;
         default: throw std::runtime_error("gemm_bt8: unknown epilogue");
     }
@@ -478,7 +510,8 @@ template <typename OT>
 static void launch8_variant(const GemmParams& p, int variant, hipStream_t st) {
     switch (variant) {
         case 3: case 5: launch8_epi<OT, 5, 0>(p, false, st); break;
-        case 4: case 6: launch8_epi<OT, 5, 0>(p, true, st); break;       // persistent walk (A/B)
+        case 4: launch8_epi<OT, 5, 0>(p, true, st); break;               // persistent walk, B fragments read in the LOAD segments (A/B)
+        case 6: launch8_epi<OT, 6, 0, 1>(p, true, st); break;            // product: persistent walk + B fragments prefetched inside COMPUTE
         case 7: launch8<OT, 5, 1, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: cache-resident operands
         case 8: launch8<OT, 5, 2, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: no epilogue
         case 9: launch8<OT, 5, 3, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: in-kernel stamps -> `bias` buffer

@@ -352,3 +352,20 @@ def test_attention_split_operand_matches_fp32(lib, hd, causal, group):
     valid = (mask.reshape(-1) != 0) if causal else torch.ones(B * S, dtype=torch.bool, device="cuda")
     err = (got - ref).abs()[valid].max().item()
     assert err < 5e-6 * ref[valid].abs().max().item(), err
+
+
+@pytest.mark.parametrize("tile", [4, 6])
+@pytest.mark.parametrize("shape", [(8192, 8192, 512), (5284, 9216, 3072), (8192, 8192, 128)])
+def test_gemm_persistent_walk_many_tiles(lib, tile, shape):
+    """More output tiles than CUs: every workgroup of the persistent kernel walks several tiles, and the ring, the fragment
+    prefetch of variant 6 and the staging epilogue are re-entered back to back (a race here shows up as scattered garbage,
+    not as a small error).  Checked against torch's fp32 matmul of the same f16 operands."""
+    M, N, K = shape
+    A = rnd((M, K), 81).to(torch.float16)
+    W = rnd((N, K), 82, 0.05).to(torch.float16)
+    out = torch.zeros(M, N, device="cuda", dtype=torch.float32)
+    assert lib.lr_op_gemm_bt(P(A), P(W), P(out), P(None), M, N, K, K, K, N, L.EPI_OUT_F32, 0, L.LR_DT_F16, tile, stream()) == 0
+    torch.cuda.synchronize()
+    ref = A.float() @ W.float().t()
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() < 2e-5 * ref.abs().max().item() * max(1.0, (K / 512) ** 0.5)
