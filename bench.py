@@ -31,8 +31,8 @@ PEAK_TFLOPS = 2500.0              # dense bf16/f16 MFMA, MI355X_MICROARCH.md "Ch
 
 def cpu_baseline(cfg_full):
     """Time the CPU oracle (oracle/phi3v_reward_oracle.py, 'port') on a bounded sample of the same
-    workload (10-30 s of CPU work): ONE row at full shapes, run with 1 and with 3 layers of each tower; the
-    per-layer cost is half the difference of the two runs and is scaled to the full depth (every layer of
+    workload (10-30 s of CPU work): ONE row at full shapes, run with 2 and with 6 layers of each tower; the
+    per-layer cost is a quarter of the difference of the two runs and is scaled to the full depth (every layer of
     a tower has identical shapes)."""
     import dataclasses
     from llava_reward_amd import synth
@@ -61,7 +61,7 @@ def cpu_baseline(cfg_full):
     batch = synth.synth_batch(cfg_full, 1234, [128], (4, 4), with_pixels=False)
     pix = torch.randn(1, 17, 3, 336, 336, generator=g)
     times = {}
-    for nl in (1, 3):
+    for nl in (2, 6):
         cfg = dataclasses.replace(cfg_full, layers=nl, clip=dataclasses.replace(cfg_full.clip, layers_used=nl))
         W = weights(cfg)
         t0 = time.time()
@@ -72,14 +72,14 @@ def cpu_baseline(cfg_full):
         t2 = time.time()
         times[nl] = (t1 - t0, t2 - t1)
         del W, feats
-    clip_layer = max((times[3][0] - times[1][0]) / 2, 1e-6)
-    clip_base = max(times[1][0] - clip_layer, 0.0)
-    dec_layer = max((times[3][1] - times[1][1]) / 2, 1e-6)
-    dec_base = max(times[1][1] - dec_layer, 0.0)
+    clip_layer = max((times[6][0] - times[2][0]) / 4, 1e-6)
+    clip_base = max(times[2][0] - 2 * clip_layer, 0.0)
+    dec_layer = max((times[6][1] - times[2][1]) / 4, 1e-6)
+    dec_base = max(times[2][1] - 2 * dec_layer, 0.0)
     total = clip_base + cfg_full.clip.layers_used * clip_layer + dec_base + cfg_full.layers * dec_layer
     spent = sum(a + b for a, b in times.values())
     return {"value": 1.0 / total, "unit": "reward-pairs/sec", "cores": cores, "kind": "port",
-            "sample": f"1 row at full shapes (17 crops, S={batch['input_ids'].shape[1]}); 1 + 3 of 23 CLIP and 1 + 3 of 32 decoder layers "
+            "sample": f"1 row at full shapes (17 crops, S={batch['input_ids'].shape[1]}); 2 + 6 of 23 CLIP and 2 + 6 of 32 decoder layers "
                       f"timed ({spent:.1f}s CPU), per-layer cost scaled to full depth -> {total:.1f}s per row, fp32 torch"}
 
 
