@@ -157,6 +157,115 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[q][i][j][r] = 0.f;
 
+        if constexpr (PB == 2) {
+        // ================= super-phase schedule (product) =================
+        // Two quadrants per barrier interval: LOAD = 8 A reads + both half-tiles of the interval by LDS-DMA + counted wait;
+        // COMPUTE = 32 MFMAs (an A half against B0 and B1) with the 4 B reads of the next use riding inside it.  Half the
+        // barriers and priority flips per K-tile, and the LOAD segment (the critical path of the 4-phase form) is shorter than
+        // its partner's COMPUTE.  Super-phase Q = 2 kt + s:
+        //   LOAD(2kt)    af <- A0(kt)                 issue half-tiles 4kt+8, 4kt+9     wait: all but the newest 4 half-tiles landed
+        //   COMPUTE(2kt)   bg <- B1(kt);  (0,0) = af x bf;  (0,1) = af x bg
+        //   LOAD(2kt+1)  af <- A1(kt)                 issue half-tiles 4kt+10, 4kt+11
+        //   COMPUTE(2kt+1) (1,0) = af x bf;  bf <- B0(kt+1);  (1,1) = af x bg
+        // RAW: a read inside COMPUTE(Q) of the leading group needs the LAGGING group's LOAD(Q-1) wait (it is still inside its own
+        // LOAD(Q)), a read in LOAD(Q+1) its LOAD(Q) wait; with 8 half-tiles issued ahead and 4 allowed in flight LOAD(Q) retires
+        // 2Q+5: B1(kt) = 4kt+2 <= 2(2kt-1)+5, A1 = 4kt+3 and B0(kt+1) = 4kt+5 <= 2(2kt)+5, A0(kt+1) = 4kt+4 <= 2(2kt+1)+5.
+        // WAR: half-tile g+NS is issued at LOAD(floor((g+NS-8)/2)); the lagging group is then in COMPUTE of the interval before
+        // and its reads of g (A0: LOAD(g/2); B1: COMPUTE(g/2-1); A1: LOAD((g-1)/2); B0: COMPUTE((g-5)/2)) are behind it iff NS-8 >= 2.
+        constexpr int PF2 = 8, WAIT2 = 2 * (PF2 - 4);
+        static_assert(NS - PF2 >= 2, "ring hazard distances (super-phase schedule)");
+        int islot = 0;
+#pragma unroll
+        for (int g = 0; g < PF2; ++g) {
+            if (g < Gtot) issue(g & 3, g >> 2, islot);
+            islot = (islot + 1 == NS) ? 0 : islot + 1;
+        }
+        if (Gtot > PF2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT2) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LR_BARRIER();
+        if (wr == 1) LR_BARRIER();                      // stagger the second wave group by one barrier
+        uint4 af[8], bf[4], bg[4];
+        if constexpr (DBG != 4) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) bf[f] = *(const uint4*)(smem + 1 * HT + boff[f]);      // B0 of K-tile 0 (slot 1)
+        }
+        int rslot = 0, gi = PF2;
+        for (int kt = 0; kt < nk; ++kt) {
+            int s2 = rslot + 2; s2 = s2 >= NS ? s2 - NS : s2;
+            int s3 = rslot + 3; s3 = s3 >= NS ? s3 - NS : s3;
+            int s5 = rslot + 5; s5 = s5 >= NS ? s5 - NS : s5;
+            const char* sA0 = smem + rslot * HT;
+            const char* sB1 = smem + s2 * HT;
+            const char* sA1 = smem + s3 * HT;
+            const char* sB0n = smem + s5 * HT;
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+                if constexpr (DBG == 3) t0 = stamp();
+                // ---------------- LOAD ----------------
+                const bool more = gi < Gtot;
+                if constexpr (DBG != 4) {
+                    const char* sa = sp == 0 ? sA0 : sA1;
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) af[f] = *(const uint4*)(sa + aoff[f]);
+                }
+                if (more) {
+                    if constexpr (DBG != 5) {
+                        issue(2 * sp, kt + 2, islot);
+                        islot = (islot + 1 == NS) ? 0 : islot + 1;
+                        issue(2 * sp + 1, kt + 2, islot);
+                        islot = (islot + 1 == NS) ? 0 : islot + 1;
+                    }
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT2) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                gi += 2;
+                if constexpr (DBG == 3) t1 = stamp();
+                LR_BARRIER();
+                if constexpr (DBG == 3) t2 = stamp();
+                // ---------------- COMPUTE ----------------
+                __builtin_amdgcn_s_setprio(1);
+                if constexpr (DBG != 4) {
+                    if (sp == 0) {
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) bg[f] = *(const uint4*)(sB1 + boff[f]);
+                    }
+                    constexpr int q0 = 0, q1 = 1, q3 = 3, q2 = 2;
+                    const int qa = sp == 0 ? q0 : q3, qb = sp == 0 ? q1 : q2;      // first block uses bf (B0), second bg (B1)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acc[qa][i][j] = Op<OT>::mfma16(af[i * 2 + ks], bf[j * 2 + ks], acc[qa][i][j]);
+                    if (sp == 1 && kt + 1 < nk) {
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) bf[f] = *(const uint4*)(sB0n + boff[f]);
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acc[qb][i][j] = Op<OT>::mfma16(af[i * 2 + ks], bg[j * 2 + ks], acc[qb][i][j]);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                if constexpr (DBG == 3) t3 = stamp();
+                LR_BARRIER();
+                if constexpr (DBG == 3) {
+                    t4 = stamp();
+                    if (sp == 0) { const unsigned long long t5 = stamp(); lsegs[0] += (unsigned)(t5 - t4); }   // cost of one stamp
+                    segs[sp][0] += (unsigned)(t1 - t0); segs[sp][1] += (unsigned)(t2 - t1);
+                    segs[sp][2] += (unsigned)(t3 - t2); segs[sp][3] += (unsigned)(t4 - t3);
+                }
+            }
+            rslot += 4;
+            rslot = rslot >= NS ? rslot - NS : rslot;
+        }
+        if (wr == 0) LR_BARRIER();                      // balance the stagger barrier
+        } else {
+        // ================= 4-phase schedule (A/B variants 3-5) =================
         // ---- prologue: PF half-tiles in flight, the first two landed.  (Stores of the previous tile's
         //      epilogue are older than these DMAs in the vmcnt queue: the wait covers them too.) ----
         int islot = 0;         // ring slot of the next half-tile to issue
@@ -266,6 +375,8 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
             rslot = rslot >= NS ? rslot - NS : rslot;
         }
         if (wr == 0) LR_BARRIER();                      // balance the stagger barrier
+
+        }
 
         if constexpr (DBG == 3) {   // diagnostic: write the segment sums of blocks 0..7 to the buffer passed as `bias`
             if (blockIdx.x < 8 && lane == 0 && vb == (int)blockIdx.x) {
@@ -511,7 +622,9 @@ static void launch8_variant(const GemmParams& p, int variant, hipStream_t st) {
     switch (variant) {
         case 3: case 5: launch8_epi<OT, 5, 0>(p, false, st); break;
         case 4: launch8_epi<OT, 5, 0>(p, true, st); break;               // persistent walk, B fragments read in the LOAD segments (A/B)
-        case 6: launch8_epi<OT, 6, 0, 1>(p, true, st); break;            // product: persistent walk + B fragments prefetched inside COMPUTE
+        case 6: launch8_epi<OT, 6, 0, 2>(p, true, st); break;            // product: persistent walk, super-phase schedule
+        case 10: launch8_epi<OT, 6, 0, 1>(p, true, st); break;           // A/B: 4-phase schedule + B fragments prefetched inside COMPUTE
+        case 13: launch8<OT, 6, 3, EPI_OUT_F32, 2>(p, false, st); break;  // diagnostic only: stamps of the super-phase schedule
         case 7: launch8<OT, 5, 1, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: cache-resident operands
         case 8: launch8<OT, 5, 2, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: no epilogue
         case 9: launch8<OT, 5, 3, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: in-kernel stamps -> `bias` buffer

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, "llava-reward_amd"))
 import torch
 from llava_reward_amd import _lib as L
 lib = L.load()
-VARIANT = int(sys.argv[1]) if len(sys.argv) > 1 else 9      # 9 = stamped build of the product schedule
+VARIANT = int(sys.argv[1]) if len(sys.argv) > 1 else 13     # 13 = stamped build of the product (super-phase) schedule; 9 = 4-phase form
 M, N, K = 84544, 16384, 3072
 A = torch.randn(M, K, device="cuda").to(torch.float16)
 W = (torch.randn(N, K, device="cuda") * 0.02).to(torch.float16)
@@ -25,6 +25,6 @@ names = ["LOAD", "BAR1", "COMP", "BAR2"]
 for grp, waves in (("group0 (waves 0-3)", [0, 1, 2, 3]), ("group1 (waves 4-7)", [4, 5, 6, 7])):
     m = d[:, waves].mean(axis=(0, 1))
     print(grp)
-    for ph in range(4):
-        print("   phase %d: " % ph + "  ".join(f"{names[k]} {m[ph, k]:6.0f}" for k in range(4)) + f"   sum {m[ph].sum():6.0f}")
+    for ph in range(2 if VARIANT == 13 else 4):
+        print("   %s %d: " % ("super-phase" if VARIANT == 13 else "phase", ph) + "  ".join(f"{names[k]} {m[ph, k]:6.0f}" for k in range(4)) + f"   sum {m[ph].sum():6.0f}")
     print(f"   per K-tile: {m.sum():.0f} cycles (MFMA issue floor per wave: 4 x 256 = 1024)")
