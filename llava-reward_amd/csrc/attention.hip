@@ -53,8 +53,10 @@ constexpr int ATT_MAX_S = 8192;        // keys covered by the LDS bitmask
 // PREC (split-operand mode): Q, K, V rows carry their rounding residuals p.lo_off columns to the right; both
 // contractions are evaluated as hi.hi + hi.lo + lo.hi (the lo.lo term is below 2^-22), P is split the same way in
 // registers, and O leaves as [O_hi | O_lo].  K_lo / V_lo tiles ride in the same ring slot as K / V.
-template <typename OT, int HD, bool CAUSAL, bool PREC>
-__global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 waves/SIMD: <= 256 unified registers, MFMA results stay in VGPRs
+// NW = waves per workgroup: 4 (128 queries; two workgroups share a CU when LDS allows) or 8 (256 queries on one K/V ring: used
+// by the split-operand mode, whose ring fills the LDS, so that every SIMD still holds two waves; waves 4-7 issue no DMA).
+template <typename OT, int HD, bool CAUSAL, bool PREC, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnParams p) {   // <= 256 unified registers per wave, MFMA results stay in VGPRs
     constexpr int KT = 64;                 // keys per tile
     constexpr int KSTEPS = HD / 16;        // MFMA k-steps over the head dim
     constexpr int DT = HD / 32;            // 32-wide output tiles over the head dim
@@ -81,11 +83,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
         const int4 it = p.items[blockIdx.x];
         rowbase = (size_t)it.x; S = it.y; qt = it.z;
     } else {
-        const int nqt = (S + 127) / 128;
+        const int nqt = (S + NW * 32 - 1) / (NW * 32);
         qt = nqt - 1 - (int)blockIdx.x;            // heavy (late) causal tiles first
         rowbase = (size_t)b * S;
     }
-    const int q0 = qt * 128 + wave * 32;
+    const int q0 = qt * (NW * 32) + wave * 32;
 
     const unsigned short* Qp = (const unsigned short*)p.Q + p.qoff + head * HD;
     const int kvh = head / p.kv_group;                 // GQA: several query heads share one key/value head
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
     // ---- key range of this workgroup ----
     int kbeg = 0, kend = S;
     if (CAUSAL) {
-        kend = min(S, qt * 128 + 128);
+        kend = min(S, qt * (NW * 32) + NW * 32);
         if (p.kmin) kbeg = (min(p.kmin[b * p.kmin_stride], S) / KT) * KT;
     }
     const int ntiles = kbeg < kend ? (kend - kbeg + KT - 1) / KT : 0;
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
                      : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
     };
     auto issue = [&](int t) {            // tile t (keys kbeg + 64 t ..) -> slot t % NSLOT
+        if (NW > 4 && wave >= 4) return;  // the DMA pieces are laid out for 256 threads
         const int slot = t % NSLOT;
         const int k0 = kbeg + t * KT;
         const unsigned dstK = __builtin_amdgcn_readfirstlane(lds_base + slot * NOPS * TILE + wave * 1024);
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
     if (PD > 1 && ntiles > 1) issue(1);
     {
         const int w0 = kbeg / KT, w1 = (kend + KT - 1) / KT;
-        for (int w = w0 + wave; w < w1; w += 4) {
+        for (int w = w0 + wave; w < w1; w += NW) {
             const int kk = w * KT + lane;
             bool ok = kk < S;
             if (ok && p.mask) ok = p.mask[(size_t)b * S + kk] != 0;
@@ -339,8 +342,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {   // 2 wav
 template <typename OT, int HD, bool CAUSAL>
 static void launch_one(const AttnParams& p, int batch, hipStream_t st) {
     const int nqt = p.items ? p.n_items : (p.S + 127) / 128;
-    if (p.lo_off > 0) hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true>), dim3(nqt, p.heads, batch), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, false>), dim3(nqt, p.heads, batch), dim3(256), 0, st, p);
+    if (p.lo_off > 0 && !p.items && p.S > 128) {      // split-operand mode: 8 waves per workgroup (the ring fills the LDS)
+        hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true, 8>), dim3((p.S + 255) / 256, p.heads, batch), dim3(512), 0, st, p);
+    } else if (p.lo_off > 0) {
+        hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true, 4>), dim3(nqt, p.heads, batch), dim3(256), 0, st, p);
+    } else {
+        hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, false, 4>), dim3(nqt, p.heads, batch), dim3(256), 0, st, p);
+    }
 }
 
 void launch_attention(const AttnParams& p, int batch, int head_dim, bool causal, int operand_dtype, hipStream_t st) {
