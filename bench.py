@@ -132,7 +132,7 @@ def dominant_kernel_probe(dtype_code, tile, steps=5, split=False):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
     # PMC passes of these exact launches (profiles/r1_pmc_gemm_gate_up.md): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE
-    pmc = {"traffic": 29.7e9, "mfma_busy": 0.595, "clock_ghz": 1.81} if split else {"traffic": 15.2e9, "mfma_busy": 0.598, "clock_ghz": 1.81}
+    pmc = {"traffic": 32.9e9, "mfma_busy": 0.652, "clock_ghz": 1.73} if split else {"traffic": 14.6e9, "mfma_busy": 0.626, "clock_ghz": 1.75}
     return {"kernel": "gemm_bt8_kernel<SwiGLU> decoder gate_up" + (", split-operand form" if split else ""), "shape": [M, N, K],
             "avg_ms": ms, "tflops": 2.0 * M * N * K / (ms * 1e-3) / 1e12, "mfma_work_factor": w,
             "algorithmic_bytes": 2.0 * (w * M * K + N * K + w * M * N // 2), "traffic_bytes_pmc": pmc["traffic"],
