@@ -260,3 +260,17 @@ def test_right_padding_single_row_and_all_padding_row():
     dead = dict(batch, attention_mask=np.concatenate([mask[:1], np.zeros((1, S), dtype=np.int64)]))
     r = _fwd(m, dead)                                             # row 1 fully masked: finite-or-not, row 0 must be untouched
     assert torch.equal(r[0], got[0]) and r.shape == got.shape
+
+
+def test_bf16x2_mode():
+    """Split-operand mode with bf16 operands (hi + lo = 16 mantissa bits): exposed for completeness; far tighter than single-pass
+    bf16 (8e-3) though not the parity mode (f16x2 carries 22 bits)."""
+    cfg = synth.tiny_config()
+    seed = 29
+    batch = synth.synth_batch(cfg, seed, [7, 3], [(1, 1), (1, 2)], max_crops=4)
+    W = orc.weights_to_torch(synth.make_weights(cfg, seed))
+    ref = orc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"])
+    got = _fwd(_model(cfg, seed, "bf16x2", upload=False), batch)
+    err = (got - ref).abs().max().item()
+    print(f"[bf16x2] max |reward err| = {err:.3e}")
+    assert err < 2e-4
