@@ -55,7 +55,8 @@ constexpr int ATT_MAX_S = 8192;        // keys covered by the LDS bitmask
 // registers, and O leaves as [O_hi | O_lo].  K_lo / V_lo tiles ride in the same ring slot as K / V.
 // NW = waves per workgroup: 4 (128 queries; two workgroups share a CU when LDS allows) or 8 (256 queries on one K/V ring: used
 // by the split-operand mode, whose ring fills the LDS, so that every SIMD still holds two waves; waves 4-7 issue no DMA).
-template <typename OT, int HD, bool CAUSAL, bool PREC, int NW>
+// PP = ping-pong schedule of an 8-wave workgroup (long sequences; see the comment at the loop).
+template <typename OT, int HD, bool CAUSAL, bool PREC, int NW, bool PP = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnParams p) {   // <= 256 unified registers per wave, MFMA results stay in VGPRs
     constexpr int KT = 64;                 // keys per tile
     constexpr int KSTEPS = HD / 16;        // MFMA k-steps over the head dim
@@ -66,8 +67,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
     constexpr int NOPS = PREC ? 4 : 2;     // operand tiles per ring slot: K, V (, K_lo, V_lo)
     constexpr int NPT = NOPS * NPO;        // DMA instructions per thread per slot
     constexpr int TILE = KT * ROW;         // bytes of one operand tile
-    constexpr int NSLOT = (PREC && HD == 128) ? 2 : 3;          // 160 KB of LDS: 2 x 4 x 16 KB is all that fits at HD 128
-    constexpr int PD = NSLOT - 1;          // tiles in flight ahead of the one being consumed
+    constexpr int NSLOT = (PP && !PREC) ? 4 : (PREC && HD == 128) ? 2 : 3; // 160 KB of LDS: 2 x 4 x 16 KB is all that fits at HD 128
+    constexpr int PD = PP ? 2 : NSLOT - 1; // tiles in flight ahead of the one being consumed
+    static_assert(!PP || (NW == 8 && NSLOT >= 3), "ping-pong schedule: 8 waves, at least 3 ring slots");
+    constexpr int DMAG = (PP && PREC) ? 1 : 0;     // which half of an 8-wave workgroup issues the DMA
     static_assert(KT * CH % 256 == 0, "tile/threads mismatch");
 
     __shared__ __attribute__((aligned(16))) char smem[NSLOT * NOPS * TILE + ATT_MAX_S / 8];
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
     int drow[NPO], dkc[NPO], dvc[NPO];
 #pragma unroll
     for (int it = 0; it < NPO; ++it) {
-        const int q = it * 256 + tid;
+        const int q = it * 256 + (tid & 255);
         const int r = q / CH, c = q - r * CH;
         drow[it] = r;
         dkc[it] = (HD == 96 ? (c ^ ((r >> 2) & 3)) : HD == 64 ? (c ^ ((r >> 1) & 7)) : (c ^ (r & 15))) * 8;
@@ -120,10 +123,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
                      : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
     };
     auto issue = [&](int t) {            // tile t (keys kbeg + 64 t ..) -> slot t % NSLOT
-        if (NW > 4 && wave >= 4) return;  // the DMA pieces are laid out for 256 threads
+        if (NW > 4 && (wave >> 2) != DMAG) return;  // the DMA pieces are laid out for 256 threads
         const int slot = t % NSLOT;
         const int k0 = kbeg + t * KT;
-        const unsigned dstK = __builtin_amdgcn_readfirstlane(lds_base + slot * NOPS * TILE + wave * 1024);
+        const unsigned dstK = __builtin_amdgcn_readfirstlane(lds_base + slot * NOPS * TILE + (wave & 3) * 1024);
 #pragma unroll
         for (int it = 0; it < NPO; ++it) {
             const size_t key = rowbase + min(k0 + drow[it], S - 1);
@@ -201,6 +204,148 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
         voff[d] = row * ROW + win * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
     }
 
+    if constexpr (PP) {
+        // Ping-pong schedule: waves w and w+4 share a SIMD and run half a tile apart, so that one is in its matrix segment
+        // [O += V(t) P(t) ; S(t+1) = K(t+1) Q] while the other is in its vector segment [softmax(t)]; the two workgroup
+        // barriers per tile are the hand-over points (the late group takes one extra barrier first, the early one at the end).
+        // Single pass: waves 0-3 (the early group) issue the DMA: tile t+2 goes out in their vector segment t into the slot of
+        // tile t-2 (4 slots: the late group reads V(t-1) during that very interval), and their counted wait for tile t+1
+        // precedes the barrier that opens both groups' S(t+1).
+        // Split operands (3 slots is all the LDS holds): waves 4-7 (the late group) issue tile t+2 in THEIR vector segment t,
+        // which starts after the barrier that ends the last read of tile t-1, and retire it at the end of their matrix
+        // segment t, one barrier before the early group's S(t+2); one tile period covers the latency.
+        const int grp = wave >> 2;
+        f32x16 s[2];
+        uint4 pf[4], pl[PREC ? 4 : 1];
+        auto act = [&](int t) { return !CAUSAL || (kbeg + t * KT <= q0 + 31); };
+        auto qk = [&](int t) {
+            const char* sK = smem + (t % NSLOT) * NOPS * TILE;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) {
+                    const uint4 kf = *(const uint4*)(sK + koff[kt][ks]);
+                    s[kt] = Op<OT>::mfma32(kf, qf[ks], s[kt]);
+                    if constexpr (PREC) {
+                        s[kt] = Op<OT>::mfma32(kf, qfl[ks], s[kt]);
+                        const uint4 kl = *(const uint4*)(sK + 2 * TILE + koff[kt][ks]);
+                        s[kt] = Op<OT>::mfma32(kl, qf[ks], s[kt]);
+                    }
+                }
+            }
+        };
+        auto soft = [&](int t) {
+            const int k0 = kbeg + t * KT;
+            const unsigned blo = __builtin_amdgcn_readfirstlane(sBits[2 * (k0 / KT)]);
+            const unsigned bhi = __builtin_amdgcn_readfirstlane(sBits[2 * (k0 / KT) + 1]);
+            const bool need_causal = CAUSAL && (k0 + KT - 1 > q0);
+            if (need_causal || (blo & bhi) != 0xFFFFFFFFu) {
+                const unsigned wl = blo >> (4 * lh), wh = bhi >> (4 * lh);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kb = (r & 3) + 8 * (r >> 2);
+                        bool ok = (((kt ? wh : wl) >> kb) & 1u) != 0;
+                        if (CAUSAL) ok = ok && (k0 + kt * 32 + kb + 4 * lh <= qpos);
+                        s[kt][r] = ok ? s[kt][r] : -INFINITY;
+                    }
+            }
+            float mx = s[0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx * sc);
+            if (!__all(m_new == m_run)) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int d = 0; d < DT; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            }
+            float rs = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -m_run));
+                    s[kt][r] = e;
+                    rs += e;
+                }
+            rs += __shfl_xor(rs, 32, 64);
+            l_run += rs;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    uint4& f = pf[2 * kt + st];
+                    if constexpr (PREC) {
+                        uint4& g = pl[2 * kt + st];
+                        split2<OT>(s[kt][8 * st + 0], s[kt][8 * st + 1], f.x, g.x);
+                        split2<OT>(s[kt][8 * st + 2], s[kt][8 * st + 3], f.y, g.y);
+                        split2<OT>(s[kt][8 * st + 4], s[kt][8 * st + 5], f.z, g.z);
+                        split2<OT>(s[kt][8 * st + 6], s[kt][8 * st + 7], f.w, g.w);
+                    } else {
+                        f.x = pack2_fast<OT>(s[kt][8 * st + 0], s[kt][8 * st + 1]);
+                        f.y = pack2_fast<OT>(s[kt][8 * st + 2], s[kt][8 * st + 3]);
+                        f.z = pack2_fast<OT>(s[kt][8 * st + 4], s[kt][8 * st + 5]);
+                        f.w = pack2_fast<OT>(s[kt][8 * st + 6], s[kt][8 * st + 7]);
+                    }
+                }
+        };
+        auto pv = [&](int t) {
+            const char* sV = smem + (t % NSLOT) * NOPS * TILE + TILE;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) {
+                        const char* vb = sV + (kt * 32 + 16 * st) * ROW + voff[d];
+                        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb));
+                        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * ROW));
+                        uint4 vf;
+                        const uint2 a = __builtin_bit_cast(uint2, v0), c = __builtin_bit_cast(uint2, v1);
+                        vf.x = a.x; vf.y = a.y; vf.z = c.x; vf.w = c.y;
+                        o[d] = Op<OT>::mfma32(vf, pf[2 * kt + st], o[d]);
+                        if constexpr (PREC) {
+                            o[d] = Op<OT>::mfma32(vf, pl[2 * kt + st], o[d]);
+                            const s16x4 w0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 2 * TILE));
+                            const s16x4 w1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 2 * TILE + 8 * ROW));
+                            uint4 vl;
+                            const uint2 a2 = __builtin_bit_cast(uint2, w0), c2 = __builtin_bit_cast(uint2, w1);
+                            vl.x = a2.x; vl.y = a2.y; vl.z = c2.x; vl.w = c2.y;
+                            o[d] = Op<OT>::mfma32(vl, pf[2 * kt + st], o[d]);
+                        }
+                    }
+        };
+        if (ntiles > 0) {
+            __syncthreads();                              // tiles 0 and 1 landed (the wait above retired them), sBits written
+            if (grp) __syncthreads();                     // the late group starts one interval behind
+            if (act(0)) qk(0);
+            for (int t = 0; t < ntiles; ++t) {
+                // ---- vector segment ----
+                if (t + 2 < ntiles) issue(t + 2);         // (the issuing group only)
+                if (act(t)) soft(t);
+                if (!PREC && grp == 0) {
+                    if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPT) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
+                // ---- matrix segment ----
+                if (act(t)) pv(t);
+                if (t + 1 < ntiles && act(t + 1)) qk(t + 1);
+                if (PREC && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (t + 1 < ntiles || grp == 0) __syncthreads();
+            }
+        }
+    } else {
     for (int t = 0; t < ntiles; ++t) {
         const int k0 = kbeg + t * KT;
         if (t + PD < ntiles) {
@@ -322,6 +467,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
         __syncthreads();                                  // every wave is done with slot t%3 before tile t+3 is issued into it
     }
 
+    }
+
     // ---- epilogue: O[q][d], d = dt*32 + (r&3) + 8(r>>2) + 4h : 4 consecutive d per register quad ----
     if (qpos < S) {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
@@ -342,7 +489,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
 template <typename OT, int HD, bool CAUSAL>
 static void launch_one(const AttnParams& p, int batch, hipStream_t st) {
     const int nqt = p.items ? p.n_items : (p.S + 127) / 128;
-    if (p.lo_off > 0 && !p.items && p.S > 128) {      // split-operand mode: 8 waves per workgroup (the ring fills the LDS)
+    // Long sequences: 256-query workgroups on the ping-pong schedule (measured at B=32: HD 128 1.47x, where the 4-wave form
+    // fits one workgroup per CU; HD 96 1.03-1.07x; split operands 1.01-1.03x; below ~1k keys the 128-query grid fills better).
+    if (p.lo_off == 0 && !p.items && p.S >= 1024) {
+        hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, false, 8, true>), dim3((p.S + 255) / 256, p.heads, batch), dim3(512), 0, st, p);
+    } else if (p.lo_off > 0 && !p.items && p.S >= 1024 && HD != 128) {
+        if constexpr (HD != 128)
+            hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true, 8, true>), dim3((p.S + 255) / 256, p.heads, batch), dim3(512), 0, st, p);
+    } else if (p.lo_off > 0 && !p.items && p.S > 128) {      // split-operand mode: 8 waves per workgroup (the ring fills the LDS)
         hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true, 8>), dim3((p.S + 255) / 256, p.heads, batch), dim3(512), 0, st, p);
     } else if (p.lo_off > 0) {
         hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true, 4>), dim3(nqt, p.heads, batch), dim3(256), 0, st, p);

@@ -163,7 +163,8 @@ def _attn_ref(q, k, v, mask, causal, scale):
 
 
 @pytest.mark.parametrize("dt", DTS, ids=[d[0] for d in DTS])
-@pytest.mark.parametrize("case", [(2, 3, 300, 96, True), (3, 2, 577, 64, False), (1, 4, 1000, 96, True), (2, 2, 130, 64, True)])
+@pytest.mark.parametrize("case", [(2, 3, 300, 96, True), (3, 2, 577, 64, False), (1, 4, 1000, 96, True), (2, 2, 130, 64, True),
+                                  (2, 3, 1300, 96, True), (2, 2, 1100, 64, False), (1, 2, 1281, 64, True), (1, 2, 1024, 96, False)])   # >= 1024: ping-pong schedule
 def test_attention(lib, dt, case):
     _, code, tdt, ulp = dt
     B, H, S, hd, causal = case
@@ -213,7 +214,7 @@ def test_norm_rows(lib, dt, H):
 
 
 @pytest.mark.parametrize("dt", DTS, ids=[d[0] for d in DTS])
-@pytest.mark.parametrize("case", [(2, 8, 2, 333), (1, 4, 4, 700), (2, 4, 1, 130)])
+@pytest.mark.parametrize("case", [(2, 8, 2, 333), (1, 4, 4, 700), (2, 4, 1, 130), (2, 4, 2, 1200)])
 def test_attention_gqa_head_dim_128(lib, dt, case):
     """Mistral-style attention of the LLaVA branch: head_dim 128, several query heads per K/V head, causal + left padding."""
     _, code, tdt, ulp = dt
@@ -319,11 +320,12 @@ def test_gemm_split_operand_matches_fp32(lib, tile):
     assert (got - sref).abs().max().item() < 4e-6 * sref.abs().max().item() + 1e-6
 
 
+@pytest.mark.parametrize("S", [333, 1300])                # >= 1024: ping-pong schedule (head_dim 64 / 96)
 @pytest.mark.parametrize("hd,causal,group", [(96, True, 1), (64, False, 1), (128, True, 4), (96, False, 1)])
-def test_attention_split_operand_matches_fp32(lib, hd, causal, group):
+def test_attention_split_operand_matches_fp32(lib, hd, causal, group, S):
     """3-pass attention (hi.hi + hi.lo + lo.hi for QK^T and PV) against fp64 softmax attention on the un-rounded q, k, v."""
     code, tdt = L.LR_DT_F16, torch.float16
-    B, H, S = 2, 4, 333
+    B, H = 2, 4
     Hkv = H // group
     wq, wkv = H * hd, Hkv * hd
     W = wq + 2 * wkv
