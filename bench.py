@@ -185,6 +185,9 @@ def main():
     ap.add_argument("--model", default="phi3v", choices=["phi3v", "llava", "qwen"],
                     help="phi3v = BASELINE metric (default); llava = LLaVA-v1.6-Mistral-7B shapes of configs[4] with 16-bit operands; "
                          "qwen = Qwen2.5-VL-7B shapes of configs[3]")
+    ap.add_argument("--num-crops", type=int, default=16, choices=[16, 4],
+                    help="phi3v: the processor's num_crops (16 = the reference's setting, utils/utils.py:24 -> 17 crops, V=2509; "
+                         "4 -> 5 crops, V=757: the other reading of '336 px', SURVEY.md §8d)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests)")
     ap.add_argument("--all-ranks-on-device", type=int, default=-1, help="smoke test: put every rank on this one GPU")
     a = ap.parse_args()
@@ -225,9 +228,14 @@ def main():
         workload = "LLaVA-v1.6-Mistral-7B (BASELINE configs[4] shapes, 16-bit operands), 3 crops/img, V=1176"
     else:
         cfg = synth.full_config()                   # BT head (d=1) + SkipCA
-        gb = synth.synth_batch(cfg, 1234, [128] * (B * world), (4, 4), with_pixels=False)
-        ncrop, flop_per_pair = 17, FLOP_PER_PAIR
-        workload = "BASELINE configs[1]: Phi-3.5-V BT head + SkipCA, 17 crops/img, V=2509"
+        if a.num_crops == 16:
+            gb = synth.synth_batch(cfg, 1234, [128] * (B * world), (4, 4), with_pixels=False)
+            ncrop, flop_per_pair = 17, FLOP_PER_PAIR
+            workload = "BASELINE configs[1]: Phi-3.5-V BT head + SkipCA, 17 crops/img, V=2509"
+        else:
+            gb = synth.synth_batch(cfg, 1234, [128] * (B * world), (2, 2), with_pixels=False)
+            ncrop, flop_per_pair = 5, 8.48e12
+            workload = "BASELINE configs[1] at num_crops=4: Phi-3.5-V BT head + SkipCA, 5 crops/img, V=757"
     S = gb["input_ids"].shape[1]
     ids = torch.from_numpy(gb["input_ids"][rows]).cuda()
     mask = torch.from_numpy(gb["attention_mask"][rows]).cuda()
@@ -310,8 +318,9 @@ def main():
                              flop_per_pair / 1e12, "; the split-operand mode executes 2x (linears) / 3x (attention) that MFMA work" if precise else "")},
         }
         if world == 1:
-            res["parity_check"] = golden_check(model, a.model)
-            if a.model == "phi3v":
+            full = a.model != "phi3v" or a.num_crops == 16      # the golden row is a 17-crop image: it does not fit the 5-crop engine
+            res["parity_check"] = golden_check(model, a.model) if full else None
+            if a.model == "phi3v" and a.num_crops == 16:
                 dk = dominant_kernel_probe(L.LR_DT_F16 if a.dtype.startswith("f16") else L.LR_DT_BF16, a.tile, split=precise)
                 # the roofline object proper: the dominant kernel, algorithmic FLOPs per launch / its live HIP-event duration
                 res["roofline"].update({"achieved": dk["tflops"], "frac": dk["tflops"] / PEAK_TFLOPS, "traffic": dk["traffic_bytes_pmc"],
@@ -319,7 +328,16 @@ def main():
                                         "whole_pass": {"achieved": tf_per_gpu, "frac": tf_per_gpu / PEAK_TFLOPS},
                                         "note": res["roofline"]["note"] + "; achieved/frac/traffic = the dominant kernel (algorithmic FLOPs per launch / HIP-event "
                                                 "time; traffic = PMC bytes per launch, profiles/r1_pmc_gemm_gate_up.md); whole_pass = the same ratio for the step"})
-            del model
+            # the same step with the pixel hand-over included: fp32 pixels start in pinned host memory (what the processor
+            # returns) and cross PCIe on the forward's stream every step.  Reported beside `value`, never as `value`.
+            pix_host = pix.cpu().pin_memory()
+            def step_h2d():
+                pix.copy_(pix_host, non_blocking=True)
+                return run_forward(model)
+            ms_h2d = timed_steps(step_h2d, 1, a.steps)
+            res["h2d_inclusive"] = {"value": B / (ms_h2d * 1e-3), "unit": "reward-pairs/sec", "ms_per_step": ms_h2d,
+                                    "pixel_bytes_per_step": pix.numel() * 4, "note": "pinned host fp32 pixels copied in every step"}
+            del model, pix_host
             torch.cuda.empty_cache()
             if precise and not a.no_fast_mode:
                 # secondary figure: the single-pass f16 mode of the same workload (noise-limited parity)
@@ -328,10 +346,10 @@ def main():
                 fv = B * a.steps / (ms * 1e-3 * a.steps)
                 res["fast_mode"] = {"dtype": "f16 single-pass MFMA operands", "value": fv, "unit": "reward-pairs/sec", "ms_per_step": ms,
                                     "roofline_frac_whole_pass": fv * flop_per_pair / 1e12 / PEAK_TFLOPS,
-                                    "parity_check": golden_check(fm, a.model)}
+                                    "parity_check": golden_check(fm, a.model) if full else None}
                 del fm
                 torch.cuda.empty_cache()
-            if a.model == "phi3v" and not a.no_cpu_baseline:
+            if a.model == "phi3v" and a.num_crops == 16 and not a.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(res), flush=True)
     if world > 1:
