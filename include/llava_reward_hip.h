@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LR_ABI_VERSION 3
+#define LR_ABI_VERSION 4
 
 enum { LR_OK = 0, LR_EINVAL = 1, LR_EHIP = 2, LR_ESTATE = 3, LR_ENOTFOUND = 4, LR_ENOMEM = 5 };
 enum { LR_DT_BF16 = 0, LR_DT_F16 = 1, LR_DT_F32 = 2 };
@@ -170,6 +170,18 @@ int lr_op_norm_rows(const float* x, const float* w, const float* b, void* y, int
                     int operand_dtype, void* hip_stream);
 int lr_op_synth_fill(float* out, size_t n, uint64_t seed, const char* name, float std, float offset, int bf16_round,
                      void* hip_stream);
+
+/* ---- input hand-over: the Phi-3.5-V image processor on the GPU ----
+ * Replaces Phi3VImageProcessor.preprocess (llava_reward/models/base_mllm/phi3_v/processing_phi3_v.py:262-288 with
+ * HD_transform :85-107 and padding_336 :62-72) for ONE image: `rgb` = DEVICE uint8 [height, width, 3] (what
+ * PIL's Image.convert('RGB') holds), `pixel_values` = DEVICE fp32 [num_crops + 1, 3, 336, 336] (global view first, then the
+ * local crops row-major, zero crops behind them), `image_size` = HOST int64 [2] = padded (h, w) (may be NULL),
+ * `num_img_tokens` = HOST int32 (:269; may be NULL).  Local crops are bit-exact with the reference (Pillow's 8-bit
+ * resampler); the bicubic global view is fp32 (<= 1e-5 of torch's).  `workspace` = DEVICE scratch of at least
+ * lr_hd_transform_workspace(height, width, num_crops) bytes (0 = invalid arguments).  Enqueues on `hip_stream` and returns. */
+size_t lr_hd_transform_workspace(int height, int width, int num_crops);
+int lr_hd_transform(const uint8_t* rgb, int height, int width, int num_crops, float* pixel_values, int64_t* image_size,
+                    int32_t* num_img_tokens, void* workspace, size_t workspace_bytes, void* hip_stream);
 
 #ifdef __cplusplus
 }

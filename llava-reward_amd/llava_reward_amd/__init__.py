@@ -7,5 +7,7 @@ Drop-in surface (mirrors eval/reward_adaptor_loader.py of the reference):
 from . import synth  # noqa: F401
 from .model import RewardModel  # noqa: F401
 from .reward_adaptor_loader import inference_process_phi3v, load_reward_adaptor, preference_compute  # noqa: F401
+from .preprocess import hd_transform_batch, inference_process_phi3v_device  # noqa: F401
 
-__all__ = ["synth", "RewardModel", "load_reward_adaptor", "inference_process_phi3v", "preference_compute"]
+__all__ = ["synth", "RewardModel", "load_reward_adaptor", "inference_process_phi3v", "preference_compute",
+           "hd_transform_batch", "inference_process_phi3v_device"]

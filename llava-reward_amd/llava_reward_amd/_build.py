@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(PKG_DIR), "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libllava_reward_hip.so")
-SOURCES = ["gemm.hip", "gemm8.hip", "attention.hip", "gemm_f32.hip", "rowops.hip", "rowops_qwen.hip", "engine.hip", "qwen.hip"]
+SOURCES = ["gemm.hip", "gemm8.hip", "attention.hip", "gemm_f32.hip", "rowops.hip", "rowops_qwen.hip", "engine.hip", "qwen.hip", "preprocess.hip"]
 HEADERS = ["common.h", "kernels.h", "engine.h", os.path.join("..", "..", "include", "llava_reward_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 

@@ -13,7 +13,7 @@ LR_MAX_HALF_HEAD = 64
 LR_MAX_PINPOINTS = 8
 LR_MAX_FULLATT = 8
 LR_BACKBONE_PHI3V, LR_BACKBONE_LLAVA_NEXT, LR_BACKBONE_QWEN2_5_VL = 0, 1, 2
-LR_ABI_VERSION = 3
+LR_ABI_VERSION = 4
 EPI_OUT_OP, EPI_OUT_F32, EPI_RESADD_F32, EPI_SWIGLU_OP, EPI_ROPE_OP = 0, 1, 2, 3, 4
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2
 
@@ -77,6 +77,9 @@ _SIGS = {
     "lr_op_attention_segments": (C.c_int, [C.c_void_p] * 4 + [C.POINTER(C.c_int32)] + [C.c_int] * 8 + [C.c_float, C.c_int, C.c_void_p]),
     "lr_op_norm_rows": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "lr_op_synth_fill": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_char_p, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "lr_hd_transform_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "lr_hd_transform": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                  C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 EXPORTS = tuple(_SIGS)

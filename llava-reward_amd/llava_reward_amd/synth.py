@@ -312,6 +312,19 @@ def synth_pixels(seed: int, name: str, shape: Tuple[int, ...]) -> np.ndarray:
     return gen_tensor(seed, name, shape, 1.0, 0.0, bf16_valued=False)
 
 
+def synth_image(seed: int, name: str, h: int, w: int, smooth: bool = False) -> np.ndarray:
+    """Seeded RGB uint8 [h, w, 3] test image: byte noise, or (smooth) gradients + noise in the low 3 bits, the kind of
+    content whose resampled bytes land on rounding boundaries."""
+    t = np.uint64(tensor_seed(seed, name))
+    idx = np.arange(h * w * 3, dtype=np.uint64)
+    noise = (_splitmix64_np(t + idx) >> np.uint64(56)).astype(np.uint8).reshape(h, w, 3)
+    if not smooth:
+        return noise
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([yy * 255 // max(h - 1, 1), xx * 255 // max(w - 1, 1), (yy + 2 * xx) % 256], axis=-1)
+    return ((base & 0xF8) | (noise & 7)).astype(np.uint8)
+
+
 def synth_batch(cfg: RewardConfig, seed: int, caption_lens: List[int], grids, max_crops: int = None,
                 pad_token_id: int = None, with_pixels: bool = True):
     """Token/mask/pixel tensors shaped like collate_fn output (reward_dataset.py:137-202, Appendix B

@@ -1,0 +1,131 @@
+"""GPU parity of the image hand-over (lr_hd_transform, csrc/preprocess.hip) through the C ABI: local crops bit-exact with
+the oracle (= Pillow), bicubic global view within 1e-5, golden digests, error paths, and the drop-in
+inference_process_phi3v_device feeding custom_forward."""
+import ctypes as C
+import glob
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from llava_reward_amd import _lib as L
+from llava_reward_amd import preprocess as P
+from llava_reward_amd import synth
+from oracle import phi3v_hd_transform_oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "pre_*.json")))
+TOL_GLOBAL = 1e-5      # fp32 bicubic of values in [-1.8, 2.2]; the local crops are compared bit-for-bit
+
+
+def sample_index(n=96):
+    return [(i % 3, (37 * i + 5) % 336, (101 * i + 11) % 336) for i in range(n)]
+
+
+CASES = [(336, 336, 16), (640, 512, 16), (512, 640, 4), (300, 900, 16), (200, 200, 4), (1344, 1344, 16), (1500, 2000, 16),
+         (97, 133, 16), (5, 400, 16), (400, 5, 16), (1344, 1000, 16), (672, 672, 4), (1, 1, 4), (3000, 700, 16)]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"{h}x{w}_nc{n}" for h, w, n in CASES])
+@pytest.mark.parametrize("smooth", [False, True])
+def test_hd_transform_matches_oracle(case, smooth):
+    h, w, nc = case
+    a = synth.synth_image(11, f"hd.{h}.{w}", h, w, smooth)
+    ref, (H, W), ntok = O.preprocess(a, nc)
+    pix, sizes, nt = P.hd_transform_batch([a], nc)
+    torch.cuda.synchronize()
+    got = pix[0].cpu().numpy()
+    assert sizes.tolist() == [[H, W]] and nt == [ntok]
+    assert np.array_equal(got[1:], ref[1:]), "local crops must be bit-exact"
+    assert np.abs(got[0] - ref[0]).max() < TOL_GLOBAL
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[4:-5] for p in GOLDEN])
+def test_hd_transform_matches_golden_digests(path):
+    g = json.load(open(path))
+    a = synth.synth_image(g["seed"], "pre." + g["name"], g["h"], g["w"], g["smooth"])
+    pix, sizes, nt = P.hd_transform_batch([torch.from_numpy(a).cuda()], g["num_crops"])       # device-resident source
+    torch.cuda.synchronize()
+    got = pix[0].cpu().numpy()
+    assert sizes.tolist() == [g["image_size"]] and nt == [g["num_img_tokens"]]
+    assert hashlib.sha256(np.ascontiguousarray(got[1:]).tobytes()).hexdigest() == g["local_sha256"]
+    s = np.array([got[0, c, y, x] for c, y, x in sample_index()], dtype=np.float64)
+    assert np.abs(s - np.array(g["global_samples"])).max() < TOL_GLOBAL
+
+
+def test_batch_of_mixed_sizes_and_reused_output():
+    imgs = [synth.synth_image(5, f"mix.{i}", h, w) for i, (h, w) in enumerate([(336, 336), (900, 300), (480, 640)])]
+    out = torch.full((3, 17, 3, 336, 336), 7.0, device="cuda")
+    pix, sizes, nt = P.hd_transform_batch(imgs, 16, out=out)
+    torch.cuda.synchronize()
+    assert pix.data_ptr() == out.data_ptr()
+    for b, a in enumerate(imgs):
+        ref, (H, W), ntok = O.preprocess(a, 16)
+        assert sizes[b].tolist() == [H, W] and nt[b] == ntok
+        got = pix[b].cpu().numpy()
+        assert np.array_equal(got[1:], ref[1:]) and np.abs(got[0] - ref[0]).max() < TOL_GLOBAL
+
+
+def test_error_paths():
+    lib = L.load()
+    assert lib.lr_hd_transform_workspace(0, 10, 16) == 0
+    assert lib.lr_hd_transform_workspace(10, 10, 0) == 0
+    assert lib.lr_hd_transform_workspace(1, 20000, 16) == 0           # resized height would be 0: the reference's resize raises
+    assert b"extreme" in lib.lr_last_error(None)
+    a = torch.zeros(64, 64, 3, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(5, 3, 336, 336, device="cuda")
+    ws = torch.zeros(1024, dtype=torch.uint8, device="cuda")
+    rc = lib.lr_hd_transform(C.c_void_p(a.data_ptr()), 64, 64, 4, C.c_void_p(out.data_ptr()), None, None,
+                             C.c_void_p(ws.data_ptr()), 1024, None)
+    assert rc != 0 and b"workspace" in lib.lr_last_error(None)
+    rc = lib.lr_hd_transform(None, 64, 64, 4, C.c_void_p(out.data_ptr()), None, None, C.c_void_p(ws.data_ptr()), 1024, None)
+    assert rc != 0
+    with pytest.raises(ValueError):
+        P.hd_transform_batch([np.zeros((8, 8), dtype=np.uint8)], 4)
+    with pytest.raises(ValueError):
+        P.hd_transform_batch([np.zeros((8, 8, 3), dtype=np.float32)], 4)
+
+
+class _Tok:
+    """Stand-in tokenizer with the three members inference_process_phi3v uses."""
+    eos_token = "<|endoftext|>"
+
+    def apply_chat_template(self, messages, tokenize=False, add_generation_prompt=True):
+        return "<|user|>\n" + messages[0]["content"] + "<|end|>\n<|assistant|>\n"      # the caller drops these 22 characters
+
+    def __call__(self, text):
+        class R:
+            pass
+        r = R()
+        r.input_ids = [3 + (ord(ch) % 200) for ch in text]
+        return r
+
+
+def test_inference_process_device_feeds_custom_forward(tmp_path):
+    from PIL import Image
+    from llava_reward_amd.model import RewardModel
+    cfg = synth.tiny_config()
+    paths = []
+    for i, (h, w) in enumerate([(200, 300), (336, 336)]):
+        a = synth.synth_image(9, f"file.{i}", h, w, True)
+        p = str(tmp_path / f"img{i}.png")
+        Image.fromarray(a).save(p)
+        paths.append((p, a))
+    tok = _Tok()
+    rows = P.inference_process_phi3v_device(None, tok, [p for p, _ in paths], "a caption", num_crops=4)
+    assert len(rows) == 2
+    model = RewardModel(cfg, synth_seed=1234, max_batch=2, max_seq=1024, max_crops=5).to("cuda").eval()
+    for (p, a), d in zip(paths, rows):
+        ref_pix, (H, W), ntok = O.preprocess(a, 4)
+        assert d["image_sizes"].tolist() == [[H, W]]
+        ids = d["input_ids"]
+        assert int((ids < 0).sum()) == ntok and (ids[ids < 0] == -1).all() and d["attention_mask"].all()
+        assert tuple(d["pixel_values"].shape) == (1, 5, 3, 336, 336)
+        r_dev, _ = model.custom_forward(**d)
+        d2 = dict(d, pixel_values=torch.from_numpy(ref_pix)[None].cuda())
+        r_ref, _ = model.custom_forward(**d2)
+        torch.cuda.synchronize()
+        assert torch.isfinite(r_dev).all() and (r_dev - r_ref).abs().max().item() < 1e-5
