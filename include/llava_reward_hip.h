@@ -183,6 +183,29 @@ size_t lr_hd_transform_workspace(int height, int width, int num_crops);
 int lr_hd_transform(const uint8_t* rgb, int height, int width, int num_crops, float* pixel_values, int64_t* image_size,
                     int32_t* num_img_tokens, void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/* The Qwen2-VL image processor (transformers image_processing_qwen2_vl, the PIL / "slow" arithmetic of the pinned 4.50;
+ * call site: the processor built in llava_reward/utils/utils.py:34-44 with min_pixels = 256*28*28, max_pixels = 1280*28*28)
+ * for ONE image: smart_resize -> Pillow BICUBIC on uint8 -> * 1/255, (x - mean) / std -> patchify.
+ * `pixel_values` = DEVICE fp32 [grid_h * grid_w, 1176] (rows in 2x2 merge-block order, the single frame repeated for the two
+ * temporal slots), `grid_thw` = HOST int64 [3] = (1, grid_h, grid_w).  lr_qwen_image_grid is host-only: call it first to size
+ * `pixel_values`.  Results are bit-exact with the processor. */
+int lr_qwen_image_grid(int height, int width, int64_t min_pixels, int64_t max_pixels, int64_t* grid_thw);
+size_t lr_qwen_image_workspace(int height, int width, int64_t min_pixels, int64_t max_pixels);
+int lr_qwen_image_transform(const uint8_t* rgb, int height, int width, int64_t min_pixels, int64_t max_pixels, float* pixel_values,
+                            int64_t* grid_thw, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* The LLaVA-NeXT image processor (transformers image_processing_llava_next, PIL arithmetic; call site: the processor built in
+ * llava_reward/utils/utils.py:46-55, used by eval/batch_inference_rm_llava.py) for ONE image: select_best_resolution over
+ * `pinpoints` (HOST int32 [n, 2] = (h, w), multiples of 336), crop 0 = the image resized to 336x336, crops 1.. = the
+ * aspect-preserving BICUBIC resize centred on a zero canvas and cut into 336x336 tiles, * 1/255, (x - mean) / std; crops up to
+ * `max_crops` zero-filled (the processor's _pad_for_batching).  `pixel_values` = DEVICE fp32 [max_crops, 3, 336, 336],
+ * `image_size` = HOST int64 [2] = the ORIGINAL (h, w).  lr_llava_image_geometry (host-only) returns
+ * (best_h, best_w, resized_h, resized_w, n_crops).  Results are bit-exact with the processor. */
+int lr_llava_image_geometry(int height, int width, const int32_t* pinpoints, int n_pinpoints, int32_t* out5);
+size_t lr_llava_image_workspace(int height, int width, const int32_t* pinpoints, int n_pinpoints);
+int lr_llava_image_transform(const uint8_t* rgb, int height, int width, const int32_t* pinpoints, int n_pinpoints, int max_crops,
+                             float* pixel_values, int64_t* image_size, void* workspace, size_t workspace_bytes, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

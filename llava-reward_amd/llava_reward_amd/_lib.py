@@ -78,6 +78,14 @@ _SIGS = {
     "lr_op_norm_rows": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "lr_op_synth_fill": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_char_p, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "lr_hd_transform_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "lr_qwen_image_grid": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
+    "lr_qwen_image_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int64, C.c_int64]),
+    "lr_qwen_image_transform": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int64),
+                                          C.c_void_p, C.c_size_t, C.c_void_p]),
+    "lr_llava_image_geometry": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32)]),
+    "lr_llava_image_workspace": (C.c_size_t, [C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int]),
+    "lr_llava_image_transform": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p,
+                                           C.POINTER(C.c_int64), C.c_void_p, C.c_size_t, C.c_void_p]),
     "lr_hd_transform": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
 }

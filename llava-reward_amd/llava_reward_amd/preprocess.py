@@ -1,4 +1,4 @@
-"""GPU input hand-over for the Phi-3.5-V path: what the reference's processor does on one CPU
+"""GPU input hand-over (Phi-3.5-V HD transform; Qwen2-VL and LLaVA-NeXT image processors) for the scoring path: what the reference's processor does on one CPU
 thread per image (processing_phi3_v.py:85-107 HD_transform, :262-288 normalise / global view / crop tiling, :407-454 text +
 image-slot merge) with the pixel work on the GPU: the decoded uint8 image crosses PCIe (0.5 MB instead of 23 MB of fp32) and
 `lr_hd_transform` (csrc/preprocess.hip) writes `pixel_values` in place.  No CPU fallback: without the HIP library this fails."""
@@ -31,10 +31,7 @@ def hd_transform_batch(images: Sequence, num_crops: int = 16, device="cuda", out
     st = torch.cuda.current_stream(dev)
     ws, ws_bytes = None, 0                                    # scratch, reused in stream order, grown as needed
     for b, im in enumerate(images):
-        t = im if torch.is_tensor(im) else torch.from_numpy(np.array(im))      # (copy: PIL-backed arrays are read-only)
-        if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
-            raise ValueError(f"image {b}: expected RGB uint8 [h, w, 3], got {tuple(t.shape)} {t.dtype}")
-        t = t.to(dev, non_blocking=True).contiguous()
+        t = _as_device_u8(im, b, dev)
         h, w = int(t.shape[0]), int(t.shape[1])
         need = lib.lr_hd_transform_workspace(h, w, num_crops)
         if need == 0:
@@ -51,6 +48,83 @@ def hd_transform_batch(images: Sequence, num_crops: int = 16, device="cuda", out
         sizes[b] = (size[0], size[1])
         ntok.append(int(n.value))
     return out, torch.from_numpy(sizes), ntok
+
+
+def _as_device_u8(im, b, dev):
+    t = im if torch.is_tensor(im) else torch.from_numpy(np.array(im))      # (copy: PIL-backed arrays are read-only)
+    if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
+        raise ValueError(f"image {b}: expected RGB uint8 [h, w, 3], got {tuple(t.shape)} {t.dtype}")
+    return t.to(dev, non_blocking=True).contiguous()
+
+
+def qwen_image_batch(images: Sequence, min_pixels: int = 256 * 28 * 28, max_pixels: int = 1280 * 28 * 28, device="cuda"):
+    """The Qwen2-VL image processor on the GPU (transformers image_processing_qwen2_vl; the reference builds it with these pixel
+    bounds, utils/utils.py:34-44).  images: RGB uint8 [h, w, 3].  Returns (pixel_values [sum gh*gw, 1176] fp32 on `device`,
+    image_grid_thw [n, 3] int64 host) -- the two image entries of the processor's BatchFeature, bit-exact."""
+    lib = L.load()
+    dev = torch.device(device)
+    grids = np.zeros((len(images), 3), dtype=np.int64)
+    shapes = []
+    for b, im in enumerate(images):
+        h, w = int(im.shape[0]), int(im.shape[1])
+        g = (C.c_int64 * 3)()
+        if lib.lr_qwen_image_grid(h, w, min_pixels, max_pixels, g) != 0:
+            raise ValueError(f"image {b} ({h}x{w}): " + lib.lr_last_error(None).decode())
+        grids[b] = (g[0], g[1], g[2])
+        shapes.append((h, w))
+    rows = (grids[:, 1] * grids[:, 2]).astype(np.int64)
+    out = torch.empty(int(rows.sum()), 1176, dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev)
+    ws, ws_bytes, r0 = None, 0, 0
+    for b, im in enumerate(images):
+        t = _as_device_u8(im, b, dev)
+        h, w = shapes[b]
+        need = lib.lr_qwen_image_workspace(h, w, min_pixels, max_pixels)
+        if need > ws_bytes:
+            ws, ws_bytes = torch.empty(need, dtype=torch.uint8, device=dev), need
+        rc = lib.lr_qwen_image_transform(C.c_void_p(t.data_ptr()), h, w, min_pixels, max_pixels, C.c_void_p(out[r0:].data_ptr()), None,
+                                         C.c_void_p(ws.data_ptr()), ws_bytes, C.c_void_p(st.cuda_stream))
+        if rc != 0:
+            raise RuntimeError(lib.lr_last_error(None).decode())
+        r0 += int(rows[b])
+    return out, torch.from_numpy(grids)
+
+
+LLAVA_PINPOINTS = ((336, 672), (672, 336), (672, 672), (1008, 336), (336, 1008))     # llava-v1.6-mistral-7b-hf
+
+
+def llava_image_batch(images: Sequence, pinpoints=LLAVA_PINPOINTS, max_crops: int = None, device="cuda"):
+    """The LLaVA-NeXT image processor on the GPU (transformers image_processing_llava_next).  Returns (pixel_values
+    [B, C, 3, 336, 336] fp32 on `device`, C = max_crops or the batch maximum as the processor pads, image_sizes [B, 2] int64 host
+    = ORIGINAL (h, w)), bit-exact with the processor."""
+    lib = L.load()
+    dev = torch.device(device)
+    pin = (C.c_int32 * (2 * len(pinpoints)))(*[int(v) for p in pinpoints for v in p])
+    ncrops, shapes = [], []
+    for b, im in enumerate(images):
+        h, w = int(im.shape[0]), int(im.shape[1])
+        g = (C.c_int32 * 5)()
+        if lib.lr_llava_image_geometry(h, w, pin, len(pinpoints), g) != 0:
+            raise ValueError(f"image {b} ({h}x{w}): " + lib.lr_last_error(None).decode())
+        ncrops.append(int(g[4]))
+        shapes.append((h, w))
+    Cn = max_crops if max_crops is not None else max(ncrops)
+    if Cn < max(ncrops):
+        raise ValueError(f"max_crops={Cn} but an image needs {max(ncrops)} crops")
+    out = torch.empty(len(images), Cn, 3, CROP, CROP, dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev)
+    ws, ws_bytes = None, 0
+    for b, im in enumerate(images):
+        t = _as_device_u8(im, b, dev)
+        h, w = shapes[b]
+        need = lib.lr_llava_image_workspace(h, w, pin, len(pinpoints))
+        if need > ws_bytes:
+            ws, ws_bytes = torch.empty(need, dtype=torch.uint8, device=dev), need
+        rc = lib.lr_llava_image_transform(C.c_void_p(t.data_ptr()), h, w, pin, len(pinpoints), Cn, C.c_void_p(out[b].data_ptr()), None,
+                                          C.c_void_p(ws.data_ptr()), ws_bytes, C.c_void_p(st.cuda_stream))
+        if rc != 0:
+            raise RuntimeError(lib.lr_last_error(None).decode())
+    return out, torch.tensor(shapes, dtype=torch.int64)
 
 
 _IMAGE_TAG = re.compile(r"<\|image_\d+\|>")

@@ -30,12 +30,37 @@ CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)          # preprocessor_config.j
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
+def _bilinear_filter(x: float) -> float:
+    if x < 0.0:
+        x = -x
+    return 1.0 - x if x < 1.0 else 0.0
+
+
+def _bicubic_filter(x: float) -> float:
+    a = -0.5                                                   # Pillow's BICUBIC (Keys, a = -0.5); torch's is a = -0.75
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+FILTERS = {"bilinear": (_bilinear_filter, 1.0), "bicubic": (_bicubic_filter, 2.0)}
+
+
 def bilinear_coeffs(in_size: int, out_size: int):
-    """Resample.c precompute_coeffs + normalize_coeffs_8bpc for the bilinear filter (support 1) over the box [0, in_size).
+    return resample_coeffs(in_size, out_size, "bilinear")
+
+
+def resample_coeffs(in_size: int, out_size: int, filt: str = "bilinear"):
+    """Resample.c precompute_coeffs + normalize_coeffs_8bpc for one of Pillow's filters over the box [0, in_size).
     Returns (bounds [out, 2] = (first tap, tap count), kk [out, ksize] int32)."""
+    fn, fsupport = FILTERS[filt]
     scale = in_size / out_size
     filterscale = max(scale, 1.0)
-    support = 1.0 * filterscale
+    support = fsupport * filterscale
     ksize = int(math.ceil(support)) * 2 + 1
     bounds = np.zeros((out_size, 2), dtype=np.int32)
     kk = np.zeros((out_size, ksize), dtype=np.int32)
@@ -52,10 +77,7 @@ def bilinear_coeffs(in_size: int, out_size: int):
         w = np.zeros(ksize, dtype=np.float64)
         ww = 0.0
         for x in range(xmax):
-            a = (x + xmin - center + 0.5) * ss
-            if a < 0.0:
-                a = -a
-            v = 1.0 - a if a < 1.0 else 0.0
+            v = fn((x + xmin - center + 0.5) * ss)
             w[x] = v
             ww += v
         for x in range(xmax):
@@ -67,10 +89,10 @@ def bilinear_coeffs(in_size: int, out_size: int):
     return bounds, kk
 
 
-def _resample_axis(img: np.ndarray, out_size: int, axis: int) -> np.ndarray:
+def _resample_axis(img: np.ndarray, out_size: int, axis: int, filt: str = "bilinear") -> np.ndarray:
     """One pass of the 8-bit resampler along `axis` (0 = rows / vertical, 1 = columns / horizontal) of an [h, w, c] image."""
     in_size = img.shape[axis]
-    bounds, kk = bilinear_coeffs(in_size, out_size)
+    bounds, kk = resample_coeffs(in_size, out_size, filt)
     src = np.moveaxis(img, axis, 0).astype(np.int64)              # [in, other, c]
     out = np.empty((out_size,) + src.shape[1:], dtype=np.uint8)
     for xx in range(out_size):
@@ -82,15 +104,19 @@ def _resample_axis(img: np.ndarray, out_size: int, axis: int) -> np.ndarray:
     return np.moveaxis(out, 0, axis)
 
 
-def resize_bilinear_u8(img: np.ndarray, new_h: int, new_w: int) -> np.ndarray:
-    """PIL Image.resize((new_w, new_h), BILINEAR) on an RGB uint8 [h, w, 3] image: horizontal pass, then vertical pass,
+def resize_u8(img: np.ndarray, new_h: int, new_w: int, filt: str = "bilinear") -> np.ndarray:
+    """PIL Image.resize((new_w, new_h), filt) on an RGB uint8 [h, w, 3] image: horizontal pass, then vertical pass,
     each skipped when that size does not change (Resample.c ImagingResample)."""
     h, w, _ = img.shape
     if new_w != w:
-        img = _resample_axis(img, new_w, 1)
+        img = _resample_axis(img, new_w, 1, filt)
     if new_h != h:
-        img = _resample_axis(img, new_h, 0)
+        img = _resample_axis(img, new_h, 0, filt)
     return img
+
+
+def resize_bilinear_u8(img: np.ndarray, new_h: int, new_w: int) -> np.ndarray:
+    return resize_u8(img, new_h, new_w, "bilinear")
 
 
 def hd_geometry(width: int, height: int, hd_num: int):

@@ -8,7 +8,10 @@ runs those real primitives, composed as processing_phi3_v.py:85-107 / :262-288 c
 `pad` on a PIL image = ImageOps.expand), on seeded images and stores digests: the padded size, the token count, a SHA-256
 of the local crops' bytes (bit-exact part) and 96 sampled values of the bicubic global view.
 
-    python tests/golden/make_preprocess_goldens.py        # writes tests/golden/pre_*.json
+The Qwen2-VL and LLaVA-NeXT processors are third party (transformers); their PIL-backend classes import here, so their
+goldens (preq_*.json, prel_*.json) are digests of the REAL processors' outputs on seeded images.
+
+    python tests/golden/make_preprocess_goldens.py        # writes tests/golden/pre_*.json, preq_*.json, prel_*.json
 """
 import hashlib
 import json
@@ -73,8 +76,50 @@ def sample_index(n=96):
     return [(c, (37 * i + 5) % 336, (101 * i + 11) % 336) for i in range(n) for c in (i % 3,)]
 
 
+QWEN_CASES = [("sq336", 336, 336, False), ("p500x375", 500, 375, True), ("big1200x1600", 1200, 1600, False),
+              ("tiny97x133", 97, 133, True), ("strip30x2000", 30, 2000, True)]
+LLAVA_CASES = [("sq336", 336, 336, False), ("p500x375", 500, 375, True), ("big1200x1600", 1200, 1600, False),
+               ("tiny97x133", 97, 133, True), ("wide300x1100", 300, 1100, True), ("tall900x200", 900, 200, False)]
+LLAVA_PINPOINTS = [[336, 672], [672, 336], [672, 672], [1008, 336], [336, 1008]]
+
+
+def sample_rows(n_rows, n=64):
+    return [((977 * i + 3) % n_rows, (131 * i + 7) % 1176) for i in range(n)]
+
+
+def third_party_processors():
+    """The real transformers image processors (PIL backend = the arithmetic of the pinned 4.50 'slow' processors)."""
+    from transformers.models.llava_next.image_processing_pil_llava_next import LlavaNextImageProcessorPil
+    from transformers.models.qwen2_vl.image_processing_pil_qwen2_vl import Qwen2VLImageProcessorPil
+    q = Qwen2VLImageProcessorPil(min_pixels=256 * 28 * 28, max_pixels=1280 * 28 * 28)              # utils/utils.py:34-44
+    l = LlavaNextImageProcessorPil(size={"shortest_edge": 336}, crop_size={"height": 336, "width": 336},
+                                   image_grid_pinpoints=LLAVA_PINPOINTS, resample=3, image_mean=list(MEAN), image_std=list(STD))
+    return q, l
+
+
 def main():
     import PIL
+    import transformers
+    q, l = third_party_processors()
+    made = {"pillow": PIL.__version__, "transformers": transformers.__version__}
+    for name, h, w, smooth in QWEN_CASES:
+        a = synth.synth_image(1234, "preq." + name, h, w, smooth)
+        out = q(images=[Image.fromarray(a)], return_tensors="np")
+        pv = np.ascontiguousarray(out["pixel_values"], dtype=np.float32)
+        g = {"name": name, "seed": 1234, "h": h, "w": w, "smooth": smooth, "min_pixels": 256 * 28 * 28, "max_pixels": 1280 * 28 * 28,
+             "image_grid_thw": out["image_grid_thw"][0].tolist(), "sha256": hashlib.sha256(pv.tobytes()).hexdigest(),
+             "samples": [float(pv[r, c]) for r, c in sample_rows(pv.shape[0])], "made_with": made}
+        json.dump(g, open(os.path.join(HERE, f"preq_{name}.json"), "w"), indent=1)
+        print("qwen", name, g["image_grid_thw"], g["sha256"][:16])
+    for name, h, w, smooth in LLAVA_CASES:
+        a = synth.synth_image(1234, "prel." + name, h, w, smooth)
+        out = l(images=[Image.fromarray(a)], return_tensors="np")
+        pv = np.ascontiguousarray(out["pixel_values"][0], dtype=np.float32)
+        g = {"name": name, "seed": 1234, "h": h, "w": w, "smooth": smooth, "pinpoints": LLAVA_PINPOINTS,
+             "n_crops": int(pv.shape[0]), "image_size": [int(v) for v in out["image_sizes"][0]],
+             "sha256": hashlib.sha256(pv.tobytes()).hexdigest(), "made_with": made}
+        json.dump(g, open(os.path.join(HERE, f"prel_{name}.json"), "w"), indent=1)
+        print("llava", name, g["n_crops"], g["sha256"][:16])
     for name, h, w, nc, smooth in CASES:
         a = synth.synth_image(1234, "pre." + name, h, w, smooth)
         pv, (H, W) = pipeline(a, nc)

@@ -129,3 +129,74 @@ def test_inference_process_device_feeds_custom_forward(tmp_path):
         r_ref, _ = model.custom_forward(**d2)
         torch.cuda.synchronize()
         assert torch.isfinite(r_dev).all() and (r_dev - r_ref).abs().max().item() < 1e-5
+
+
+# ---------------------------------------------------------------- Qwen2-VL / LLaVA-NeXT image processors
+from oracle import llava_next_image_oracle as LO  # noqa: E402
+from oracle import qwen2vl_image_oracle as QO  # noqa: E402
+
+GOLDEN_Q = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "preq_*.json")))
+GOLDEN_L = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "prel_*.json")))
+QL_CASES = [(336, 336), (500, 375), (375, 500), (1200, 1600), (97, 133), (30, 2000), (2000, 30), (448, 448), (28, 28), (3, 5)]
+
+
+@pytest.mark.parametrize("hw", QL_CASES, ids=[f"{h}x{w}" for h, w in QL_CASES])
+def test_qwen_image_transform_is_bit_exact(hw):
+    h, w = hw
+    a = synth.synth_image(13, f"q.{h}.{w}", h, w, True)
+    ref, grid = QO.preprocess(a)
+    pix, thw = P.qwen_image_batch([a])
+    torch.cuda.synchronize()
+    assert thw.tolist() == [list(grid)]
+    assert np.array_equal(pix.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("hw", QL_CASES, ids=[f"{h}x{w}" for h, w in QL_CASES])
+def test_llava_image_transform_is_bit_exact(hw):
+    h, w = hw
+    a = synth.synth_image(13, f"l.{h}.{w}", h, w, True)
+    ref, size = LO.preprocess(a, max_crops=5)
+    pix, sizes = P.llava_image_batch([a], max_crops=5)
+    torch.cuda.synchronize()
+    assert sizes.tolist() == [list(size)]
+    assert np.array_equal(pix[0].cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("path", GOLDEN_Q + GOLDEN_L, ids=[os.path.basename(p)[:-5] for p in GOLDEN_Q + GOLDEN_L])
+def test_image_transforms_match_real_processor_digests(path):
+    g = json.load(open(path))
+    if "image_grid_thw" in g:
+        a = synth.synth_image(g["seed"], "preq." + g["name"], g["h"], g["w"], g["smooth"])
+        pix, thw = P.qwen_image_batch([torch.from_numpy(a).cuda()], g["min_pixels"], g["max_pixels"])
+        assert thw.tolist() == [g["image_grid_thw"]]
+    else:
+        a = synth.synth_image(g["seed"], "prel." + g["name"], g["h"], g["w"], g["smooth"])
+        pix, sizes = P.llava_image_batch([torch.from_numpy(a).cuda()], g["pinpoints"])
+        assert sizes.tolist() == [g["image_size"]] and pix.shape[1] == g["n_crops"]
+        pix = pix[0]
+    torch.cuda.synchronize()
+    assert hashlib.sha256(np.ascontiguousarray(pix.cpu().numpy()).tobytes()).hexdigest() == g["sha256"]
+
+
+def test_qwen_and_llava_batches_and_errors():
+    imgs = [synth.synth_image(5, f"qb.{i}", h, w) for i, (h, w) in enumerate([(336, 336), (200, 700), (640, 480)])]
+    pix, thw = P.qwen_image_batch(imgs)
+    torch.cuda.synchronize()
+    r0 = 0
+    for b, a in enumerate(imgs):
+        ref, grid = QO.preprocess(a)
+        assert thw[b].tolist() == list(grid)
+        assert np.array_equal(pix[r0:r0 + ref.shape[0]].cpu().numpy(), ref)
+        r0 += ref.shape[0]
+    assert r0 == pix.shape[0]
+    pixl, sizes = P.llava_image_batch(imgs)                  # padded to the batch maximum, as the processor's do_pad
+    torch.cuda.synchronize()
+    Cn = pixl.shape[1]
+    for b, a in enumerate(imgs):
+        assert np.array_equal(pixl[b].cpu().numpy(), LO.preprocess(a, max_crops=Cn)[0])
+    with pytest.raises(ValueError):
+        P.qwen_image_batch([np.zeros((10, 2100, 3), dtype=np.uint8)])          # aspect ratio > 200, as the processor raises
+    with pytest.raises(ValueError):
+        P.llava_image_batch([imgs[2]], max_crops=2)
+    lib = L.load()
+    assert lib.lr_qwen_image_workspace(0, 5, 100, 200) == 0 and lib.lr_llava_image_workspace(5, 5, None, 0) == 0

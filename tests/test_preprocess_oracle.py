@@ -63,3 +63,67 @@ def test_oracle_matches_golden_digests(path):
     got = np.array([pv[0, c, y, x] for c, y, x in sample_index()], dtype=np.float64)
     assert np.abs(got - np.array(g["global_samples"])).max() < 2e-6                                       # fp32 bicubic
     assert (pv[1 + g["n_local"]:] == 0).all()
+
+
+# ---------------------------------------------------------------- Qwen2-VL / LLaVA-NeXT image processors (third party)
+from oracle import llava_next_image_oracle as LO  # noqa: E402
+from oracle import qwen2vl_image_oracle as QO  # noqa: E402
+
+GOLDEN_Q = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "preq_*.json")))
+GOLDEN_L = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "prel_*.json")))
+
+
+@pytest.mark.parametrize("case", [(336, 336, 448, 448), (700, 500, 300, 211), (1000, 1500, 336, 504), (64, 48, 336, 336), (40, 3, 9, 200)])
+def test_bicubic_resampler_restatement_is_bit_exact_with_pillow(case):
+    from PIL import Image
+    h, w, nh, nw = case
+    a = synth.synth_image(7, f"bc.{h}.{w}", h, w, True)
+    ref = np.asarray(Image.fromarray(a).resize((nw, nh), Image.BICUBIC))
+    assert np.array_equal(ref, O.resize_u8(a, nh, nw, "bicubic"))
+
+
+@pytest.mark.parametrize("path", GOLDEN_Q, ids=[os.path.basename(p)[5:-5] for p in GOLDEN_Q])
+def test_qwen_image_oracle_matches_real_processor_digest(path):
+    g = json.load(open(path))
+    a = synth.synth_image(g["seed"], "preq." + g["name"], g["h"], g["w"], g["smooth"])
+    pv, grid = QO.preprocess(a, g["min_pixels"], g["max_pixels"])
+    assert list(grid) == g["image_grid_thw"]
+    assert hashlib.sha256(pv.tobytes()).hexdigest() == g["sha256"]          # bit-exact with the transformers processor
+
+
+@pytest.mark.parametrize("path", GOLDEN_L, ids=[os.path.basename(p)[5:-5] for p in GOLDEN_L])
+def test_llava_image_oracle_matches_real_processor_digest(path):
+    g = json.load(open(path))
+    a = synth.synth_image(g["seed"], "prel." + g["name"], g["h"], g["w"], g["smooth"])
+    pv, size = LO.preprocess(a, g["pinpoints"])
+    assert pv.shape[0] == g["n_crops"] and list(size) == g["image_size"]
+    assert hashlib.sha256(pv.tobytes()).hexdigest() == g["sha256"]
+
+
+def test_smart_resize_kats():
+    # the reference's processor bounds (utils/utils.py:34-44): a 336 px image is lifted to 448x448 = 32x32 patches = 256 slots
+    assert QO.smart_resize(336, 336, 28, 256 * 28 * 28, 1280 * 28 * 28) == (448, 448)
+    assert QO.smart_resize(1200, 1600, 28, 256 * 28 * 28, 1280 * 28 * 28) == (840, 1148)
+    assert QO.smart_resize(42, 70, 28, 56 * 56, 1280 * 28 * 28) == (56, 56)          # Python round() is half-to-even: 1.5 -> 2, 2.5 -> 2
+    assert QO.smart_resize(3, 5, 28, 256 * 28 * 28, 1280 * 28 * 28) == (364, 588)
+    with pytest.raises(ValueError):
+        QO.smart_resize(10, 2100)
+
+
+def test_oracles_against_live_processors_when_importable():
+    """Where transformers' PIL-backend processors import (this image: yes), re-run them instead of trusting the digests."""
+    try:
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+        from make_preprocess_goldens import third_party_processors
+        q, l = third_party_processors()
+    except Exception as e:                                   # pragma: no cover
+        pytest.skip(f"processors not importable: {e}")
+    from PIL import Image
+    for (h, w) in [(123, 456), (640, 480)]:
+        a = synth.synth_image(21, f"live.{h}.{w}", h, w, True)
+        out = q(images=[Image.fromarray(a)], return_tensors="np")
+        pv, grid = QO.preprocess(a)
+        assert np.array_equal(out["pixel_values"], pv) and out["image_grid_thw"][0].tolist() == list(grid)
+        out = l(images=[Image.fromarray(a)], return_tensors="np")
+        assert np.array_equal(out["pixel_values"][0], LO.preprocess(a)[0])
