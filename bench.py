@@ -339,6 +339,20 @@ def main():
                                     "pixel_bytes_per_step": pix.numel() * 4, "note": "pinned host fp32 pixels copied in every step"}
             del model, pix_host
             torch.cuda.empty_cache()
+            if a.model == "phi3v":
+                # the image hand-over in front of the path: decoded uint8 336 px image -> pixel_values rows
+                from llava_reward_amd import preprocess
+                img = torch.from_numpy(synth.synth_image(1234, "bench.image", 336, 336)).cuda()
+                preprocess.hd_transform_batch([img] * B, a.num_crops, out=pix)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    preprocess.hd_transform_batch([img] * B, a.num_crops, out=pix)
+                torch.cuda.synchronize()
+                us = 1e6 * (time.perf_counter() - t1) / (5 * B)
+                res["input_handover"] = {"kernel": "lr_hd_transform (uint8 336x336 -> [%d,3,336,336] fp32, local crops bit-exact with Pillow)" % (ncrop),
+                                         "us_per_image": us, "images_per_sec": 1e6 / us,
+                                         "hbm_GBps_algorithmic": (ncrop * 3 * 336 * 336 * 4 + 336 * 336 * 3) / us / 1e3}
             if precise and not a.no_fast_mode:
                 # secondary figure: the single-pass f16 mode of the same workload (noise-limited parity)
                 fm = build_model("f16")
