@@ -176,7 +176,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=32, help="rows per GPU")
-    ap.add_argument("--dtype", default="f16x2", choices=["f16x2", "f16", "bf16", "bf16x2"],
+    ap.add_argument("--dtype", default="f16x2", choices=["f16x2", "f16x2f8", "f16", "bf16", "bf16x2"],
                     help="MFMA operands: f16x2 = split-operand parity mode (default, rewards within 1e-3 of the fp32 reference); "
                          "f16 / bf16 = single-pass fast modes (noise-limited, DESIGN.md §4)")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the secondary single-pass f16 measurement")
@@ -239,7 +239,7 @@ def main():
     S = gb["input_ids"].shape[1]
     ids = torch.from_numpy(gb["input_ids"][rows]).cuda()
     mask = torch.from_numpy(gb["attention_mask"][rows]).cuda()
-    precise = a.dtype.endswith("x2")
+    precise = "x2" in a.dtype
     if a.model == "qwen":
         sizes = torch.from_numpy(gb["image_grid_thw"][rows])
         pix = torch.randn(B * 32 * 32, cfg.vision.patch_dim, device="cuda", generator=gen)   # normalised pixel noise, fp32

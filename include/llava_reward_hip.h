@@ -89,7 +89,10 @@ typedef struct lr_model_desc {
     int32_t ca_token_id, max_patches;
     /* Split-operand ("precise") mode, any backbone: every activation that feeds an MFMA is carried as hi + lo in the
      * operand type (f16: 22 mantissa bits), weights stay single (bf16 checkpoints are exact in f16); every contraction
-     * costs 2x (linears) / 3x (attention) the MFMA work.  0 = single-pass operands (default). */
+     * costs 2x (linears) / 3x (attention) the MFMA work.  0 = single-pass operands (default).
+     * 2 = the same, with the residual pass of every GEMM that runs on the deep-pipelined kernel made in e4m3 (F16 operands only):
+     * the residual half of A is re-encoded in place with one power-of-two scale per row, W gets an e4m3 twin on first use, the
+     * scaled MFMA accumulates both passes in the same registers; 1.5x instead of 2x, ~8e-6 instead of ~1e-6 per GEMM. */
     int32_t precise;
     /* rw_model_general_preference.py:398-406 `mean_hidden_state`: the SkipCA block + its RMSNorm are applied to every token and
      * the value head reads the attention-mask-weighted mean (fp32 path; rewards are [B, value_head_dim] in train and eval). */
@@ -166,6 +169,17 @@ int lr_op_attention_split(const void* Q, const void* K, const void* V, void* O, 
 int lr_op_attention_segments(const void* Q, const void* K, const void* V, void* O, const int32_t* cu_seqlens_host, int n_seg,
                              int ldq, int ldo, int qoff, int koff, int voff, int heads, int head_dim, float scale,
                              int operand_dtype, void* hip_stream);
+/* W8A8 mode: rows of an operand-typed matrix -> OCP e4m3 bytes q [rows, K] + one fp32 scale per row (max|x| / 448), and
+ * C = epilogue((A8 W8^T) * ascale[m] * wscale[n]) on v_mfma_scale_f32_16x16x128_f8f6f4; K multiple of 128. */
+int lr_op_quantize_rows_fp8(const void* x, int rows, int K, int ldx, void* q, float* scale, int operand_dtype, void* hip_stream);
+int lr_op_gemm_fp8(const void* A8, const float* ascale, const void* W8, const float* wscale, void* C, const float* bias, int M, int N,
+                   int K, int ldc, int epi, int act, int operand_dtype, void* hip_stream);
+/* Split-operand GEMM with the e4m3 residual pass (lr_model_desc.precise == 2): A = [A_hi | A_lo] (2-byte elements, 2K per row),
+ * W [N, K], W8 = DEVICE scratch of the size of W (the e4m3 twin), aexp = DEVICE int32 [M] scratch, wexp = HOST int (in/out).
+ * flags: 1 = prepare W8 from W and store its exponent in *wexp (synchronous), 2 = re-encode the residual half of A in place
+ * (e4m3 bytes + one E8M0 exponent per row), 4 = stop there (no GEMM).  Output as lr_op_gemm_bt_split.  K multiple of 128. */
+int lr_op_gemm_bt_mixed(void* A, const void* W, void* W8, int* aexp, void* C, const float* bias, int M, int N, int K, int epi, int act,
+                        int operand_dtype, int flags, int* wexp, void* hip_stream);
 int lr_op_norm_rows(const float* x, const float* w, const float* b, void* y, int rows, int H, float eps,
                     int operand_dtype, void* hip_stream);
 int lr_op_synth_fill(float* out, size_t n, uint64_t seed, const char* name, float std, float offset, int bf16_round,

@@ -113,6 +113,12 @@ struct GemmParams {
     // split-operand mode with weights that are NOT exact in the operand type (e.g. LoRA-merged fp32 weights): Wlo holds the
     // rounding residuals of W (same layout) and K = 3 kw runs A = [hi | lo | hi] against [W | W | Wlo]
     const void* Wlo;
+    // W8A8 mode (launch_gemm_bt8_fp8): dequantisation scales, one per row of A and one per row of W
+    const float* ascale;
+    const float* wscale;
+    // split-operand mode with an e4m3 residual pass (launch_gemm_bt8_mixed): E8M0 scale of every residual row, and of W8
+    const int* aexp;
+    int wexp;
 };
 
 struct AttnParams {

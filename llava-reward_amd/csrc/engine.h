@@ -82,6 +82,10 @@ struct lr_engine {
     bool llava = false, qwen = false;
     int op_dt = DT_BF16;
     int prec = 0;              // split-operand mode: operand buffers are [hi | lo], twice as wide
+    int lo8 = 0;               // ... with the residual pass of the big GEMMs in e4m3 (desc.precise == 2)
+    int* aexp = nullptr; size_t aexp_cap = 0;        // E8M0 exponent of every residual row of the GEMM being launched
+    unsigned* amax_word = nullptr;
+    std::unordered_map<const void*, int> w8exp;      // weight base pointer -> E8M0 exponent of its prepared e4m3 twin
 
     // Qwen2.5-VL ViT geometry: head dim vhd stored vhdp wide, MLP width vI stored vIp wide, patch vector vK padded to vKpad
     int vH = 0, vhd = 0, vhdp = 0, vHp = 0, vI = 0, vIp = 0, vK = 0, vKpad = 0, vHm = 0, vunit = 0;
@@ -245,7 +249,11 @@ template <typename F> int guarded(lr_engine* e, F&& f) {
 
 // Split-operand mode: callers pass LOGICAL shapes; here A becomes [A_hi | A_lo] (K doubled, W re-read from column 0) and an
 // operand-typed output becomes [C_hi | C_lo].
-inline void apply_prec(const lr_engine* e, GemmParams& p) {
+// With desc.precise == 2 the residual pass of a GEMM that runs on the deep-pipelined kernel is made in e4m3: the residual half of
+// A is re-encoded in place (stream-ordered, right here: every operand buffer feeds exactly one GEMM after it is produced) and W's
+// e4m3 twin is prepared on first use in the rows of its residual buffer (exact weights only; one synchronisation per weight).
+// apply_prec_base only rewrites the parameters (no side effects); upgrade_lo8 commits the e4m3 form right before the launch.
+inline void apply_prec_base(const lr_engine* e, GemmParams& p) {
     if (!e->prec) return;
     p.kw = p.K; p.K *= 2; p.lda *= 2;
     auto it = e->wbuf_of.find(p.W);
@@ -254,6 +262,39 @@ inline void apply_prec(const lr_engine* e, GemmParams& p) {
         p.K = 3 * p.kw;
     }
     if (p.epi == EPI_OUT_OP || p.epi == EPI_SWIGLU_OP || p.epi == EPI_ROPE_OP) { p.split = p.ldc; p.ldc *= 2; }
+}
+// The choice must not depend on M: a row's reward has to be bit-identical whatever else is in the batch (sharding across GPUs
+// must not change a preference), so every eligible GEMM takes this form -- on the deep-pipelined kernel -- at any row count.
+inline bool lo8_eligible(const lr_engine* e, const GemmParams& p) {      // p after apply_prec_base
+    if (!e->lo8 || p.kw <= 0 || p.Wlo != nullptr) return false;          // (Wlo: weights inexact in the operand type)
+    if (e->wbuf_of.find(p.W) == e->wbuf_of.end()) return false;
+    const bool aligned = p.N % 8 == 0 && p.ldc % 8 == 0 && (((uintptr_t)p.C) & 15) == 0 && (!p.bias || (((uintptr_t)p.bias) & 15) == 0);
+    return aligned && p.kw % 128 == 0 && p.ldw == p.kw && (e->gemm_tile < 0 || e->gemm_tile == 6);
+}
+inline void upgrade_lo8(lr_engine* e, GemmParams& p, hipStream_t st) {
+    if (p.aexp) return;
+    if (lo8_eligible(e, p)) {
+        auto it = e->wbuf_of.find(p.W);
+        auto w8 = e->w8exp.find(p.W);
+        if (w8 == e->w8exp.end()) {
+            if (!e->amax_word) e->amax_word = (unsigned*)e->dalloc(256, false);
+            const int E = prepare_weight_e4m3(p.W, p.ldw, p.kw, p.N, e->wbufs[it->second].lo, e->op_dt, e->amax_word, st);
+            w8 = e->w8exp.emplace(p.W, E).first;
+        }
+        if ((size_t)p.M > e->aexp_cap) {
+            e->aexp_cap = ((size_t)p.M + 4095) & ~(size_t)4095;
+            e->aexp = (int*)e->dalloc(e->aexp_cap * 4, false);
+        }
+        launch_quantize_lo_inplace(const_cast<void*>(p.A), p.lda, p.kw, p.M, e->aexp, e->op_dt, st);
+        p.K = p.kw + p.kw / 2;
+        p.Wlo = e->wbufs[it->second].lo;
+        p.aexp = e->aexp;
+        p.wexp = w8->second;
+    }
+}
+inline void apply_prec(lr_engine* e, GemmParams& p, hipStream_t st) {
+    apply_prec_base(e, p);
+    upgrade_lo8(e, p, st);
 }
 inline void apply_prec(const lr_engine* e, AttnParams& p) {
     if (!e->prec) return;
@@ -264,7 +305,7 @@ inline void apply_prec(const lr_engine* e, AttnParams& p) {
 inline void gemm(lr_engine* e, hipStream_t st, const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int lda,
           int ldw, int ldc, int epi, int act) {
     GemmParams p{A, W, C, bias, M, N, K, lda, ldw, ldc, epi, act, nullptr, 0, 0};
-    apply_prec(e, p);
+    apply_prec(e, p, st);
     launch_gemm_bt(p, e->op_dt, e->gemm_tile, st);
 }
 

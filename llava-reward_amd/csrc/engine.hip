@@ -155,6 +155,8 @@ void validate_desc(const lr_model_desc& d) {
     if (d.value_head_dim < 1 || d.value_head_dim > 64) bad("value_head_dim out of range");
     if (d.max_batch < 1 || d.max_seq < 1) bad("capacity fields must be positive");
     if (d.operand_dtype != LR_DT_BF16 && d.operand_dtype != LR_DT_F16) bad("operand_dtype must be BF16 or F16");
+    if (d.precise < 0 || d.precise > 2) bad("precise must be 0, 1 or 2");
+    if (d.precise == 2 && d.operand_dtype != LR_DT_F16) bad("precise == 2 (e4m3 residual pass) needs F16 operands");
     if (d.layers < 0 || d.clip_layers < 0) bad("layer counts must be non-negative");
 }
 
@@ -173,8 +175,9 @@ void run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_ma
         launch_norm_rows(h->x, L.ln1, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st, h->prec);
         {   // qkv projection with RoPE on q,k: fused in the GEMM epilogue when the deep-pipelined kernel runs
             GemmParams gp{h->h, L.qkv_w, h->qkv, L.qkv_b, Rl, Nqkv, D, D, D, Nqkv, EPI_ROPE_OP, ACT_NONE, h->cs, Hq + Hkv, h->hd};
-            apply_prec(h, gp);
-            if ((Hq + Hkv) % 256 == 0 && gemm_bt_is_deep(gp, h->gemm_tile)) {
+            apply_prec_base(h, gp);
+            if ((Hq + Hkv) % 256 == 0 && (lo8_eligible(h, gp) || gemm_bt_is_deep(gp, h->gemm_tile))) {
+                upgrade_lo8(h, gp, st);
                 launch_gemm_bt(gp, h->op_dt, h->gemm_tile, st);
             } else {
                 gemm(h, st, h->h, L.qkv_w, h->qkv32, L.qkv_b, Rl, Nqkv, D, D, D, Nqkv, EPI_OUT_F32, ACT_NONE);
@@ -250,6 +253,7 @@ int lr_create(const lr_model_desc* desc, int device, lr_handle* out) {
         e->device = device;
         e->op_dt = desc->operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16;
         e->prec = desc->precise ? 1 : 0;
+        e->lo8 = desc->precise == 2 ? 1 : 0;
         e->llava = desc->backbone == LR_BACKBONE_LLAVA_NEXT;
         e->qwen = desc->backbone == LR_BACKBONE_QWEN2_5_VL;
         if (!e->qwen) {
@@ -599,6 +603,43 @@ int lr_op_gemm_bt_split(const void* A, const void* W, void* C, const float* bias
         const bool op_out = epi == EPI_OUT_OP || epi == EPI_SWIGLU_OP;
         GemmParams p{A, W, C, bias, M, N, 2 * K, 2 * K, K, op_out ? 2 * nout : nout, epi, act, nullptr, 0, 0, K, op_out ? nout : 0};
         launch_gemm_bt(p, operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16, tile, (hipStream_t)hip_stream);
+    });
+}
+
+int lr_op_gemm_bt_mixed(void* A, const void* W, void* W8, int* aexp, void* C, const float* bias, int M, int N, int K, int epi, int act,
+                        int operand_dtype, int flags, int* wexp, void* hip_stream) {
+    return op_guard([&] {
+        const int dt = operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16;
+        hipStream_t st = (hipStream_t)hip_stream;
+        if (!wexp) throw std::runtime_error("lr_op_gemm_bt_mixed: wexp is required");
+        if (flags & 1) {                                   // prepare the e4m3 twin of W (synchronous)
+            unsigned* word = nullptr;
+            LR_HIP_CHECK(hipMalloc((void**)&word, 4));
+            *wexp = prepare_weight_e4m3(W, K, K, N, W8, dt, word, st);
+            LR_HIP_CHECK(hipFree(word));
+        }
+        if (flags & 2) launch_quantize_lo_inplace(A, 2 * K, K, M, aexp, dt, st);       // re-encode the residual half of A
+        if (flags & 4) return;
+        const int nout = epi == EPI_SWIGLU_OP ? N / 2 : N;
+        const bool op_out = epi == EPI_OUT_OP || epi == EPI_SWIGLU_OP;
+        GemmParams p{A, W, C, bias, M, N, K + K / 2, 2 * K, K, op_out ? 2 * nout : nout, epi, act, nullptr, 0, 0, K, op_out ? nout : 0, W8};
+        p.aexp = aexp; p.wexp = *wexp;
+        launch_gemm_bt8_mixed(p, dt, st);
+    });
+}
+
+int lr_op_quantize_rows_fp8(const void* x, int rows, int K, int ldx, void* q, float* scale, int operand_dtype, void* hip_stream) {
+    return op_guard([&] {
+        launch_quantize_rows_fp8(x, ldx, K, rows, q, K, scale, operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16, (hipStream_t)hip_stream);
+    });
+}
+
+int lr_op_gemm_fp8(const void* A8, const float* ascale, const void* W8, const float* wscale, void* C, const float* bias, int M, int N,
+                   int K, int ldc, int epi, int act, int operand_dtype, void* hip_stream) {
+    return op_guard([&] {
+        GemmParams p{A8, W8, C, bias, M, N, K, K, K, ldc, epi, act, nullptr, 0, 0};
+        p.ascale = ascale; p.wscale = wscale;
+        launch_gemm_bt8_fp8(p, operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16, (hipStream_t)hip_stream);
     });
 }
 

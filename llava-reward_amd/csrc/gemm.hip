@@ -245,6 +245,7 @@ bool gemm_bt_is_deep(const GemmParams& p, int tile) { return pick_tile(p, tile) 
 
 void launch_gemm_bt(const GemmParams& p, int operand_dtype, int tile, hipStream_t st) {
     if (p.M <= 0) return;
+    if (p.aexp) { launch_gemm_bt8_mixed(p, operand_dtype, st); return; }      // split-operand mode with the e4m3 residual pass
     if (p.K % 64 != 0) throw std::runtime_error("gemm_bt: K must be a multiple of 64");
     if (p.kw < 0 || (p.kw > 0 && (p.kw % 64 || p.K != (p.Wlo ? 3 : 2) * p.kw)))
         throw std::runtime_error("gemm_bt: split-operand mode needs K == 2 kw (3 kw with Wlo), kw % 64 == 0");

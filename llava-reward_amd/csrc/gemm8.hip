@@ -26,6 +26,8 @@
 //
 // Column mapping inside a block tile: wave wc owns columns wc*64 + qb*32 + [0,32) for qb = 0,1, so the
 // SwiGLU pair (gate block, up block: weight rows interleaved in 32s) stays in one lane/register.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -38,8 +40,32 @@ namespace lr {
 //      Diagnostics for tools/gemm_bench.py / tools/gemm_stamps.py only.
 // EPI is a template parameter so that each instantiation carries ONE epilogue: with all of them
 // unrolled in one kernel the code was ~130 KB and every tile's epilogue ran out of the instruction cache.
-template <typename OT, int PF, int NS, int DBG, int EPI, int PB>
+// F8: the operands are OCP e4m3 bytes (W8A8 mode).  Nothing about the tile images, the DMA stream or the
+// fragment reads changes -- p.K / lda / ldw count 2-byte units, a K-tile is still 128 bytes of a row -- only the matrix
+// instruction: v_mfma_scale_f32_16x16x128_f8f6f4 takes 32 bytes per lane, and the two 16-byte fragments a lane already holds
+// for the two f16 k-steps (chunks q and 4+q of the row) are those 32 bytes; A and B use the same chunk order, so the
+// contraction sees a consistent permutation of k.  One instruction per 16x16 tile and K-tile (twice the K at the same MFMA
+// time); the per-row / per-channel dequantisation scales multiply the accumulators in front of the epilogue.
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma_f8(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1, const f32x4 c) {
+    const v8i_t a = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+    const v8i_t b = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127);     // e4m3 x e4m3, scales 2^0
+}
+
+__device__ __forceinline__ f32x4 mfma_f8s(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1, const f32x4 c, const int ea, const int eb) {
+    const v8i_t a = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+    const v8i_t b = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, ea, 0, eb);     // x 2^(ea - 127) x 2^(eb - 127)
+}
+
+// F8 == 2: split-operand mode with an e4m3 residual pass: A rows are [hi f16 x kw | lo e4m3 x kw bytes], the K loop
+// runs kw / 64 f16 K-tiles against W and then kw / 128 e4m3 K-tiles against W8 (the e4m3 twin of W, in the rows of p.Wlo), with
+// the power-of-two scales of the residual rows (p.aexp, E8M0 per row) and of W8 (p.wexp, one per tensor) applied by the matrix
+// instruction itself, so both passes meet in the same accumulators and every epilogue is the one of the 16-bit form.
+template <typename OT, int PF, int NS, int DBG, int EPI, int PB, int F8 = 0>
 __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
+    static_assert(!F8 || PB == 2, "the fp8 operand path exists in the super-phase schedule only");
     constexpr int E_ = EPI & 15;          // epilogue selector; bit 4 = bias present (SwiGLU / RoPE epilogues)
     constexpr bool BIAS_ = (EPI & 16) != 0;
 
@@ -57,6 +83,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
     const int Mt = (p.M + BM - 1) / BM, Nt = (p.N + BN - 1) / BN;
     const int nwg = Mt * Nt;
     const int nk = p.K / BK;
+    const int nk_hi = F8 == 2 ? p.kw / BK : nk;      // K-tiles of 16-bit operands; the rest are e4m3
     const int Gtot = 4 * nk;
     typedef __attribute__((address_space(3))) char lds_char;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_char*)smem;
@@ -135,7 +162,9 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * HT + wave * 1024 + it * 8192);
             int koff = DBG == 1 ? 0 : kt * BK, koffw = koff;
             ptrdiff_t wsel = 0;
-            if (p.kw > 0) {                      // split-operand mode: A = [hi | lo (| hi)], W repeats along K (, then its residuals)
+            if constexpr (F8 == 2) {             // A = [hi | lo8]: the row continues; W8 sits in the rows of Wlo
+                if (koff >= p.kw) { koffw = koff - p.kw; wsel = wlo_delta; }
+            } else if (p.kw > 0) {               // split-operand mode: A = [hi | lo (| hi)], W repeats along K (, then its residuals)
                 if (koff >= 2 * p.kw) { koff -= 2 * p.kw; koffw = koff; wsel = wlo_delta; }
                 else if (koff >= p.kw) koffw = koff - p.kw;
             }
@@ -156,6 +185,22 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[q][i][j][r] = 0.f;
+
+        // F8 == 2: E8M0 exponents of this tile's residual rows (one per A row a lane feeds: [A half][row tile]) and of W8.  Ordinary
+        // loads: retired here, in front of the DMA stream, so that no compiler-placed vmcnt wait can appear inside the K loop.
+        int ea[2][4] = {{127, 127, 127, 127}, {127, 127, 127, 127}};
+        const int eb = p.wexp;
+        if constexpr (F8 == 2) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ea[h2][i] = p.aexp[min(m0 + h2 * 128 + wr * 64 + i * 16 + l15, p.M - 1)];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(ea[h2][i]));
+        }
 
         if constexpr (PB == 2) {
         // ================= super-phase schedule (product) =================
@@ -190,7 +235,11 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
             for (int f = 0; f < 4; ++f) bf[f] = *(const uint4*)(smem + 1 * HT + boff[f]);      // B0 of K-tile 0 (slot 1)
         }
         int rslot = 0, gi = PF2;
-        for (int kt = 0; kt < nk; ++kt) {
+        // One K-tile.  A generic lambda so that the mixed form (F8 == 2) can run two loops, 16-bit tiles then e4m3 tiles, each
+        // with its own straight-line body: a run-time branch around the two MFMA kinds merges 64 accumulator registers behind it
+        // and spills inside the K loop.
+        auto ktile = [&](auto lo_tag, const int kt) {
+            constexpr bool LO = decltype(lo_tag)::value;
             int s2 = rslot + 2; s2 = s2 >= NS ? s2 - NS : s2;
             int s3 = rslot + 3; s3 = s3 >= NS ? s3 - NS : s3;
             int s5 = rslot + 5; s5 = s5 >= NS ? s5 - NS : s5;
@@ -233,22 +282,48 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                     }
                     constexpr int q0 = 0, q1 = 1, q3 = 3, q2 = 2;
                     const int qa = sp == 0 ? q0 : q3, qb = sp == 0 ? q1 : q2;      // first block uses bf (B0), second bg (B1)
+                    if constexpr (F8 == 1 || (F8 == 2 && LO)) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc[qa][i][j] = F8 == 1 ? mfma_f8(af[i * 2], af[i * 2 + 1], bf[j * 2], bf[j * 2 + 1], acc[qa][i][j])
+                                                        : mfma_f8s(af[i * 2], af[i * 2 + 1], bf[j * 2], bf[j * 2 + 1], acc[qa][i][j], ea[sp][i], eb);
+                    } else {
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
                             for (int j = 0; j < 2; ++j) acc[qa][i][j] = Op<OT>::mfma16(af[i * 2 + ks], bf[j * 2 + ks], acc[qa][i][j]);
+                    }
                     if (sp == 1 && kt + 1 < nk) {
 #pragma unroll
                         for (int f = 0; f < 4; ++f) bf[f] = *(const uint4*)(sB0n + boff[f]);
                     }
+                    if constexpr (F8 == 1 || (F8 == 2 && LO)) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc[qb][i][j] = F8 == 1 ? mfma_f8(af[i * 2], af[i * 2 + 1], bg[j * 2], bg[j * 2 + 1], acc[qb][i][j])
+                                                        : mfma_f8s(af[i * 2], af[i * 2 + 1], bg[j * 2], bg[j * 2 + 1], acc[qb][i][j], ea[sp][i], eb);
+                    } else {
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
                             for (int j = 0; j < 2; ++j) acc[qb][i][j] = Op<OT>::mfma16(af[i * 2 + ks], bg[j * 2 + ks], acc[qb][i][j]);
+                    }
+                    if constexpr (F8 != 0) {
+                        // pin this segment's MFMAs in front of its closing barrier: they touch no memory, so nothing else stops
+                        // the optimiser from sinking them into the next segment (it did: all 32 ended up in one)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) { asm volatile("" : "+v"(acc[qa][i][j])); asm volatile("" : "+v"(acc[qb][i][j])); }
+                    }
                 }
                 __builtin_amdgcn_s_setprio(0);
                 if constexpr (DBG == 3) t3 = stamp();
@@ -262,6 +337,12 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
             }
             rslot += 4;
             rslot = rslot >= NS ? rslot - NS : rslot;
+        };
+        {
+            int kt = 0;
+            for (; kt < nk_hi; ++kt) ktile(std::false_type{}, kt);
+            if constexpr (F8 == 2)
+                for (; kt < nk; ++kt) ktile(std::true_type{}, kt);
         }
         if (wr == 0) LR_BARRIER();                      // balance the stagger barrier
         } else {
@@ -395,6 +476,35 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(acc[q][i][0]), "v"(acc[q][i][1])); }
             continue;
+        }
+
+        if constexpr (F8 == 1) {    // dequantise: C[m][n] *= ascale[m] * wscale[n]
+            // (the pointers are laundered so that these ordinary loads cannot be hoisted above the K loop, where their vmcnt
+            //  waits would drain the DMA ring in front of every ds_read)
+            const float* asc = p.ascale;
+            const float* wsc = p.wscale;
+            asm volatile("" : "+s"(asc), "+s"(wsc) :: "memory");
+            float sw[2][2];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = n0 + wc * 64 + qb * 32 + j * 16 + l15;
+                    sw[qb][j] = col < p.N ? wsc[col] : 0.f;
+                }
+#pragma unroll
+            for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = m0 + qa * 128 + wr * 64 + i * 16 + 4 * l4 + r;
+                        const float sa = row < p.M ? asc[row] : 0.f;
+#pragma unroll
+                        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acc[qa == 0 ? qb : 3 - qb][i][j][r] *= sa * sw[qb][j];
+                    }
         }
 
         // ---- epilogue ----  quadrant index q -> (qa, qb): 0:(0,0) 1:(0,1) 2:(1,1) 3:(1,0)
@@ -583,12 +693,12 @@ static int num_cus() {
     return n;
 }
 
-template <typename OT, int PF, int DBG, int EPI, int PB = 0>
+template <typename OT, int PF, int DBG, int EPI, int PB = 0, int F8 = 0>
 static void launch8(const GemmParams& p, bool persistent, hipStream_t st) {
     constexpr int NS = 10;
     constexpr int smem = NS * 16384;
     static bool attr_set = false;
-    auto kfn = gemm_bt8_kernel<OT, PF, NS, DBG, EPI, PB>;
+    auto kfn = gemm_bt8_kernel<OT, PF, NS, DBG, EPI, PB, F8>;
     if (!attr_set) {
         LR_HIP_CHECK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
@@ -599,19 +709,19 @@ static void launch8(const GemmParams& p, bool persistent, hipStream_t st) {
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), smem, st, p);
 }
 
-template <typename OT, int PF, int DBG, int PB = 0>
+template <typename OT, int PF, int DBG, int PB = 0, int F8 = 0>
 static void launch8_epi(const GemmParams& p, bool persistent, hipStream_t st) {
     switch (p.epi) {
-        case EPI_OUT_OP: launch8<OT, PF, DBG, EPI_OUT_OP, PB>(p, persistent, st); break;
-        case EPI_OUT_F32: launch8<OT, PF, DBG, EPI_OUT_F32, PB>(p, persistent, st); break;
-        case EPI_RESADD_F32: launch8<OT, PF, DBG, EPI_RESADD_F32, PB>(p, persistent, st); break;
+        case EPI_OUT_OP: launch8<OT, PF, DBG, EPI_OUT_OP, PB, F8>(p, persistent, st); break;
+        case EPI_OUT_F32: launch8<OT, PF, DBG, EPI_OUT_F32, PB, F8>(p, persistent, st); break;
+        case EPI_RESADD_F32: launch8<OT, PF, DBG, EPI_RESADD_F32, PB, F8>(p, persistent, st); break;
         case EPI_SWIGLU_OP:
-            if (p.bias) launch8<OT, PF, DBG, EPI_SWIGLU_OP | 16, PB>(p, persistent, st);
-            else launch8<OT, PF, DBG, EPI_SWIGLU_OP, PB>(p, persistent, st);
+            if (p.bias) launch8<OT, PF, DBG, EPI_SWIGLU_OP | 16, PB, F8>(p, persistent, st);
+            else launch8<OT, PF, DBG, EPI_SWIGLU_OP, PB, F8>(p, persistent, st);
             break;
         case EPI_ROPE_OP:
-            if (p.bias) launch8<OT, PF, DBG, EPI_ROPE_OP | 16, PB>(p, persistent, st);
-            else launch8<OT, PF, DBG, EPI_ROPE_OP, PB>(p, persistent, st);
+            if (p.bias) launch8<OT, PF, DBG, EPI_ROPE_OP | 16, PB, F8>(p, persistent, st);
+            else launch8<OT, PF, DBG, EPI_ROPE_OP, PB, F8>(p, persistent, st);
             break;
         default: throw std::runtime_error("gemm_bt8: unknown epilogue");
     }
@@ -632,6 +742,38 @@ static void launch8_variant(const GemmParams& p, int variant, hipStream_t st) {
         case 15: launch8<OT, 5, 5, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: ds_reads + MFMA alone (no LDS-DMA in the loop)
         default: throw std::runtime_error("gemm_bt8: unknown variant");
     }
+}
+
+// W8A8: A = e4m3 bytes [M, K8] with one fp32 scale per row, W = e4m3 bytes [N, K8] with one scale per output channel; the
+// activations C leaves as are operand_dtype (f16 / bf16) or fp32, exactly as in the 16-bit form.  p.K / lda / ldw are given in
+// BYTES here and halved for the kernel (2-byte units).
+void launch_gemm_bt8_fp8(GemmParams p, int operand_dtype, hipStream_t st) {
+    if (p.M <= 0) return;
+    if (!p.ascale || !p.wscale) throw std::runtime_error("gemm_bt8_fp8: row / channel scales are required");
+    if (p.K % 128 || p.lda % 16 || p.ldw % 16 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15))
+        throw std::runtime_error("gemm_bt8_fp8: K must be a multiple of 128 bytes, rows 16-byte aligned");
+    if (p.kw || p.split || p.Wlo) throw std::runtime_error("gemm_bt8_fp8: no split-operand form");
+    if (p.N % 8 || p.ldc % 8 || ((uintptr_t)p.C & 15) || (p.bias && ((uintptr_t)p.bias & 15)))
+        throw std::runtime_error("gemm_bt8_fp8: N and ldc must be multiples of 8 and C/bias 16-byte aligned");
+    if (p.epi == EPI_ROPE_OP && (!p.rope_cs || p.rope_hd % 16 || p.rope_cols % 256 || p.rope_cols % p.rope_hd || ((uintptr_t)p.rope_cs & 15)))
+        throw std::runtime_error("gemm_bt8_fp8: bad RoPE epilogue parameters");
+    p.K /= 2; p.lda /= 2; p.ldw /= 2;
+    if (operand_dtype == DT_F16) launch8_epi<F16, 6, 0, 2, 1>(p, true, st);
+    else launch8_epi<BF16, 6, 0, 2, 1>(p, true, st);
+}
+
+// Split-operand mode with the e4m3 residual pass (kernel form F8 == 2, see there).  p as for the 16-bit split form but
+// K = kw + kw / 2 (2-byte units), Wlo = the rows that hold W8, aexp / wexp = the E8M0 scales.
+void launch_gemm_bt8_mixed(const GemmParams& p, int operand_dtype, hipStream_t st) {
+    if (p.M <= 0) return;
+    if (p.kw <= 0 || p.kw % 128 || p.K != p.kw + p.kw / 2 || !p.Wlo || !p.aexp)
+        throw std::runtime_error("gemm_bt8_mixed: needs kw % 128 == 0, K == 1.5 kw, W8 rows and row exponents");
+    if (p.N % 8 || p.ldc % 8 || ((uintptr_t)p.C & 15) || (p.bias && ((uintptr_t)p.bias & 15)))
+        throw std::runtime_error("gemm_bt8_mixed: N and ldc must be multiples of 8 and C/bias 16-byte aligned");
+    if (p.epi == EPI_ROPE_OP && (!p.rope_cs || p.rope_hd % 16 || p.rope_cols % 256 || p.rope_cols % p.rope_hd || ((uintptr_t)p.rope_cs & 15)))
+        throw std::runtime_error("gemm_bt8_mixed: bad RoPE epilogue parameters");
+    if (operand_dtype == DT_F16) launch8_epi<F16, 6, 0, 2, 2>(p, true, st);
+    else launch8_epi<BF16, 6, 0, 2, 2>(p, true, st);
 }
 
 void launch_gemm_bt8(const GemmParams& p, int operand_dtype, int variant, hipStream_t st) {

@@ -304,8 +304,9 @@ extern "C" int lr_forward_qwen(lr_handle h, const int64_t* input_ids, const int6
             launch_norm_rows(h->vx, L.n1, nullptr, h->vhn, N, vH, d.vit_eps, h->op_dt, st, h->prec);
             {
                 GemmParams gp{h->vhn, L.qkv_w, h->vqkv, L.qkv_b, N, 3 * vHp, vH, vH, vH, 3 * vHp, EPI_ROPE_OP, ACT_NONE, h->vcs, 2 * vHp, vhdp};
-                apply_prec(h, gp);
-                if ((2 * vHp) % 256 == 0 && gemm_bt_is_deep(gp, h->gemm_tile)) {
+                apply_prec_base(h, gp);
+                if ((2 * vHp) % 256 == 0 && (lo8_eligible(h, gp) || gemm_bt_is_deep(gp, h->gemm_tile))) {
+                    upgrade_lo8(h, gp, st);
                     launch_gemm_bt(gp, h->op_dt, h->gemm_tile, st);
                 } else {
                     gemm(h, st, h->vhn, L.qkv_w, h->vqkv32, L.qkv_b, N, 3 * vHp, vH, vH, vH, 3 * vHp, EPI_OUT_F32, ACT_NONE);

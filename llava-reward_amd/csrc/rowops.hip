@@ -1,6 +1,9 @@
 // HBM-bound row kernels of the scoring path: norms, patchify, embedding scatter, RoPE, HD gather,
 // the fp32 reward tail, and weight packing / synthesis.  One wave (64 lanes) per row wherever a
 // row reduction is needed; 16-byte fp32 loads and 8-byte operand stores.
+#include <cmath>
+#include <cstring>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -824,6 +827,156 @@ void launch_cvt_to_f32(const void* src, int src_dtype, float* dst, size_t n, hip
     if (!n) return;
     const int grid = (int)std::min<size_t>((n + 255) / 256, 16384);
     hipLaunchKernelGGL(cvt_to_f32_kernel, dim3(grid), dim3(256), 0, st, src, src_dtype, dst, n);
+}
+
+// ---- W8A8 mode: per-row dynamic quantisation to OCP e4m3 ----
+// q[m][k] = e4m3(x[m][k] / s[m]), s[m] = max_k |x[m][k]| / 448 (1 when the row is zero).  One wave per row; the division is the
+// correctly rounded fp32 one and the conversion rounds to nearest even, so the oracle reproduces every byte.
+template <typename OT>
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const unsigned short* __restrict__ x, int ldx, int K, int rows,
+                                                                unsigned char* __restrict__ q, int ldq, float* __restrict__ scale) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const unsigned short* xr = x + (size_t)row * ldx;
+    float amax = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        const uint4 v = *(const uint4*)(xr + k);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            amax = fmaxf(amax, fabsf(Op<OT>::to_f32((unsigned short)(w[i] & 0xFFFF))));
+            amax = fmaxf(amax, fabsf(Op<OT>::to_f32((unsigned short)(w[i] >> 16))));
+        }
+    }
+    amax = wave_max(amax);
+    const float s = amax > 0.f ? amax / 448.0f : 1.0f;
+    if (lane == 0) scale[row] = s;
+    unsigned char* qr = q + (size_t)row * ldq;
+    for (int k = lane * 8; k < K; k += 512) {
+        const uint4 v = *(const uint4*)(xr + k);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        float f[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = Op<OT>::to_f32((unsigned short)(w[i] & 0xFFFF)) / s;
+            f[2 * i + 1] = Op<OT>::to_f32((unsigned short)(w[i] >> 16)) / s;
+        }
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+        *(uint2*)(qr + k) = make_uint2((unsigned)lo, (unsigned)hi);
+    }
+}
+
+// ---- split-operand mode, e4m3 residual pass: power-of-two scaled e4m3 with the scale in E8M0 form ----
+__device__ __forceinline__ int e8m0_of_amax(float amax) {      // 2^(E-127) puts amax into [128, 256) <= 448; E = 127 for a zero row
+    return amax > 0.f ? 127 + (ilogbf(amax) - 7) : 127;
+}
+
+// Rows [hi x K | lo x K] of 2-byte elements: the residual half is rewritten IN PLACE as K e4m3 bytes (the first half of its own
+// space) + one E8M0 exponent per row.  One wave per row, two sweeps (row maximum, then convert); a sweep step reads bytes
+// [1024 t, 1024 t + 1024) of the residual half and writes [512 t, 512 t + 512): only bytes that were already consumed.
+template <typename OT>
+__global__ __launch_bounds__(256) void quantize_lo_inplace_kernel(unsigned short* __restrict__ a, int ld, int K, int rows, int* __restrict__ aexp) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    unsigned short* lo = a + (size_t)row * ld + K;
+    float amax = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        const uint4 v = *(const uint4*)(lo + k);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            amax = fmaxf(amax, fabsf(Op<OT>::to_f32((unsigned short)(w[i] & 0xFFFF))));
+            amax = fmaxf(amax, fabsf(Op<OT>::to_f32((unsigned short)(w[i] >> 16))));
+        }
+    }
+    amax = wave_max(amax);
+    const int E = e8m0_of_amax(amax);
+    if (lane == 0) aexp[row] = E;
+    unsigned char* q = (unsigned char*)lo;
+    for (int k0 = 0; k0 < K; k0 += 512) {
+        const int k = k0 + lane * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (k < K) v = *(const uint4*)(lo + k);
+        __builtin_amdgcn_s_waitcnt(0);                       // the whole wave has its 16 bytes before anyone overwrites them
+        if (k < K) {
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+            float f[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f[2 * i] = ldexpf(Op<OT>::to_f32((unsigned short)(w[i] & 0xFFFF)), 127 - E);
+                f[2 * i + 1] = ldexpf(Op<OT>::to_f32((unsigned short)(w[i] >> 16)), 127 - E);
+            }
+            int l2 = 0, h2 = 0;
+            l2 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], l2, false);
+            l2 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], l2, true);
+            h2 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], h2, false);
+            h2 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], h2, true);
+            *(uint2*)(q + k) = make_uint2((unsigned)l2, (unsigned)h2);
+        }
+    }
+}
+
+void launch_quantize_lo_inplace(void* a, int ld, int K, int rows, int* aexp, int operand_dtype, hipStream_t st) {
+    if (rows <= 0) return;
+    if (K % 8 || ld % 8) throw std::runtime_error("quantize_lo_inplace: K and the row stride must be multiples of 8");
+    const dim3 grid((rows + 3) / 4), block(256);
+    if (operand_dtype == DT_F16) hipLaunchKernelGGL(quantize_lo_inplace_kernel<F16>, grid, block, 0, st, (unsigned short*)a, ld, K, rows, aexp);
+    else hipLaunchKernelGGL(quantize_lo_inplace_kernel<BF16>, grid, block, 0, st, (unsigned short*)a, ld, K, rows, aexp);
+}
+
+// W8 twin of a weight matrix [N, K] (2-byte elements, row stride ldw): e4m3(W * 2^(127 - E)) into the first K bytes of the rows of
+// `dst` (same row stride, in 2-byte units), one exponent per TENSOR.  amax_bits: device word, max |w| as float bits.
+template <typename OT>
+__global__ __launch_bounds__(256) void weight_amax_kernel(const unsigned short* __restrict__ w, int ldw, int K, int N, unsigned* __restrict__ amax_bits) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    float amax = 0.f;
+    for (int k = lane; k < K; k += 64) amax = fmaxf(amax, fabsf(Op<OT>::to_f32(w[(size_t)row * ldw + k])));
+    amax = wave_max(amax);
+    if (lane == 0) atomicMax(amax_bits, __float_as_uint(amax));
+}
+template <typename OT>
+__global__ __launch_bounds__(256) void weight_to_e4m3_kernel(const unsigned short* __restrict__ w, int ldw, int K, int N, int E, unsigned char* __restrict__ dst) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const unsigned short* wr = w + (size_t)row * ldw;
+    unsigned char* q = dst + (size_t)row * ldw * 2;
+    for (int k = lane * 4; k < K; k += 256) {
+        int pk = 0;
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(Op<OT>::to_f32(wr[k]), 127 - E), ldexpf(Op<OT>::to_f32(wr[k + 1]), 127 - E), pk, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(Op<OT>::to_f32(wr[k + 2]), 127 - E), ldexpf(Op<OT>::to_f32(wr[k + 3]), 127 - E), pk, true);
+        *(unsigned*)(q + k) = (unsigned)pk;
+    }
+}
+
+// Synchronous (one-time weight preparation): returns the E8M0 exponent of the tensor.
+int prepare_weight_e4m3(const void* w, int ldw, int K, int N, void* dst, int operand_dtype, unsigned* scratch_word, hipStream_t st) {
+    if (K % 4 || ldw % 2) throw std::runtime_error("prepare_weight_e4m3: K must be a multiple of 4");
+    LR_HIP_CHECK(hipMemsetAsync(scratch_word, 0, 4, st));
+    const dim3 grid((N + 3) / 4), block(256);
+    if (operand_dtype == DT_F16) hipLaunchKernelGGL(weight_amax_kernel<F16>, grid, block, 0, st, (const unsigned short*)w, ldw, K, N, scratch_word);
+    else hipLaunchKernelGGL(weight_amax_kernel<BF16>, grid, block, 0, st, (const unsigned short*)w, ldw, K, N, scratch_word);
+    unsigned bits = 0;
+    LR_HIP_CHECK(hipMemcpyAsync(&bits, scratch_word, 4, hipMemcpyDeviceToHost, st));
+    LR_HIP_CHECK(hipStreamSynchronize(st));
+    float amax;
+    memcpy(&amax, &bits, 4);
+    const int E = amax > 0.f ? 127 + (std::ilogb(amax) - 7) : 127;
+    if (operand_dtype == DT_F16) hipLaunchKernelGGL(weight_to_e4m3_kernel<F16>, grid, block, 0, st, (const unsigned short*)w, ldw, K, N, E, (unsigned char*)dst);
+    else hipLaunchKernelGGL(weight_to_e4m3_kernel<BF16>, grid, block, 0, st, (const unsigned short*)w, ldw, K, N, E, (unsigned char*)dst);
+    return E;
+}
+
+void launch_quantize_rows_fp8(const void* x, int ldx, int K, int rows, void* q, int ldq, float* scale, int operand_dtype, hipStream_t st) {
+    if (rows <= 0) return;
+    if (K % 8 || ldx % 8 || ldq % 8) throw std::runtime_error("quantize_rows_fp8: K and the row strides must be multiples of 8");
+    const dim3 grid((rows + 3) / 4), block(256);
+    if (operand_dtype == DT_F16) hipLaunchKernelGGL(quantize_rows_fp8_kernel<F16>, grid, block, 0, st, (const unsigned short*)x, ldx, K, rows, (unsigned char*)q, ldq, scale);
+    else hipLaunchKernelGGL(quantize_rows_fp8_kernel<BF16>, grid, block, 0, st, (const unsigned short*)x, ldx, K, rows, (unsigned char*)q, ldq, scale);
 }
 
 }  // namespace lr

@@ -11,8 +11,9 @@ import torch
 from . import _lib as L
 from .synth import LlavaConfig, QwenConfig, RewardConfig
 
-_DT = {"bf16": L.LR_DT_BF16, "f16": L.LR_DT_F16, "fp16": L.LR_DT_F16, "f16x2": L.LR_DT_F16, "bf16x2": L.LR_DT_BF16}
-_PRECISE = {"f16x2", "bf16x2"}      # split-operand mode: activations as hi + lo (include/llava_reward_hip.h `precise`)
+_DT = {"bf16": L.LR_DT_BF16, "f16": L.LR_DT_F16, "fp16": L.LR_DT_F16, "f16x2": L.LR_DT_F16, "bf16x2": L.LR_DT_BF16, "f16x2f8": L.LR_DT_F16}
+# split-operand mode: activations as hi + lo (include/llava_reward_hip.h `precise`); "f16x2f8" = residual pass of the big GEMMs in e4m3
+_PRECISE = {"f16x2": 1, "bf16x2": 1, "f16x2f8": 2}
 
 
 def rope_inv_freq(factors, head_dim: int, theta: float) -> torch.Tensor:
@@ -85,7 +86,7 @@ def make_desc(cfg, max_batch: int, max_seq: int, max_crops: int, operand_dtype: 
     d.ca_eps = getattr(cfg, "ca_eps", 1e-5)
     d.max_batch, d.max_seq, d.max_crops = max_batch, max_seq, max_crops
     d.operand_dtype = _DT[operand_dtype]
-    d.precise = 1 if operand_dtype in _PRECISE else 0
+    d.precise = _PRECISE.get(operand_dtype, 0)
     d.mean_hidden_state = 1 if mean_hidden_state else 0
     return d
 

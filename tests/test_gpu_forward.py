@@ -27,6 +27,7 @@ pytestmark = pytest.mark.gpu
 
 TOL_F16 = 1e-3
 TOL_X2 = 1e-4
+TOL_X8 = 3e-4          # "f16x2f8": residual pass of the deep-pipelined GEMMs in e4m3 (measured <= 8e-5 on the full-size rows)
 TOL_BF16 = 8e-3
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -100,7 +101,7 @@ def test_stage_taps_tiny():
     assert np.abs(x - ref_x)[valid].max() < 2e-2 * np.abs(ref_x[valid]).max()
 
 
-@pytest.mark.parametrize("dtype", ["f16x2", "f16"])
+@pytest.mark.parametrize("dtype", ["f16x2", "f16x2f8", "f16"])
 def test_batch_invariance_and_preference_order_bit_exact(dtype):
     """A row's reward must not depend on what else is in the batch (fixed reduction order, no atomics),
     so preference ordering is bit-exact however rows are sharded across GPUs."""
@@ -144,7 +145,7 @@ def test_training_flag_and_errors():
 CASES = sorted(glob.glob(os.path.join(GOLD, "ref_small_*.json")))
 
 
-@pytest.mark.parametrize("dtype,tol", [("f16x2", TOL_X2), ("f16", TOL_F16)])
+@pytest.mark.parametrize("dtype,tol", [("f16x2", TOL_X2), ("f16x2f8", TOL_X8), ("f16", TOL_F16)])
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-5] for p in CASES])
 def test_reference_goldens_small(path, dtype, tol):
     """Rewards produced by the reference itself (fp32 CPU) on full CLIP ViT-L + a 2-layer decoder."""
@@ -170,7 +171,7 @@ def test_reference_goldens_small(path, dtype, tol):
 FULL = sorted(glob.glob(os.path.join(GOLD, "ref_full_*.json")))
 
 
-@pytest.mark.parametrize("dtype", ["f16x2", "f16"])
+@pytest.mark.parametrize("dtype", ["f16x2", "f16x2f8", "f16"])
 @pytest.mark.parametrize("path", FULL, ids=[os.path.basename(p)[:-5] for p in FULL])
 def test_reference_golden_full_size(path, dtype):
     """Full Phi-3.5-V shapes (32 layers, D=3072, 17 crops, V=2509, S=2643): reward of the reference's
@@ -188,6 +189,8 @@ def test_reference_golden_full_size(path, dtype):
     print(f"[{g['name']} {dtype}] reward hip={got.flatten().tolist()} ref={ref.flatten().tolist()} err={err:.3e}")
     if dtype == "f16x2":
         assert err < TOL_X2                      # parity mode: measured 2.6e-6 / 5.5e-6
+    elif dtype == "f16x2f8":
+        assert err < TOL_X8                      # default parity mode (e4m3 residual pass): measured 4.8e-7 on the BT row
     else:
         # single-pass f16: 1e-3 in the assert_close sense (atol = rtol = 1e-3).  At full depth (23 + 32 layers) numerically
         # equivalent builds land anywhere within about +-1e-3 of the reference on this row (sigma ~ 7e-4 at |r| = 1.3,
@@ -274,3 +277,26 @@ def test_bf16x2_mode():
     err = (got - ref).abs().max().item()
     print(f"[bf16x2] max |reward err| = {err:.3e}")
     assert err < 2e-4
+
+
+@pytest.mark.parametrize("variant", ["bt_ca", "gpm2_ca"])
+def test_e4m3_residual_pass_on_tiny_config(variant):
+    """"f16x2f8" with the deep-pipelined kernel forced for every GEMM (tile 6), so that the in-place residual encoder, the W8
+    twins and the mixed f16 / e4m3 K loop run on a config the oracle finishes in seconds (K = 128 .. 640)."""
+    kw = dict(bt_ca={}, gpm2_ca=dict(is_general_preference=True, value_head_dim=2))[variant]
+    cfg = synth.tiny_config(**kw)
+    seed = 17
+    batch = synth.synth_batch(cfg, seed, [7, 3, 5], [(1, 1), (1, 2), (2, 1)], max_crops=4)
+    W = orc.weights_to_torch(synth.make_weights(cfg, seed))
+    ref = orc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"])
+    errs = {}
+    for dtype in ("f16x2f8", "f16"):
+        m = _model(cfg, seed, dtype, upload=False)
+        m.engine.set_gemm_tile(6)
+        got = _fwd(m, batch)
+        errs[dtype] = (got - ref).abs().max().item()
+        if dtype == "f16x2f8":
+            again = _fwd(m, batch)                  # second pass: the W8 twins are reused, the residuals re-encoded
+            assert torch.equal(got, again)
+    print(f"[tiny {variant}, tile 6] f16x2f8 err {errs['f16x2f8']:.2e}   f16 err {errs['f16']:.2e}")
+    assert errs["f16x2f8"] < TOL_X8 and errs["f16x2f8"] < 0.5 * errs["f16"] + 2e-5

@@ -371,3 +371,74 @@ def test_gemm_persistent_walk_many_tiles(lib, tile, shape):
     ref = A.float() @ W.float().t()
     assert torch.isfinite(out).all()
     assert (out - ref).abs().max().item() < 2e-5 * ref.abs().max().item() * max(1.0, (K / 512) ** 0.5)
+
+
+def test_gemm_e4m3_residual_pass_matches_fp64(lib):
+    """Split-operand GEMM with the residual pass in e4m3 (precise == 2): A_hi W^T on the f16 instruction + A_lo8 W8^T on the scaled
+    e4m3 instruction in the same accumulators.  ~8e-6 of the output scale against fp64 on the un-rounded A (single pass: 2e-4)."""
+    code, tdt = L.LR_DT_F16, torch.float16
+    for (M, N, K, rows_scaled) in [(700, 512, 384, False), (4100, 768, 3072, True), (8192, 8192, 512, True)]:     # last: 1024 tiles > 256 CUs
+        A32 = rnd((M, K), 161, 0.7)
+        if rows_scaled:
+            A32 = A32 * torch.exp2(torch.randint(-6, 7, (M, 1), generator=torch.Generator().manual_seed(5)).float()).cuda()
+        W = rnd((N, K), 162, 0.05).to(torch.bfloat16).to(tdt)
+        bias = rnd((N,), 163)
+        hi, lo = _split(A32, tdt)
+        A2 = torch.cat([hi, lo], dim=1).contiguous()
+        ref = (A32.double() @ W.double().t() + bias.double()).float()
+        W8 = torch.zeros(N, K, device="cuda", dtype=tdt)
+        aexp = torch.zeros(M, dtype=torch.int32, device="cuda")
+        wexp = C.c_int(0)
+        out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+        A_work = A2.clone()
+        assert lib.lr_op_gemm_bt_mixed(P(A_work), P(W), P(W8), P(aexp), P(out), P(bias), M, N, K, L.EPI_OUT_F32, 0, code, 3, C.byref(wexp), stream()) == 0
+        torch.cuda.synchronize()
+        scale = ref.abs().max().item()
+        err = (out - ref).abs().max().item()
+        single = torch.empty(M, N, device="cuda", dtype=torch.float32)
+        assert lib.lr_op_gemm_bt(P(hi), P(W), P(single), P(bias), M, N, K, K, K, N, L.EPI_OUT_F32, 0, code, 6, stream()) == 0
+        torch.cuda.synchronize()
+        e1 = (single - ref).abs().max().item()
+        assert err < 3e-5 * scale and err < e1 / 8, (M, N, K, err / scale, e1 / scale)
+        # the residual half now holds e4m3 bytes with one power-of-two scale per row: decode and compare with the f16 residuals
+        lo8 = A_work[:, K:].contiguous().view(torch.uint8)[:, :K].contiguous().view(torch.float8_e4m3fn).float()
+        dec = lo8 * torch.exp2((aexp - 127).float())[:, None]
+        ref_lo = lo.float()
+        assert (dec - ref_lo).abs().max().item() <= 2.0 ** -4 * ref_lo.abs().amax(dim=1).max().item()
+        assert torch.equal(A_work[:, :K], hi)                                  # the hi half is untouched
+        # operand-typed output with GELU: [hi | lo]
+        o2 = torch.zeros(M, 2 * N, device="cuda", dtype=tdt)
+        A_work = A2.clone()
+        assert lib.lr_op_gemm_bt_mixed(P(A_work), P(W), P(W8), P(aexp), P(o2), P(bias), M, N, K, L.EPI_OUT_OP, L.ACT_GELU_ERF, code, 2, C.byref(wexp), stream()) == 0
+        g = torch.nn.functional.gelu(ref)
+        got = o2[:, :N].float() + o2[:, N:].float()
+        assert (got - g).abs().max().item() < 4e-5 * g.abs().max().item()
+
+
+def test_gemm_w8a8_e4m3(lib):
+    """W8A8 building block (BASELINE configs[4]): the row quantiser against torch.float8_e4m3fn on the CPU (bytes and scales equal),
+    the e4m3 GEMM against the dequantised fp32 product."""
+    code, tdt = L.LR_DT_F16, torch.float16
+    for (M, N, K) in [(300, 256, 128), (4100, 768, 3072)]:
+        x = (rnd((M, K), 171) * (torch.rand(M, 1, generator=torch.Generator().manual_seed(3)).cuda() * 3)).to(tdt)
+        w = rnd((N, K), 172, 0.02).to(tdt)
+        qs = []
+        for t in (x, w):
+            q = torch.empty(t.shape, dtype=torch.uint8, device="cuda")
+            s = torch.empty(t.shape[0], dtype=torch.float32, device="cuda")
+            assert lib.lr_op_quantize_rows_fp8(P(t), t.shape[0], K, K, P(q), P(s), code, stream()) == 0
+            torch.cuda.synchronize()
+            tc = t.float().cpu()
+            amax = tc.abs().amax(1)
+            sref = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+            qref = (tc / sref[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)
+            assert torch.equal(s.cpu(), sref) and torch.equal(q.cpu(), qref)
+            qs.append((q, s))
+        (xq, xs), (wq, ws) = qs
+        bias = rnd((N,), 173)
+        out = torch.zeros(M, N, device="cuda")
+        assert lib.lr_op_gemm_fp8(P(xq), P(xs), P(wq), P(ws), P(out), P(bias), M, N, K, N, L.EPI_OUT_F32, 0, code, stream()) == 0
+        torch.cuda.synchronize()
+        ref = (xq.view(torch.float8_e4m3fn).float() @ wq.view(torch.float8_e4m3fn).float().T) * xs[:, None] * ws[None, :] + bias
+        assert (out - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
+    assert lib.lr_op_gemm_fp8(P(xq), P(xs), P(wq), P(ws), P(out), None, M, N, 100, N, L.EPI_OUT_F32, 0, code, stream()) != 0     # K % 128

@@ -58,7 +58,7 @@ def test_llava_tiny_vs_oracle(dtype, tol, gpm):
 CASES = sorted(glob.glob(os.path.join(GOLD, "ref_llava_*.json")))
 
 
-@pytest.mark.parametrize("dtype", ["f16x2", "f16"])
+@pytest.mark.parametrize("dtype", ["f16x2", "f16x2f8", "f16"])
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-5] for p in CASES])
 def test_llava_reference_goldens(path, dtype):
     g = json.load(open(path))
@@ -71,6 +71,8 @@ def test_llava_reference_goldens(path, dtype):
     print(f"[{g['name']} {dtype}] max |reward err| vs reference = {err:.3e}")
     if dtype == "f16x2":
         assert err < 1e-4
+    elif dtype == "f16x2f8":
+        assert err < 3e-4                        # e4m3 residual pass (default parity mode): measured 1.1e-6 on the full-size row
     else:
         assert bool(((got - ref).abs() <= 1e-3 + 1e-3 * ref.abs()).all())
 

@@ -188,7 +188,7 @@ def test_qwen_reference_goldens(path, dtype):
 FULL = sorted(glob.glob(os.path.join(GOLD, "ref_qwen_full_*.json")))
 
 
-@pytest.mark.parametrize("dtype", ["f16x2", "f16"])
+@pytest.mark.parametrize("dtype", ["f16x2", "f16x2f8", "f16"])
 @pytest.mark.parametrize("path", FULL, ids=[os.path.basename(p)[:-5] for p in FULL])
 def test_qwen_reference_golden_full_size(path, dtype):
     """Qwen2.5-VL-7B shapes (ViT 32 x 1280, 28 layers, D = 3584, 28/4 heads, vocab 152064): reward of the reference's
@@ -202,7 +202,7 @@ def test_qwen_reference_golden_full_size(path, dtype):
     got = _fwd(m, batch).reshape(ref.shape)
     err = (got - ref).abs().max().item()
     print(f"[{g['name']} {dtype}] reward hip={got.flatten().tolist()} ref={ref.flatten().tolist()} err={err:.3e}")
-    assert err < (1e-4 if dtype == "f16x2" else 5e-3)                   # see the module docstring / DESIGN.md §4
+    assert err < {"f16x2": 1e-4, "f16x2f8": 3e-4}.get(dtype, 5e-3)      # see the module docstring / DESIGN.md §4 (f16x2f8: measured 8.1e-5)
     dup = dict(input_ids=np.concatenate([batch["input_ids"]] * 2), attention_mask=np.concatenate([batch["attention_mask"]] * 2),
                pixel_values=np.concatenate([batch["pixel_values"]] * 2), image_grid_thw=np.concatenate([batch["image_grid_thw"]] * 2))
     r2 = _fwd(m, dup)
