@@ -95,7 +95,7 @@ class RewardEngine:
     """Owns one lr_handle (one GPU).  Not thread-safe; forward() enqueues on the current torch stream."""
 
     def __init__(self, cfg, device: int = 0, max_batch: int = 32, max_seq: int = 2816,
-                 max_crops: int = 17, operand_dtype: str = "f16x2", max_patches: int = 0, mean_hidden_state: bool = False):
+                 max_crops: int = 17, operand_dtype: str = "f16x2f8", max_patches: int = 0, mean_hidden_state: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("RewardEngine needs a HIP device (torch.cuda.is_available() is False); "
                                "the scoring path has no CPU fallback")

@@ -18,7 +18,7 @@ from .synth import LlavaConfig, QwenConfig, RewardConfig, llava_geometry
 
 class RewardModel:
     def __init__(self, cfg, weights: Optional[Dict[str, torch.Tensor]] = None, synth_seed: Optional[int] = None,
-                 max_batch: int = 32, max_seq: int = 2816, max_crops: int = 17, operand_dtype: str = "f16x2",
+                 max_batch: int = 32, max_seq: int = 2816, max_crops: int = 17, operand_dtype: str = "f16x2f8",
                  layer_id: int = 32, mean_hidden_state=None, max_patches: int = 0):
         if weights is None and synth_seed is None:
             raise ValueError("RewardModel needs weights or a synth_seed")

@@ -41,7 +41,7 @@ def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=Fal
         model = RewardModel(cfg, weights=weights,
                             max_batch=getattr(args, "max_batch", 32), max_seq=getattr(args, "max_seq", 2816),
                             max_crops=getattr(args, "max_crops", 17),
-                            operand_dtype=getattr(args, "operand_dtype", "f16x2"))
+                            operand_dtype=getattr(args, "operand_dtype", "f16x2f8"))
         model.model_type = "phi3v"
         if load_tokenizer:
             from transformers import AutoProcessor
@@ -66,7 +66,7 @@ def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=Fal
         weights.update(ckpt.read_heads(args.pm_path, cfg, getattr(args, "ft_projector", False)))
         model = RewardModel(cfg, weights=weights, max_batch=getattr(args, "max_batch", 32),
                             max_seq=getattr(args, "max_seq", 4096), max_crops=getattr(args, "max_crops", 5),
-                            operand_dtype=getattr(args, "operand_dtype", "f16x2"))
+                            operand_dtype=getattr(args, "operand_dtype", "f16x2f8"))
         if load_tokenizer:
             from transformers import LlavaNextProcessor
             processor = LlavaNextProcessor.from_pretrained(args.pretrain, cache_dir=getattr(args, "cache_dir", None))   # utils/utils.py:46-55
@@ -89,7 +89,7 @@ def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=Fal
         weights.update(ckpt.read_heads(args.pm_path, cfg, getattr(args, "ft_projector", False)))
         model = RewardModel(cfg, weights=weights, max_batch=getattr(args, "max_batch", 32),
                             max_seq=getattr(args, "max_seq", 2048), max_patches=getattr(args, "max_patches", 0),
-                            operand_dtype=getattr(args, "operand_dtype", "f16x2"))
+                            operand_dtype=getattr(args, "operand_dtype", "f16x2f8"))
         if load_tokenizer:
             from transformers import AutoProcessor
             processor = AutoProcessor.from_pretrained(args.pretrain, cache_dir=getattr(args, "cache_dir", None),
