@@ -339,7 +339,10 @@ int lr_upload_weight(lr_handle h, const char* name, const void* data, const int6
             f32 = h->stage_f32;
         }
         pack_slot(h, s, f32);
+        h->w8exp.clear();          // the e4m3 twins live in the residual buffers pack_slot has just rewritten
         LR_HIP_CHECK(hipStreamSynchronize(0));
+        if (h->finalized && h->inexact_dev)      // a re-upload after lr_finalize may have made a buffer inexact
+            LR_HIP_CHECK(hipMemcpy(h->inexact.data(), h->inexact_dev, h->wbufs.size() * sizeof(int), hipMemcpyDeviceToHost));
     });
 }
 
@@ -352,6 +355,7 @@ int lr_synth_weights(lr_handle h, uint64_t seed) {
             launch_synth_fill(h->stage_f32, n, tensor_seed(seed, s.name.c_str()), uniform_scale(s.std_), (float)s.offset, 1, 0);
             pack_slot(h, s, h->stage_f32);
         }
+        h->w8exp.clear();
         LR_HIP_CHECK(hipStreamSynchronize(0));
     });
 }
