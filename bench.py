@@ -186,7 +186,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=32, help="rows per GPU")
-    ap.add_argument("--dtype", default="f16x2f8", choices=["f16x2", "f16x2f8", "f16", "bf16", "bf16x2"],
+    ap.add_argument("--dtype", default="f16x2f8", choices=["f16x2", "f16x2f8", "f16", "bf16", "bf16x2", "fp8"],
                     help="MFMA operands: f16x2f8 = split-operand parity mode with the residual pass of the big GEMMs in e4m3 (default, rewards "
                          "within 1e-3 of the fp32 reference with > 10x margin); f16x2 = the same with 16-bit residual passes (strict); "
                          "f16 / bf16 = single-pass fast modes (noise-limited, DESIGN.md §4)")

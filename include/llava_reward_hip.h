@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LR_ABI_VERSION 4
+#define LR_ABI_VERSION 5
 
 enum { LR_OK = 0, LR_EINVAL = 1, LR_EHIP = 2, LR_ESTATE = 3, LR_ENOTFOUND = 4, LR_ENOMEM = 5 };
 enum { LR_DT_BF16 = 0, LR_DT_F16 = 1, LR_DT_F32 = 2 };
@@ -97,6 +97,12 @@ typedef struct lr_model_desc {
     /* rw_model_general_preference.py:398-406 `mean_hidden_state`: the SkipCA block + its RMSNorm are applied to every token and
      * the value head reads the attention-mask-weighted mean (fp32 path; rewards are [B, value_head_dim] in train and eval). */
     int32_t mean_hidden_state;
+    /* W8A8 mode ("fp8 MFMA weight path", BASELINE configs[4]); needs precise == 0 and F16 operands.  Activations stay f16 in HBM;
+     * in front of every GEMM with K % 128 == 0 the rows of A are quantised to OCP e4m3 with one fp32 scale per row (max|x| / 448),
+     * each weight gets an e4m3 twin with one scale per output channel on first use, and the GEMM runs on
+     * v_mfma_scale_f32_16x16x128_f8f6f4 (1.9x the f16 GEMM rate).  Attention, norms and the fp32 tail are unchanged.  Rewards move
+     * by ~1e-2: NOT a parity mode. */
+    int32_t w8a8;
 } lr_model_desc;
 
 int lr_abi_version(void);

@@ -86,6 +86,11 @@ struct lr_engine {
     int* aexp = nullptr; size_t aexp_cap = 0;        // E8M0 exponent of every residual row of the GEMM being launched
     unsigned* amax_word = nullptr;
     std::unordered_map<const void*, int> w8exp;      // weight base pointer -> E8M0 exponent of its prepared e4m3 twin
+    int w8a8 = 0;              // W8A8 mode (desc.w8a8): e4m3 GEMM operands with per-row / per-channel fp32 scales
+    struct W8 { void* q; float* scale; };
+    std::unordered_map<const void*, W8> w8;          // weight base pointer -> its e4m3 twin (prepared on first use)
+    void* q8 = nullptr; size_t q8_cap = 0;           // quantised rows of the A operand of the GEMM being launched
+    float* q8s = nullptr; size_t q8s_cap = 0;
 
     // Qwen2.5-VL ViT geometry: head dim vhd stored vhdp wide, MLP width vI stored vIp wide, patch vector vK padded to vKpad
     int vH = 0, vhd = 0, vhdp = 0, vHp = 0, vI = 0, vIp = 0, vK = 0, vKpad = 0, vHm = 0, vunit = 0;
@@ -302,9 +307,34 @@ inline void apply_prec(const lr_engine* e, AttnParams& p) {
     p.o_split = p.ldo; p.ldo *= 2;
 }
 
+// W8A8 mode: quantise the rows of A, make sure W has its e4m3 twin, launch the e4m3 form.  Like lo8_eligible, the choice never
+// depends on M.  Returns false when this GEMM has to stay in 16 bits (K % 128 != 0, unaligned output).
+inline bool w8a8_eligible(const lr_engine* e, const GemmParams& p) {
+    const bool aligned = p.N % 8 == 0 && p.ldc % 8 == 0 && (((uintptr_t)p.C) & 15) == 0 && (!p.bias || (((uintptr_t)p.bias) & 15) == 0);
+    return e->w8a8 && aligned && p.K % 128 == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 && (e->gemm_tile < 0 || e->gemm_tile == 6);
+}
+inline bool launch_w8a8(lr_engine* e, GemmParams p, hipStream_t st) {
+    if (!w8a8_eligible(e, p)) return false;
+    auto it = e->w8.find(p.W);
+    if (it == e->w8.end()) {
+        lr_engine::W8 t{e->dalloc((size_t)p.N * p.K, true), (float*)e->dalloc((size_t)p.N * 4, true)};
+        launch_quantize_rows_fp8(p.W, p.ldw, p.K, p.N, t.q, p.K, t.scale, e->op_dt, st);
+        it = e->w8.emplace(p.W, t).first;
+    }
+    const size_t need = (size_t)p.M * p.K;
+    if (need > e->q8_cap) { e->q8_cap = (need + (1u << 20)) & ~(size_t)((1u << 20) - 1); e->q8 = e->dalloc(e->q8_cap, false); }
+    if ((size_t)p.M > e->q8s_cap) { e->q8s_cap = ((size_t)p.M + 4095) & ~(size_t)4095; e->q8s = (float*)e->dalloc(e->q8s_cap * 4, false); }
+    launch_quantize_rows_fp8(p.A, p.lda, p.K, p.M, e->q8, p.K, e->q8s, e->op_dt, st);
+    p.A = e->q8; p.W = it->second.q; p.lda = p.K; p.ldw = p.K;
+    p.ascale = e->q8s; p.wscale = it->second.scale;
+    launch_gemm_bt8_fp8(p, e->op_dt, st);
+    return true;
+}
+
 inline void gemm(lr_engine* e, hipStream_t st, const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int lda,
           int ldw, int ldc, int epi, int act) {
     GemmParams p{A, W, C, bias, M, N, K, lda, ldw, ldc, epi, act, nullptr, 0, 0};
+    if (launch_w8a8(e, p, st)) return;
     apply_prec(e, p, st);
     launch_gemm_bt(p, e->op_dt, e->gemm_tile, st);
 }

@@ -157,6 +157,8 @@ void validate_desc(const lr_model_desc& d) {
     if (d.operand_dtype != LR_DT_BF16 && d.operand_dtype != LR_DT_F16) bad("operand_dtype must be BF16 or F16");
     if (d.precise < 0 || d.precise > 2) bad("precise must be 0, 1 or 2");
     if (d.precise == 2 && d.operand_dtype != LR_DT_F16) bad("precise == 2 (e4m3 residual pass) needs F16 operands");
+    if (d.w8a8 != 0 && d.w8a8 != 1) bad("w8a8 must be 0 or 1");
+    if (d.w8a8 && (d.precise || d.operand_dtype != LR_DT_F16)) bad("w8a8 needs precise == 0 and F16 operands");
     if (d.layers < 0 || d.clip_layers < 0) bad("layer counts must be non-negative");
 }
 
@@ -176,7 +178,9 @@ void run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_ma
         {   // qkv projection with RoPE on q,k: fused in the GEMM epilogue when the deep-pipelined kernel runs
             GemmParams gp{h->h, L.qkv_w, h->qkv, L.qkv_b, Rl, Nqkv, D, D, D, Nqkv, EPI_ROPE_OP, ACT_NONE, h->cs, Hq + Hkv, h->hd};
             apply_prec_base(h, gp);
-            if ((Hq + Hkv) % 256 == 0 && (lo8_eligible(h, gp) || gemm_bt_is_deep(gp, h->gemm_tile))) {
+            if ((Hq + Hkv) % 256 == 0 && w8a8_eligible(h, gp)) {
+                launch_w8a8(h, gp, st);
+            } else if ((Hq + Hkv) % 256 == 0 && (lo8_eligible(h, gp) || gemm_bt_is_deep(gp, h->gemm_tile))) {
                 upgrade_lo8(h, gp, st);
                 launch_gemm_bt(gp, h->op_dt, h->gemm_tile, st);
             } else {
@@ -254,6 +258,7 @@ int lr_create(const lr_model_desc* desc, int device, lr_handle* out) {
         e->op_dt = desc->operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16;
         e->prec = desc->precise ? 1 : 0;
         e->lo8 = desc->precise == 2 ? 1 : 0;
+        e->w8a8 = desc->w8a8 ? 1 : 0;
         e->llava = desc->backbone == LR_BACKBONE_LLAVA_NEXT;
         e->qwen = desc->backbone == LR_BACKBONE_QWEN2_5_VL;
         if (!e->qwen) {
@@ -339,7 +344,7 @@ int lr_upload_weight(lr_handle h, const char* name, const void* data, const int6
             f32 = h->stage_f32;
         }
         pack_slot(h, s, f32);
-        h->w8exp.clear();          // the e4m3 twins live in the residual buffers pack_slot has just rewritten
+        h->w8exp.clear(); h->w8.clear();          // the e4m3 twins live in the residual buffers pack_slot has just rewritten
         LR_HIP_CHECK(hipStreamSynchronize(0));
         if (h->finalized && h->inexact_dev)      // a re-upload after lr_finalize may have made a buffer inexact
             LR_HIP_CHECK(hipMemcpy(h->inexact.data(), h->inexact_dev, h->wbufs.size() * sizeof(int), hipMemcpyDeviceToHost));
@@ -355,7 +360,7 @@ int lr_synth_weights(lr_handle h, uint64_t seed) {
             launch_synth_fill(h->stage_f32, n, tensor_seed(seed, s.name.c_str()), uniform_scale(s.std_), (float)s.offset, 1, 0);
             pack_slot(h, s, h->stage_f32);
         }
-        h->w8exp.clear();
+        h->w8exp.clear(); h->w8.clear();
         LR_HIP_CHECK(hipStreamSynchronize(0));
     });
 }

@@ -305,7 +305,9 @@ extern "C" int lr_forward_qwen(lr_handle h, const int64_t* input_ids, const int6
             {
                 GemmParams gp{h->vhn, L.qkv_w, h->vqkv, L.qkv_b, N, 3 * vHp, vH, vH, vH, 3 * vHp, EPI_ROPE_OP, ACT_NONE, h->vcs, 2 * vHp, vhdp};
                 apply_prec_base(h, gp);
-                if ((2 * vHp) % 256 == 0 && (lo8_eligible(h, gp) || gemm_bt_is_deep(gp, h->gemm_tile))) {
+                if ((2 * vHp) % 256 == 0 && w8a8_eligible(h, gp)) {
+                    launch_w8a8(h, gp, st);
+                } else if ((2 * vHp) % 256 == 0 && (lo8_eligible(h, gp) || gemm_bt_is_deep(gp, h->gemm_tile))) {
                     upgrade_lo8(h, gp, st);
                     launch_gemm_bt(gp, h->op_dt, h->gemm_tile, st);
                 } else {

@@ -13,7 +13,7 @@ LR_MAX_HALF_HEAD = 64
 LR_MAX_PINPOINTS = 8
 LR_MAX_FULLATT = 8
 LR_BACKBONE_PHI3V, LR_BACKBONE_LLAVA_NEXT, LR_BACKBONE_QWEN2_5_VL = 0, 1, 2
-LR_ABI_VERSION = 4
+LR_ABI_VERSION = 5
 EPI_OUT_OP, EPI_OUT_F32, EPI_RESADD_F32, EPI_SWIGLU_OP, EPI_ROPE_OP = 0, 1, 2, 3, 4
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2
 
@@ -46,6 +46,7 @@ class ModelDesc(C.Structure):
         ("ca_token_id", C.c_int32), ("max_patches", C.c_int32),
         ("precise", C.c_int32),
         ("mean_hidden_state", C.c_int32),
+        ("w8a8", C.c_int32),
     ]
 
 

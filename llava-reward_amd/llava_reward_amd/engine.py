@@ -11,7 +11,8 @@ import torch
 from . import _lib as L
 from .synth import LlavaConfig, QwenConfig, RewardConfig
 
-_DT = {"bf16": L.LR_DT_BF16, "f16": L.LR_DT_F16, "fp16": L.LR_DT_F16, "f16x2": L.LR_DT_F16, "bf16x2": L.LR_DT_BF16, "f16x2f8": L.LR_DT_F16}
+_DT = {"bf16": L.LR_DT_BF16, "f16": L.LR_DT_F16, "fp16": L.LR_DT_F16, "f16x2": L.LR_DT_F16, "bf16x2": L.LR_DT_BF16, "f16x2f8": L.LR_DT_F16,
+       "fp8": L.LR_DT_F16}     # "fp8" = W8A8: f16 activations in HBM, e4m3 GEMM operands (lr_model_desc.w8a8)
 # split-operand mode: activations as hi + lo (include/llava_reward_hip.h `precise`); "f16x2f8" = residual pass of the big GEMMs in e4m3
 _PRECISE = {"f16x2": 1, "bf16x2": 1, "f16x2f8": 2}
 
@@ -88,6 +89,7 @@ def make_desc(cfg, max_batch: int, max_seq: int, max_crops: int, operand_dtype: 
     d.operand_dtype = _DT[operand_dtype]
     d.precise = _PRECISE.get(operand_dtype, 0)
     d.mean_hidden_state = 1 if mean_hidden_state else 0
+    d.w8a8 = 1 if operand_dtype == "fp8" else 0
     return d
 
 

@@ -34,7 +34,28 @@ Ident = lambda x: x  # noqa: E731
 
 
 def _lin(x, w, b=None, opr=Ident):
+    lq = getattr(opr, "lin", None)           # W8A8 emulation: an extra per-row quantisation of both GEMM operands
+    if lq is not None and x.shape[-1] % 128 == 0:
+        return F.linear(lq(opr(x)), lq(opr(w)), b)
     return F.linear(opr(x), opr(w), b)
+
+
+class W8A8Round:
+    """Operand rounding of the W8A8 mode (lr_model_desc.w8a8, BASELINE configs[4]): activations are stored in f16 (`act`), and in
+    front of every GEMM with K % 128 == 0 the rows of both operands go to OCP e4m3 with one fp32 scale per row, max|x| / 448
+    (csrc/rowops.hip quantize_rows_fp8_kernel).  Attention contractions see the f16 rounding only."""
+
+    def __init__(self, act):
+        self.act = act
+
+    def __call__(self, t):
+        return self.act(t)
+
+    @staticmethod
+    def lin(t):
+        amax = t.abs().amax(dim=-1, keepdim=True)
+        s = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+        return (t / s).to(torch.float8_e4m3fn).float() * s
 
 
 # ---------------------------------------------------------------------------------- CLIP tower
@@ -50,8 +71,13 @@ def clip_tower(W: Dict[str, torch.Tensor], pixels: torch.Tensor, ccfg, opr=Ident
     N = pixels.shape[0]
     H, nh, hd = ccfg.hidden, ccfg.heads, ccfg.head_dim
     wpe = W[p + "embeddings.patch_embedding.weight"]
-    x = F.conv2d(opr(pixels), opr(wpe), stride=ccfg.patch)                      # [N,H,24,24]
-    x = x.flatten(2).transpose(1, 2)                                             # [N,576,H]
+    if getattr(opr, "lin", None) is not None:     # W8A8 emulation: the conv as the GEMM the engine runs (rows zero-padded to 640)
+        pt = F.unfold(opr(pixels), kernel_size=ccfg.patch, stride=ccfg.patch).transpose(1, 2)      # [N,576,588], (c, ky, kx) order
+        kp = (pt.shape[-1] + 127) // 128 * 128
+        x = _lin(F.pad(pt, (0, kp - pt.shape[-1])), F.pad(wpe.reshape(H, -1), (0, kp - pt.shape[-1])), None, opr)
+    else:
+        x = F.conv2d(opr(pixels), opr(wpe), stride=ccfg.patch)                  # [N,H,24,24]
+        x = x.flatten(2).transpose(1, 2)                                         # [N,576,H]
     cls = W[p + "embeddings.class_embedding"].expand(N, 1, H)
     x = torch.cat([cls, x], dim=1) + W[p + "embeddings.position_embedding.weight"]
     x = F.layer_norm(x, (H,), W[p + "pre_layrnorm.weight"], W[p + "pre_layrnorm.bias"], ccfg.ln_eps)

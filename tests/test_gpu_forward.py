@@ -302,3 +302,67 @@ def test_e4m3_residual_pass_on_tiny_config(variant):
             assert torch.equal(got, again)
     print(f"[tiny {variant}, tile 6] f16x2f8 err {errs['f16x2f8']:.2e}   f16 err {errs['f16']:.2e}")
     assert errs["f16x2f8"] < TOL_X8 and errs["f16x2f8"] < 0.5 * errs["f16"] + 2e-5
+
+
+@pytest.mark.parametrize("backbone", ["phi3v", "llava"])
+def test_w8a8_mode_against_quantisation_aware_oracle(backbone):
+    """W8A8 mode (operand_dtype="fp8", BASELINE configs[4] "fp8 MFMA weight path"): every GEMM with K % 128 == 0 runs on e4m3
+    operands with per-row / per-channel scales.  NOT a parity mode.  The oracle is evaluated with the SAME operand quantisation
+    (W8A8Round: f16 storage + per-row e4m3 in front of each GEMM).  An e4m3 model is chaotic in its inputs -- two emulations that
+    differ only in the 2^-11 activation rounding (f16 vs none) already differ by ~3e-2 in the reward -- so the bars are: the
+    engine sits as close to the emulation as such a twin does, far inside the quantisation noise at the first stage (CLIP
+    tower, where little has been amplified yet), finite and deterministic."""
+    seed = 23
+    taps_hip = None
+    if backbone == "phi3v":
+        cfg = synth.tiny_config()
+        batch = synth.synth_batch(cfg, seed, [7, 3, 5], [(1, 1), (1, 2), (2, 1)], max_crops=4)
+        W = orc.weights_to_torch(synth.make_weights(cfg, seed))
+
+        def fwd(opr, taps=None):
+            return orc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"],
+                                      opr=opr, taps=taps)
+
+        def hip(dtype):
+            m = _model(cfg, seed, dtype, upload=False)
+            r = _fwd(m, batch)
+            ncrop = int(sum(h // 336 * (w // 336) + 1 for h, w in batch["image_sizes"].tolist()))
+            T, Hc = cfg.clip.tokens, cfg.clip.hidden
+            return r, m.engine.read_tap("clip_x", ncrop * T * Hc).reshape(ncrop, T, Hc)[:, 1:]
+    else:
+        from oracle import llava_next_reward_oracle as lorc
+        cfg = synth.llava_tiny_config()
+        batch = synth.llava_synth_batch(cfg, seed, [6, 3], [(336, 336), (300, 500)])
+        W = orc.weights_to_torch(synth.llava_make_weights(cfg, seed))
+
+        def fwd(opr, taps=None):
+            return lorc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"], opr=opr)
+
+        def hip(dtype):
+            m = RewardModel(cfg, synth_seed=seed, max_batch=4, max_seq=4096, max_crops=5, operand_dtype=dtype).to("cuda").eval()
+            r, _ = m.custom_forward(inputs_batch={k: torch.from_numpy(v).cuda() for k, v in batch.items()})
+            torch.cuda.synchronize()
+            return r.cpu(), None
+    t32, t8 = {}, {}
+    ref32 = fwd(orc.Ident, t32)
+    ref8 = fwd(orc.W8A8Round(orc.f16_round), t8)
+    twin = fwd(orc.W8A8Round(orc.Ident))                       # same quantisation, activations not rounded to f16 first
+    got, clip = hip("fp8")
+    e_sim = (got - ref8).abs().max().item()
+    e_twin = (twin - ref8).abs().max().item()
+    q_noise = (ref8 - ref32).abs().max().item()
+    print(f"[w8a8 {backbone}] |hip - emulation| = {e_sim:.2e}   |twin emulation - emulation| = {e_twin:.2e}   "
+          f"|emulation - fp32 oracle| = {q_noise:.2e}   |hip - fp32 oracle| = {(got - ref32).abs().max().item():.2e}")
+    assert torch.isfinite(got).all()
+    assert e_sim < 3.0 * max(e_twin, 1e-2)
+    if clip is not None and "clip_out" in t8:
+        used = [h // 336 * (w // 336) + 1 for h, w in batch["image_sizes"].tolist()]       # the engine skips the zero crops
+
+        def pick(t):
+            t = t.reshape(len(used), -1, clip.shape[1], clip.shape[2])
+            return np.concatenate([t[i, :n].numpy() for i, n in enumerate(used)])
+        rc8, rc32 = pick(t8["clip_out"]), pick(t32["clip_out"])
+        d_hip, d_q = np.abs(clip - rc8).max(), np.abs(rc32 - rc8).max()
+        print(f"[w8a8 {backbone}] CLIP tower: |hip - emulation| = {d_hip:.2e}   |fp32 - emulation| = {d_q:.2e}")
+        assert d_hip < 0.25 * d_q                               # the engine reproduces the quantised tower, not merely something e4m3-ish
+    assert torch.equal(got, hip("fp8")[0])                        # deterministic, twins rebuilt identically
