@@ -53,11 +53,15 @@ __device__ __forceinline__ f32x4 mfma_f8(const uint4 a0, const uint4 a1, const u
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127);     // e4m3 x e4m3, scales 2^0
 }
 
+// SEL: which byte of `ea` holds the E8M0 scale of the A rows (four row tiles share one register)
+template <int SEL>
 __device__ __forceinline__ f32x4 mfma_f8s(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1, const f32x4 c, const int ea, const int eb) {
     const v8i_t a = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
     const v8i_t b = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
-    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, ea, 0, eb);     // x 2^(ea - 127) x 2^(eb - 127)
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, SEL, ea, 0, eb);   // x 2^(ea.byte[SEL] - 127) x 2^(eb - 127)
 }
+template <int I> struct IC { static constexpr int value = I; };
+template <typename F> __device__ __forceinline__ void for4(F&& f) { f(IC<0>{}); f(IC<1>{}); f(IC<2>{}); f(IC<3>{}); }
 
 // F8 == 2: split-operand mode with an e4m3 residual pass: A rows are [hi f16 x kw | lo e4m3 x kw bytes], the K loop
 // runs kw / 64 f16 K-tiles against W and then kw / 128 e4m3 K-tiles against W8 (the e4m3 twin of W, in the rows of p.Wlo), with
@@ -188,18 +192,18 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 
         // F8 == 2: E8M0 exponents of this tile's residual rows (one per A row a lane feeds: [A half][row tile]) and of W8.  Ordinary
         // loads: retired here, in front of the DMA stream, so that no compiler-placed vmcnt wait can appear inside the K loop.
-        int ea[2][4] = {{127, 127, 127, 127}, {127, 127, 127, 127}};
+        int ea[2] = {0x7F7F7F7F, 0x7F7F7F7F};        // [A half]: byte i = exponent of row tile i
         const int eb = p.wexp;
         if constexpr (F8 == 2) {
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ea[h2][i] = p.aexp[min(m0 + h2 * 128 + wr * 64 + i * 16 + l15, p.M - 1)];
+                for (int i = 0; i < 4; ++i) {
+                    const int e1 = p.aexp[min(m0 + h2 * 128 + wr * 64 + i * 16 + l15, p.M - 1)] & 255;
+                    ea[h2] = i == 0 ? e1 : (ea[h2] | (e1 << (8 * i)));
+                }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(ea[h2][i]));
+            asm volatile("" : "+v"(ea[0]), "+v"(ea[1]));
         }
 
         if constexpr (PB == 2) {
@@ -283,12 +287,13 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                     constexpr int q0 = 0, q1 = 1, q3 = 3, q2 = 2;
                     const int qa = sp == 0 ? q0 : q3, qb = sp == 0 ? q1 : q2;      // first block uses bf (B0), second bg (B1)
                     if constexpr (F8 == 1 || (F8 == 2 && LO)) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
+                        for4([&](auto ic) {
+                            constexpr int i = decltype(ic)::value;
 #pragma unroll
                             for (int j = 0; j < 2; ++j)
                                 acc[qa][i][j] = F8 == 1 ? mfma_f8(af[i * 2], af[i * 2 + 1], bf[j * 2], bf[j * 2 + 1], acc[qa][i][j])
-                                                        : mfma_f8s(af[i * 2], af[i * 2 + 1], bf[j * 2], bf[j * 2 + 1], acc[qa][i][j], ea[sp][i], eb);
+                                                        : mfma_f8s<i>(af[i * 2], af[i * 2 + 1], bf[j * 2], bf[j * 2 + 1], acc[qa][i][j], ea[sp], eb);
+                        });
                     } else {
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)
@@ -302,12 +307,13 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                         for (int f = 0; f < 4; ++f) bf[f] = *(const uint4*)(sB0n + boff[f]);
                     }
                     if constexpr (F8 == 1 || (F8 == 2 && LO)) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
+                        for4([&](auto ic) {
+                            constexpr int i = decltype(ic)::value;
 #pragma unroll
                             for (int j = 0; j < 2; ++j)
                                 acc[qb][i][j] = F8 == 1 ? mfma_f8(af[i * 2], af[i * 2 + 1], bg[j * 2], bg[j * 2 + 1], acc[qb][i][j])
-                                                        : mfma_f8s(af[i * 2], af[i * 2 + 1], bg[j * 2], bg[j * 2 + 1], acc[qb][i][j], ea[sp][i], eb);
+                                                        : mfma_f8s<i>(af[i * 2], af[i * 2 + 1], bg[j * 2], bg[j * 2 + 1], acc[qb][i][j], ea[sp], eb);
+                        });
                     } else {
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)
