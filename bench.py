@@ -258,11 +258,12 @@ def main():
         sizes = torch.from_numpy(gb["image_sizes"][rows])
         pix = torch.randn(B, ncrop, 3, 336, 336, device="cuda", generator=gen)      # CLIP-normalised pixel noise, fp32
 
-    def build_model(dtype):
+    def build_model(dtype, fp32_valued=False):
         if a.model == "qwen":
             m = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=S, max_patches=B * 32 * 32, operand_dtype=dtype)
         else:
             m = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=S, max_crops=max(ncrop, 5 if a.model == 'llava' else 17), operand_dtype=dtype)
+        m.synth_fp32_valued = fp32_valued
         m = m.to(f"cuda:{local}").eval()
         if a.tile >= 0:
             m.engine.set_gemm_tile(a.tile)
@@ -374,6 +375,15 @@ def main():
                                     "roofline_frac_whole_pass": fv * flop_per_pair / 1e12 / PEAK_TFLOPS,
                                     "parity_check": golden_check(fm, a.model) if full else None}
                 del fm
+                torch.cuda.empty_cache()
+            if precise and not a.no_fast_mode:
+                # the same parity mode on weights that are NOT bf16-valued (fp32-valued synthetic weights): what a real LLaVA-Reward
+                # checkpoint looks like once its all-linear LoRA adapter is merged (every GEMM carries the weights' residuals too)
+                mm = build_model(a.dtype, fp32_valued=True)
+                ms = timed_steps(lambda: run_forward(mm), a.warmup, a.steps)
+                res["merged_lora_weights"] = {"dtype": a.dtype, "value": B / (ms * 1e-3), "unit": "reward-pairs/sec", "ms_per_step": ms,
+                                              "note": "weights inexact in f16: third K segment per GEMM (e4m3 A_hi x e4m3 W_lo in f16x2f8; 16-bit in f16x2)"}
+                del mm
                 torch.cuda.empty_cache()
             if a.model == "phi3v" and a.num_crops == 16 and not a.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(cfg)

@@ -118,6 +118,9 @@ int lr_upload_weight(lr_handle h, const char* name, const void* data, const int6
 /* Fill every tensor with the deterministic synthetic weights of llava_reward_amd.synth (same
  * integer hash, generated directly in HBM).  Used by bench.py and the full-size parity test. */
 int lr_synth_weights(lr_handle h, uint64_t seed);
+/* The same with flags: 1 = do NOT round the synthetic values to bf16, i.e. fp32-valued weights that are inexact in the operand
+ * type, as the merged LoRA weights of a real LLaVA-Reward checkpoint are (bench.py --merged-weights). */
+int lr_synth_weights_ex(lr_handle h, uint64_t seed, int flags);
 /* Number of expected weight tensors / name of the i-th one (for loaders and tests). */
 int lr_num_weights(lr_handle h);
 const char* lr_weight_name(lr_handle h, int i);
@@ -183,7 +186,9 @@ int lr_op_gemm_fp8(const void* A8, const float* ascale, const void* W8, const fl
 /* Split-operand GEMM with the e4m3 residual pass (lr_model_desc.precise == 2): A = [A_hi | A_lo] (2-byte elements, 2K per row),
  * W [N, K], W8 = DEVICE scratch of the size of W (the e4m3 twin), aexp = DEVICE int32 [M] scratch, wexp = HOST int (in/out).
  * flags: 1 = prepare W8 from W and store its exponent in *wexp (synchronous), 2 = re-encode the residual half of A in place
- * (e4m3 bytes + one E8M0 exponent per row), 4 = stop there (no GEMM).  Output as lr_op_gemm_bt_split.  K multiple of 128. */
+ * (e4m3 bytes + one E8M0 exponent per row), 4 = stop there (no GEMM), 8 = W is NOT exact in the operand type: on entry W8 holds
+ * its 16-bit residuals (W's layout); a third segment A_hi(e4m3) x e4m3(W_lo)^T is added (aexp: int32 [2 M], wexp: int [2]).
+ * Output as lr_op_gemm_bt_split.  K multiple of 128. */
 int lr_op_gemm_bt_mixed(void* A, const void* W, void* W8, int* aexp, void* C, const float* bias, int M, int N, int K, int epi, int act,
                         int operand_dtype, int flags, int* wexp, void* hip_stream);
 int lr_op_norm_rows(const float* x, const float* w, const float* b, void* y, int rows, int H, float eps,

@@ -119,6 +119,10 @@ struct GemmParams {
     // split-operand mode with an e4m3 residual pass (launch_gemm_bt8_mixed): E8M0 scale of every residual row, and of W8
     const int* aexp;
     int wexp;
+    // ... with weights that are not exact in the operand type: a third segment, A_hi as e4m3 (row exponents aexp2, bytes behind the
+    // residual bytes) against e4m3(W_lo) (tensor exponent wexp2, bytes behind W8 in the same rows); K = 2 kw
+    const int* aexp2;
+    int wexp2;
 };
 
 struct AttnParams {

@@ -86,6 +86,8 @@ struct lr_engine {
     int* aexp = nullptr; size_t aexp_cap = 0;        // E8M0 exponent of every residual row of the GEMM being launched
     unsigned* amax_word = nullptr;
     std::unordered_map<const void*, int> w8exp;      // weight base pointer -> E8M0 exponent of its prepared e4m3 twin
+    std::unordered_map<const void*, int> w8exp2;     // ... and of e4m3(W_lo) for weights that are inexact in the operand type
+    void* w8tmp = nullptr; size_t w8tmp_cap = 0;
     int w8a8 = 0;              // W8A8 mode (desc.w8a8): e4m3 GEMM operands with per-row / per-channel fp32 scales
     struct W8 { void* q; float* scale; };
     std::unordered_map<const void*, W8> w8;          // weight base pointer -> its e4m3 twin (prepared on first use)
@@ -271,7 +273,7 @@ inline void apply_prec_base(const lr_engine* e, GemmParams& p) {
 // The choice must not depend on M: a row's reward has to be bit-identical whatever else is in the batch (sharding across GPUs
 // must not change a preference), so every eligible GEMM takes this form -- on the deep-pipelined kernel -- at any row count.
 inline bool lo8_eligible(const lr_engine* e, const GemmParams& p) {      // p after apply_prec_base
-    if (!e->lo8 || p.kw <= 0 || p.Wlo != nullptr) return false;          // (Wlo: weights inexact in the operand type)
+    if (!e->lo8 || p.kw <= 0) return false;
     if (e->wbuf_of.find(p.W) == e->wbuf_of.end()) return false;
     const bool aligned = p.N % 8 == 0 && p.ldc % 8 == 0 && (((uintptr_t)p.C) & 15) == 0 && (!p.bias || (((uintptr_t)p.bias) & 15) == 0);
     return aligned && p.kw % 128 == 0 && p.ldw == p.kw && (e->gemm_tile < 0 || e->gemm_tile == 6);
@@ -279,22 +281,39 @@ inline bool lo8_eligible(const lr_engine* e, const GemmParams& p) {      // p af
 inline void upgrade_lo8(lr_engine* e, GemmParams& p, hipStream_t st) {
     if (p.aexp) return;
     if (lo8_eligible(e, p)) {
+        // Weights inexact in the operand type (Wlo set by apply_prec_base: a merged LoRA adapter, fp32-trained weights): a third
+        // e4m3 segment, A_hi8 x e4m3(W_lo)^T, replaces the 16-bit [x_hi] x [W_lo] segment (2x instead of 3x the single pass).
+        const bool inexact = p.Wlo != nullptr;
         auto it = e->wbuf_of.find(p.W);
+        char* twin = e->wbufs[it->second].lo;
         auto w8 = e->w8exp.find(p.W);
         if (w8 == e->w8exp.end()) {
             if (!e->amax_word) e->amax_word = (unsigned*)e->dalloc(256, false);
-            const int E = prepare_weight_e4m3(p.W, p.ldw, p.kw, p.N, e->wbufs[it->second].lo, e->op_dt, e->amax_word, st);
+            int E = 127, E2 = 127;
+            if (inexact) {
+                const size_t need = (size_t)p.N * p.ldw * 2;
+                if (need > e->w8tmp_cap) { e->w8tmp_cap = need; e->w8tmp = e->dalloc(need, false); }
+                prepare_weight_e4m3_pair(p.W, twin, p.ldw, p.kw, p.N, e->w8tmp, e->op_dt, e->amax_word, st, &E, &E2);
+            } else {
+                E = prepare_weight_e4m3(p.W, p.ldw, p.kw, p.N, twin, e->op_dt, e->amax_word, st);
+            }
             w8 = e->w8exp.emplace(p.W, E).first;
+            e->w8exp2[p.W] = E2;
         }
         if ((size_t)p.M > e->aexp_cap) {
             e->aexp_cap = ((size_t)p.M + 4095) & ~(size_t)4095;
-            e->aexp = (int*)e->dalloc(e->aexp_cap * 4, false);
+            e->aexp = (int*)e->dalloc(e->aexp_cap * 2 * 4, false);          // [residual rows | hi rows]
         }
-        launch_quantize_lo_inplace(const_cast<void*>(p.A), p.lda, p.kw, p.M, e->aexp, e->op_dt, st);
-        p.K = p.kw + p.kw / 2;
-        p.Wlo = e->wbufs[it->second].lo;
+        int* aexp2 = inexact ? e->aexp + e->aexp_cap : nullptr;
+        launch_quantize_lo_inplace(const_cast<void*>(p.A), p.lda, p.kw, p.M, e->aexp, e->op_dt, st, aexp2);
+        p.K = inexact ? 2 * p.kw : p.kw + p.kw / 2;
+        p.Wlo = twin;
         p.aexp = e->aexp;
         p.wexp = w8->second;
+        p.aexp2 = aexp2;
+        p.wexp2 = e->w8exp2[p.W];
+    } else if (e->lo8 && p.Wlo && e->w8exp.count(p.W)) {
+        throw std::runtime_error("this weight's residual twin has been converted to e4m3; re-upload the weights before changing the GEMM tile");
     }
 }
 inline void apply_prec(lr_engine* e, GemmParams& p, hipStream_t st) {

@@ -344,23 +344,25 @@ int lr_upload_weight(lr_handle h, const char* name, const void* data, const int6
             f32 = h->stage_f32;
         }
         pack_slot(h, s, f32);
-        h->w8exp.clear(); h->w8.clear();          // the e4m3 twins live in the residual buffers pack_slot has just rewritten
+        h->w8exp.clear(); h->w8exp2.clear(); h->w8.clear();          // the e4m3 twins live in the residual buffers pack_slot has just rewritten
         LR_HIP_CHECK(hipStreamSynchronize(0));
         if (h->finalized && h->inexact_dev)      // a re-upload after lr_finalize may have made a buffer inexact
             LR_HIP_CHECK(hipMemcpy(h->inexact.data(), h->inexact_dev, h->wbufs.size() * sizeof(int), hipMemcpyDeviceToHost));
     });
 }
 
-int lr_synth_weights(lr_handle h, uint64_t seed) {
+int lr_synth_weights(lr_handle h, uint64_t seed) { return lr_synth_weights_ex(h, seed, 0); }
+
+int lr_synth_weights_ex(lr_handle h, uint64_t seed, int flags) {
     if (!h) return LR_EINVAL;
     return guarded(h, [&] {
         for (Slot& s : h->slots) {
             const size_t n = (size_t)s.rows * s.cols;
             ensure_stage(h, 0, n);
-            launch_synth_fill(h->stage_f32, n, tensor_seed(seed, s.name.c_str()), uniform_scale(s.std_), (float)s.offset, 1, 0);
+            launch_synth_fill(h->stage_f32, n, tensor_seed(seed, s.name.c_str()), uniform_scale(s.std_), (float)s.offset, (flags & 1) ? 0 : 1, 0);
             pack_slot(h, s, h->stage_f32);
         }
-        h->w8exp.clear(); h->w8.clear();
+        h->w8exp.clear(); h->w8exp2.clear(); h->w8.clear();
         LR_HIP_CHECK(hipStreamSynchronize(0));
     });
 }
@@ -621,18 +623,27 @@ int lr_op_gemm_bt_mixed(void* A, const void* W, void* W8, int* aexp, void* C, co
         const int dt = operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16;
         hipStream_t st = (hipStream_t)hip_stream;
         if (!wexp) throw std::runtime_error("lr_op_gemm_bt_mixed: wexp is required");
-        if (flags & 1) {                                   // prepare the e4m3 twin of W (synchronous)
+        const bool inexact = (flags & 8) != 0;
+        if (flags & 1) {                                   // prepare the e4m3 twin(s) of W (synchronous)
             unsigned* word = nullptr;
             LR_HIP_CHECK(hipMalloc((void**)&word, 4));
-            *wexp = prepare_weight_e4m3(W, K, K, N, W8, dt, word, st);
+            if (inexact) {
+                void* tmp = nullptr;
+                LR_HIP_CHECK(hipMalloc(&tmp, (size_t)N * K * 2));
+                prepare_weight_e4m3_pair(W, W8, K, K, N, tmp, dt, word, st, &wexp[0], &wexp[1]);
+                LR_HIP_CHECK(hipFree(tmp));
+            } else {
+                wexp[0] = prepare_weight_e4m3(W, K, K, N, W8, dt, word, st);
+            }
             LR_HIP_CHECK(hipFree(word));
         }
-        if (flags & 2) launch_quantize_lo_inplace(A, 2 * K, K, M, aexp, dt, st);       // re-encode the residual half of A
+        if (flags & 2) launch_quantize_lo_inplace(A, 2 * K, K, M, aexp, dt, st, inexact ? aexp + M : nullptr);       // re-encode A's residual half
         if (flags & 4) return;
         const int nout = epi == EPI_SWIGLU_OP ? N / 2 : N;
         const bool op_out = epi == EPI_OUT_OP || epi == EPI_SWIGLU_OP;
-        GemmParams p{A, W, C, bias, M, N, K + K / 2, 2 * K, K, op_out ? 2 * nout : nout, epi, act, nullptr, 0, 0, K, op_out ? nout : 0, W8};
-        p.aexp = aexp; p.wexp = *wexp;
+        GemmParams p{A, W, C, bias, M, N, inexact ? 2 * K : K + K / 2, 2 * K, K, op_out ? 2 * nout : nout, epi, act, nullptr, 0, 0, K, op_out ? nout : 0, W8};
+        p.aexp = aexp; p.wexp = wexp[0];
+        if (inexact) { p.aexp2 = aexp + M; p.wexp2 = wexp[1]; }
         launch_gemm_bt8_mixed(p, dt, st);
     });
 }

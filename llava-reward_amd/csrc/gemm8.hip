@@ -88,6 +88,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
     const int nwg = Mt * Nt;
     const int nk = p.K / BK;
     const int nk_hi = F8 == 2 ? p.kw / BK : nk;      // K-tiles of 16-bit operands; the rest are e4m3
+    const int nk_lo = F8 == 2 ? nk_hi + p.kw / (2 * BK) : nk;      // end of the residual segment; beyond it: A_hi8 x Wlo8 (inexact weights)
     const int Gtot = 4 * nk;
     typedef __attribute__((address_space(3))) char lds_char;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_char*)smem;
@@ -193,6 +194,8 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         // F8 == 2: E8M0 exponents of this tile's residual rows (one per A row a lane feeds: [A half][row tile]) and of W8.  Ordinary
         // loads: retired here, in front of the DMA stream, so that no compiler-placed vmcnt wait can appear inside the K loop.
         int ea[2] = {0x7F7F7F7F, 0x7F7F7F7F};        // [A half]: byte i = exponent of row tile i
+        int ea2[2] = {0x7F7F7F7F, 0x7F7F7F7F};       // the same for the third segment (A_hi as e4m3)
+        const int eb2 = p.wexp2;
         const int eb = p.wexp;
         if constexpr (F8 == 2) {
 #pragma unroll
@@ -202,8 +205,17 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                     const int e1 = p.aexp[min(m0 + h2 * 128 + wr * 64 + i * 16 + l15, p.M - 1)] & 255;
                     ea[h2] = i == 0 ? e1 : (ea[h2] | (e1 << (8 * i)));
                 }
+            if (nk > nk_lo) {                    // weights inexact in the operand type: third segment, A_hi as e4m3 against e4m3(W_lo)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int e1 = p.aexp2[min(m0 + h2 * 128 + wr * 64 + i * 16 + l15, p.M - 1)] & 255;
+                        ea2[h2] = i == 0 ? e1 : (ea2[h2] | (e1 << (8 * i)));
+                    }
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("" : "+v"(ea[0]), "+v"(ea[1]));
+            asm volatile("" : "+v"(ea[0]), "+v"(ea[1]), "+v"(ea2[0]), "+v"(ea2[1]));
         }
 
         if constexpr (PB == 2) {
@@ -243,7 +255,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         // with its own straight-line body: a run-time branch around the two MFMA kinds merges 64 accumulator registers behind it
         // and spills inside the K loop.
         auto ktile = [&](auto lo_tag, const int kt) {
-            constexpr bool LO = decltype(lo_tag)::value;
+            constexpr int LO = decltype(lo_tag)::value;          // 0: 16-bit K-tile, 1: e4m3 residual K-tile, 2: e4m3 A_hi x W_lo K-tile
             int s2 = rslot + 2; s2 = s2 >= NS ? s2 - NS : s2;
             int s3 = rslot + 3; s3 = s3 >= NS ? s3 - NS : s3;
             int s5 = rslot + 5; s5 = s5 >= NS ? s5 - NS : s5;
@@ -292,7 +304,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 #pragma unroll
                             for (int j = 0; j < 2; ++j)
                                 acc[qa][i][j] = F8 == 1 ? mfma_f8(af[i * 2], af[i * 2 + 1], bf[j * 2], bf[j * 2 + 1], acc[qa][i][j])
-                                                        : mfma_f8s<i>(af[i * 2], af[i * 2 + 1], bf[j * 2], bf[j * 2 + 1], acc[qa][i][j], ea[sp], eb);
+                                                        : mfma_f8s<i>(af[i * 2], af[i * 2 + 1], bf[j * 2], bf[j * 2 + 1], acc[qa][i][j], LO == 2 ? ea2[sp] : ea[sp], LO == 2 ? eb2 : eb);
                         });
                     } else {
 #pragma unroll
@@ -312,7 +324,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 #pragma unroll
                             for (int j = 0; j < 2; ++j)
                                 acc[qb][i][j] = F8 == 1 ? mfma_f8(af[i * 2], af[i * 2 + 1], bg[j * 2], bg[j * 2 + 1], acc[qb][i][j])
-                                                        : mfma_f8s<i>(af[i * 2], af[i * 2 + 1], bg[j * 2], bg[j * 2 + 1], acc[qb][i][j], ea[sp], eb);
+                                                        : mfma_f8s<i>(af[i * 2], af[i * 2 + 1], bg[j * 2], bg[j * 2 + 1], acc[qb][i][j], LO == 2 ? ea2[sp] : ea[sp], LO == 2 ? eb2 : eb);
                         });
                     } else {
 #pragma unroll
@@ -346,9 +358,11 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         };
         {
             int kt = 0;
-            for (; kt < nk_hi; ++kt) ktile(std::false_type{}, kt);
-            if constexpr (F8 == 2)
-                for (; kt < nk; ++kt) ktile(std::true_type{}, kt);
+            for (; kt < nk_hi; ++kt) ktile(IC<0>{}, kt);
+            if constexpr (F8 == 2) {
+                for (; kt < nk_lo; ++kt) ktile(IC<1>{}, kt);
+                for (; kt < nk; ++kt) ktile(IC<2>{}, kt);
+            }
         }
         if (wr == 0) LR_BARRIER();                      // balance the stagger barrier
         } else {
@@ -772,8 +786,8 @@ void launch_gemm_bt8_fp8(GemmParams p, int operand_dtype, hipStream_t st) {
 // K = kw + kw / 2 (2-byte units), Wlo = the rows that hold W8, aexp / wexp = the E8M0 scales.
 void launch_gemm_bt8_mixed(const GemmParams& p, int operand_dtype, hipStream_t st) {
     if (p.M <= 0) return;
-    if (p.kw <= 0 || p.kw % 128 || p.K != p.kw + p.kw / 2 || !p.Wlo || !p.aexp)
-        throw std::runtime_error("gemm_bt8_mixed: needs kw % 128 == 0, K == 1.5 kw, W8 rows and row exponents");
+    if (p.kw <= 0 || p.kw % 128 || (p.K != p.kw + p.kw / 2 && p.K != 2 * p.kw) || !p.Wlo || !p.aexp || (p.K == 2 * p.kw && !p.aexp2))
+        throw std::runtime_error("gemm_bt8_mixed: needs kw % 128 == 0, K == 1.5 kw (2 kw with the A_hi8 x Wlo8 segment), W8 rows and row exponents");
     if (p.N % 8 || p.ldc % 8 || ((uintptr_t)p.C & 15) || (p.bias && ((uintptr_t)p.bias & 15)))
         throw std::runtime_error("gemm_bt8_mixed: N and ldc must be multiples of 8 and C/bias 16-byte aligned");
     if (p.epi == EPI_ROPE_OP && (!p.rope_cs || p.rope_hd % 16 || p.rope_cols % 256 || p.rope_cols % p.rope_hd || ((uintptr_t)p.rope_cs & 15)))

@@ -878,8 +878,11 @@ __device__ __forceinline__ int e8m0_of_amax(float amax) {      // 2^(E-127) puts
 // Rows [hi x K | lo x K] of 2-byte elements: the residual half is rewritten IN PLACE as K e4m3 bytes (the first half of its own
 // space) + one E8M0 exponent per row.  One wave per row, two sweeps (row maximum, then convert); a sweep step reads bytes
 // [1024 t, 1024 t + 1024) of the residual half and writes [512 t, 512 t + 512): only bytes that were already consumed.
+// aexp2 != null (weights inexact in the operand type): the hi half is ALSO encoded, K more e4m3 bytes + exponent, into the second half
+// of the residual space (behind the residual bytes), after the residual sweep has consumed it.
 template <typename OT>
-__global__ __launch_bounds__(256) void quantize_lo_inplace_kernel(unsigned short* __restrict__ a, int ld, int K, int rows, int* __restrict__ aexp) {
+__global__ __launch_bounds__(256) void quantize_lo_inplace_kernel(unsigned short* __restrict__ a, int ld, int K, int rows, int* __restrict__ aexp,
+                                                                  int* __restrict__ aexp2) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     unsigned short* lo = a + (size_t)row * ld + K;
@@ -918,14 +921,47 @@ __global__ __launch_bounds__(256) void quantize_lo_inplace_kernel(unsigned short
             *(uint2*)(q + k) = make_uint2((unsigned)l2, (unsigned)h2);
         }
     }
+    if (aexp2) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned short* hi = a + (size_t)row * ld;
+        float hmax = 0.f;
+        for (int k = lane * 8; k < K; k += 512) {
+            const uint4 v = *(const uint4*)(hi + k);
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                hmax = fmaxf(hmax, fabsf(Op<OT>::to_f32((unsigned short)(w[i] & 0xFFFF))));
+                hmax = fmaxf(hmax, fabsf(Op<OT>::to_f32((unsigned short)(w[i] >> 16))));
+            }
+        }
+        hmax = wave_max(hmax);
+        const int E2 = e8m0_of_amax(hmax);
+        if (lane == 0) aexp2[row] = E2;
+        for (int k = lane * 8; k < K; k += 512) {
+            const uint4 v = *(const uint4*)(hi + k);
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+            float f[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f[2 * i] = ldexpf(Op<OT>::to_f32((unsigned short)(w[i] & 0xFFFF)), 127 - E2);
+                f[2 * i + 1] = ldexpf(Op<OT>::to_f32((unsigned short)(w[i] >> 16)), 127 - E2);
+            }
+            int l2 = 0, h2 = 0;
+            l2 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], l2, false);
+            l2 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], l2, true);
+            h2 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], h2, false);
+            h2 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], h2, true);
+            *(uint2*)(q + K + k) = make_uint2((unsigned)l2, (unsigned)h2);
+        }
+    }
 }
 
-void launch_quantize_lo_inplace(void* a, int ld, int K, int rows, int* aexp, int operand_dtype, hipStream_t st) {
+void launch_quantize_lo_inplace(void* a, int ld, int K, int rows, int* aexp, int operand_dtype, hipStream_t st, int* aexp2) {
     if (rows <= 0) return;
     if (K % 8 || ld % 8) throw std::runtime_error("quantize_lo_inplace: K and the row stride must be multiples of 8");
     const dim3 grid((rows + 3) / 4), block(256);
-    if (operand_dtype == DT_F16) hipLaunchKernelGGL(quantize_lo_inplace_kernel<F16>, grid, block, 0, st, (unsigned short*)a, ld, K, rows, aexp);
-    else hipLaunchKernelGGL(quantize_lo_inplace_kernel<BF16>, grid, block, 0, st, (unsigned short*)a, ld, K, rows, aexp);
+    if (operand_dtype == DT_F16) hipLaunchKernelGGL(quantize_lo_inplace_kernel<F16>, grid, block, 0, st, (unsigned short*)a, ld, K, rows, aexp, aexp2);
+    else hipLaunchKernelGGL(quantize_lo_inplace_kernel<BF16>, grid, block, 0, st, (unsigned short*)a, ld, K, rows, aexp, aexp2);
 }
 
 // W8 twin of a weight matrix [N, K] (2-byte elements, row stride ldw): e4m3(W * 2^(127 - E)) into the first K bytes of the rows of
@@ -951,6 +987,33 @@ __global__ __launch_bounds__(256) void weight_to_e4m3_kernel(const unsigned shor
         pk = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(Op<OT>::to_f32(wr[k + 2]), 127 - E), ldexpf(Op<OT>::to_f32(wr[k + 3]), 127 - E), pk, true);
         *(unsigned*)(q + k) = (unsigned)pk;
     }
+}
+
+// Weights that are not exact in the operand type: `twin` holds their 16-bit residuals (same layout as W).  The residuals become
+// e4m3 bytes K .. 2K-1 of their own rows and W's e4m3 twin bytes 0 .. K-1 (via `tmp`, a scratch of W's size, because both overwrite
+// their source rows).  Returns the two tensor exponents (W8, Wlo8).  Synchronous, one-time.
+void prepare_weight_e4m3_pair(const void* w, void* twin, int ldw, int K, int N, void* tmp, int operand_dtype, unsigned* scratch_word,
+                              hipStream_t st, int* wexp, int* wexp2) {
+    if (K % 4 || ldw % 2) throw std::runtime_error("prepare_weight_e4m3_pair: K must be a multiple of 4");
+    const dim3 grid((N + 3) / 4), block(256);
+    auto amax_of = [&](const void* src) {
+        LR_HIP_CHECK(hipMemsetAsync(scratch_word, 0, 4, st));
+        if (operand_dtype == DT_F16) hipLaunchKernelGGL(weight_amax_kernel<F16>, grid, block, 0, st, (const unsigned short*)src, ldw, K, N, scratch_word);
+        else hipLaunchKernelGGL(weight_amax_kernel<BF16>, grid, block, 0, st, (const unsigned short*)src, ldw, K, N, scratch_word);
+        unsigned bits = 0;
+        LR_HIP_CHECK(hipMemcpyAsync(&bits, scratch_word, 4, hipMemcpyDeviceToHost, st));
+        LR_HIP_CHECK(hipStreamSynchronize(st));
+        float amax;
+        memcpy(&amax, &bits, 4);
+        return amax > 0.f ? 127 + (std::ilogb(amax) - 7) : 127;
+    };
+    *wexp2 = amax_of(twin);
+    // e4m3(W_lo) -> bytes 0 .. K-1 of tmp's rows (tmp has W's layout and size)
+    if (operand_dtype == DT_F16) hipLaunchKernelGGL(weight_to_e4m3_kernel<F16>, grid, block, 0, st, (const unsigned short*)twin, ldw, K, N, *wexp2, (unsigned char*)tmp);
+    else hipLaunchKernelGGL(weight_to_e4m3_kernel<BF16>, grid, block, 0, st, (const unsigned short*)twin, ldw, K, N, *wexp2, (unsigned char*)tmp);
+    *wexp = prepare_weight_e4m3(w, ldw, K, N, twin, operand_dtype, scratch_word, st);          // bytes 0 .. K-1 of the twin's rows
+    LR_HIP_CHECK(hipMemcpy2DAsync((char*)twin + K, (size_t)ldw * 2, tmp, (size_t)ldw * 2, K, N, hipMemcpyDeviceToDevice, st));
+    LR_HIP_CHECK(hipStreamSynchronize(st));
 }
 
 // Synchronous (one-time weight preparation): returns the E8M0 exponent of the tensor.

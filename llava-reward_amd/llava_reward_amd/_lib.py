@@ -59,6 +59,7 @@ _SIGS = {
     "lr_last_error": (C.c_char_p, [C.c_void_p]),
     "lr_upload_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int]),
     "lr_synth_weights": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "lr_synth_weights_ex": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int]),
     "lr_num_weights": (C.c_int, [C.c_void_p]),
     "lr_weight_name": (C.c_char_p, [C.c_void_p, C.c_int]),
     "lr_finalize": (C.c_int, [C.c_void_p]),

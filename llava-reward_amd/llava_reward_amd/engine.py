@@ -148,8 +148,8 @@ class RewardEngine:
         if strict and names:
             raise KeyError(f"missing weights: {sorted(names)[:8]}{' ...' if len(names) > 8 else ''}")
 
-    def synth_weights(self, seed: int) -> None:
-        L.check(self.lib, self.lib.lr_synth_weights(self.h, C.c_uint64(seed)), self.h, "lr_synth_weights")
+    def synth_weights(self, seed: int, fp32_valued: bool = False) -> None:
+        L.check(self.lib, self.lib.lr_synth_weights_ex(self.h, C.c_uint64(seed), 1 if fp32_valued else 0), self.h, "lr_synth_weights")
 
     def finalize(self) -> None:
         L.check(self.lib, self.lib.lr_finalize(self.h), self.h, "lr_finalize")

@@ -58,7 +58,7 @@ class RewardModel:
         if self._weights is not None:
             eng.load_state_dict(self._weights, strict=True)
         else:
-            eng.synth_weights(self._synth_seed)
+            eng.synth_weights(self._synth_seed, getattr(self, "synth_fp32_valued", False))
         eng.finalize()
         if self.engine is not None:
             self.engine.close()

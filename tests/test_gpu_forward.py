@@ -231,7 +231,7 @@ def test_parity_mode_with_inexact_weights(backbone):
     for dtype in ("f16x2", "f16x2f8", "f16"):
         m = RewardModel(cfg, weights=W, max_batch=4, max_seq=1024, max_crops=5, max_patches=4096, operand_dtype=dtype).to("cuda").eval()
         if dtype == "f16x2f8":
-            m.engine.set_gemm_tile(6)       # deep-pipelined kernel everywhere: inexact weights must still take the 16-bit 3-segment form
+            m.engine.set_gemm_tile(6)       # deep-pipelined kernel everywhere: inexact weights take the e4m3 third segment (A_hi8 x Wlo8)
         tb = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
         if backbone == "phi3v":
             r, _ = m.custom_forward(tb["input_ids"], tb["attention_mask"], tb["pixel_values"], tb["image_sizes"])
@@ -240,7 +240,8 @@ def test_parity_mode_with_inexact_weights(backbone):
         torch.cuda.synchronize()
         errs[dtype] = (r.cpu() - ref).abs().max().item()
     print(f"[inexact weights, {backbone}] f16x2 err {errs['f16x2']:.2e}   f16 err {errs['f16']:.2e}")
-    assert errs["f16x2"] < TOL_X2 and errs["f16x2f8"] < TOL_X2 and errs["f16"] < 3e-3
+    print(f"[inexact weights, {backbone}] f16x2f8 err {errs['f16x2f8']:.2e}")
+    assert errs["f16x2"] < TOL_X2 and errs["f16x2f8"] < TOL_X8 and errs["f16x2f8"] < 0.5 * errs["f16"] and errs["f16"] < 3e-3
 
 
 def test_right_padding_single_row_and_all_padding_row():

@@ -442,3 +442,32 @@ def test_gemm_w8a8_e4m3(lib):
         ref = (xq.view(torch.float8_e4m3fn).float() @ wq.view(torch.float8_e4m3fn).float().T) * xs[:, None] * ws[None, :] + bias
         assert (out - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
     assert lib.lr_op_gemm_fp8(P(xq), P(xs), P(wq), P(ws), P(out), None, M, N, 100, N, L.EPI_OUT_F32, 0, code, stream()) != 0     # K % 128
+
+
+def test_gemm_e4m3_residual_pass_with_inexact_weights(lib):
+    """Weights that are not exact in f16 (fp32-valued: a merged LoRA adapter): W = W_hi + W_lo, and the e4m3 form adds a third
+    segment A_hi(e4m3) x e4m3(W_lo)^T.  Against fp64 on the un-rounded A and W."""
+    code, tdt = L.LR_DT_F16, torch.float16
+    for (M, N, K) in [(700, 512, 384), (4100, 768, 3072)]:
+        A32 = rnd((M, K), 181, 0.7)
+        W32 = rnd((N, K), 182, 0.05)
+        Whi = W32.to(tdt)
+        Wlo = (W32 - Whi.float()).to(tdt)
+        hi, lo = _split(A32, tdt)
+        A2 = torch.cat([hi, lo], dim=1).contiguous()
+        ref = (A32.double() @ W32.double().t()).float()
+        scale = ref.abs().max().item()
+        twin = Wlo.clone().contiguous()
+        aexp = torch.zeros(2 * M, dtype=torch.int32, device="cuda")
+        wexp = (C.c_int * 2)(0, 0)
+        out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+        assert lib.lr_op_gemm_bt_mixed(P(A2), P(Whi), P(twin), P(aexp), P(out), None, M, N, K, L.EPI_OUT_F32, 0, code, 11, wexp, stream()) == 0
+        torch.cuda.synchronize()
+        err = (out - ref).abs().max().item()
+        exact_w = torch.empty(M, N, device="cuda", dtype=torch.float32)           # the same launch without the third segment: W_lo ignored
+        A3 = torch.cat([hi, lo], dim=1).contiguous()
+        twin2 = torch.zeros_like(Whi)
+        assert lib.lr_op_gemm_bt_mixed(P(A3), P(Whi), P(twin2), P(aexp), P(exact_w), None, M, N, K, L.EPI_OUT_F32, 0, code, 3, wexp, stream()) == 0
+        torch.cuda.synchronize()
+        e_nolo = (exact_w - ref).abs().max().item()
+        assert err < 3e-5 * scale and err < e_nolo / 4, (M, N, K, err / scale, e_nolo / scale)
