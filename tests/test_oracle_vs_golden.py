@@ -160,3 +160,22 @@ def test_qwen_geometry_kats():
     assert pos[0, 1, 9:21].tolist() == [3] * 12
     assert pos[1, 1, 9:21].tolist() == [3] * 6 + [4] * 6 and pos[2, 1, 9:21].tolist() == [3, 4, 5, 6, 7, 8] * 2
     assert pos[:, 1, 21].tolist() == [9, 9, 9]
+
+
+def test_w8a8_emulation_known_answers():
+    """The W8A8 emulation of the oracle (phi3v_reward_oracle.W8A8Round.lin) against OCP e4m3 known answers: per-row scale
+    max|x| / 448, round-to-nearest-even, and the byte patterns of torch.float8_e4m3fn the HIP quantiser is tested against."""
+    import torch
+    from oracle import phi3v_reward_oracle as orc
+    f8 = torch.float8_e4m3fn
+    kat = {448.0: 0x7E, 1.0: 0x38, 1.5: 0x3C, 0.015625: 0x08, 2.0 ** -9: 0x01, -2.0: 0xC0, 0.0: 0x00, 240.0: 0x77, 17.0: 0x58, 19.0: 0x5A}
+    for v, byte in kat.items():           # 17 -> 16 (tie to even mantissa 000), 19 -> 20 (tie to even mantissa 010)
+        assert torch.tensor([v]).to(f8).view(torch.uint8).item() == byte, v
+    x = torch.tensor([[448.0, 1.0, -224.0, 0.4], [0.0, 0.0, 0.0, 0.0], [1e-3, -2e-3, 5e-4, 0.0]])
+    q = orc.W8A8Round.lin(x)
+    assert torch.equal(q[0], torch.tensor([448.0, 1.0, -224.0, 0.40625]))      # scale 1: 0.4 -> 0.40625 (13 / 32)
+    assert torch.equal(q[1], torch.zeros(4))                                    # zero row: scale 1
+    s = 2e-3 / 448.0
+    assert torch.allclose(q[2], torch.tensor([224.0 * s, -448.0 * s, 112.0 * s, 0.0]), rtol=1e-6, atol=0)
+    r = orc.W8A8Round(orc.f16_round)
+    assert torch.equal(r(torch.tensor([1.0 + 2.0 ** -12])), torch.tensor([1.0]))   # the activation rounding stays f16
