@@ -88,6 +88,7 @@ struct lr_engine {
     std::unordered_map<const void*, int> w8exp;      // weight base pointer -> E8M0 exponent of its prepared e4m3 twin
     std::unordered_map<const void*, int> w8exp2;     // ... and of e4m3(W_lo) for weights that are inexact in the operand type
     void* w8tmp = nullptr; size_t w8tmp_cap = 0;
+    const void* pre_enc = nullptr;                   // operand buffer whose residual half its producer has already written in e4m3
     int w8a8 = 0;              // W8A8 mode (desc.w8a8): e4m3 GEMM operands with per-row / per-channel fp32 scales
     struct W8 { void* q; float* scale; };
     std::unordered_map<const void*, W8> w8;          // weight base pointer -> its e4m3 twin (prepared on first use)
@@ -305,7 +306,8 @@ inline void upgrade_lo8(lr_engine* e, GemmParams& p, hipStream_t st) {
             e->aexp = (int*)e->dalloc(e->aexp_cap * 2 * 4, false);          // [residual rows | hi rows]
         }
         int* aexp2 = inexact ? e->aexp + e->aexp_cap : nullptr;
-        launch_quantize_lo_inplace(const_cast<void*>(p.A), p.lda, p.kw, p.M, e->aexp, e->op_dt, st, aexp2);
+        if (e->pre_enc == p.A && !inexact) e->pre_enc = nullptr;          // the producer (a norm kernel) wrote [hi | e4m3(lo)] and e->aexp itself
+        else launch_quantize_lo_inplace(const_cast<void*>(p.A), p.lda, p.kw, p.M, e->aexp, e->op_dt, st, aexp2);
         p.K = inexact ? 2 * p.kw : p.kw + p.kw / 2;
         p.Wlo = twin;
         p.aexp = e->aexp;
@@ -319,6 +321,20 @@ inline void upgrade_lo8(lr_engine* e, GemmParams& p, hipStream_t st) {
 inline void apply_prec(lr_engine* e, GemmParams& p, hipStream_t st) {
     apply_prec_base(e, p);
     upgrade_lo8(e, p, st);
+}
+// For a norm kernel that feeds the GEMM described by `probe` (logical shapes, as passed to gemm()): where to put the row exponents if
+// that GEMM will take the e4m3 residual form with exact weights, else null (the norm then writes 16-bit residuals as usual).
+inline int* lo8_norm_target(lr_engine* e, GemmParams probe) {
+    e->pre_enc = nullptr;
+    if (!e->lo8) return nullptr;
+    apply_prec_base(e, probe);
+    if (!lo8_eligible(e, probe) || probe.Wlo) return nullptr;
+    if ((size_t)probe.M > e->aexp_cap) {
+        e->aexp_cap = ((size_t)probe.M + 4095) & ~(size_t)4095;
+        e->aexp = (int*)e->dalloc(e->aexp_cap * 2 * 4, false);
+    }
+    e->pre_enc = probe.A;
+    return e->aexp;
 }
 inline void apply_prec(const lr_engine* e, AttnParams& p) {
     if (!e->prec) return;

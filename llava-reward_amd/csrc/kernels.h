@@ -26,7 +26,8 @@ void launch_attention(const AttnParams& p, int batch, int head_dim, bool causal,
 // y_op[r][:] = LN(x[r][:]) * w + b   (b == null -> RMSNorm: x * rsqrt(mean x^2 + eps) * w)
 // prec = 1 (every operand producer below): split-operand mode, rows are stored [hi | lo], twice as wide (common.h split2)
 void launch_norm_rows(const float* x, const float* w, const float* b, void* y, int rows, int H, float eps,
-                      int operand_dtype, hipStream_t st, int prec = 0, int group = 1);   // group g: g consecutive rows form one output row
+                      int operand_dtype, hipStream_t st, int prec = 0, int group = 1, int* lo8 = nullptr);   // group g: g consecutive rows form one output row;
+// lo8: write the residual half as e4m3 + one E8M0 exponent per row (lo8[row]) instead of 16-bit residuals
 // pixels [B, C, 3, img, img] (fp32/bf16) -> patch matrix [ncrop*g*g, Kpad] operand dtype; crop_src[i] = b*C + c
 void launch_im2col(const void* pixels, int pix_dtype, const int* crop_src, int ncrop, int img, int patch, int Kpad,
                    void* out, int operand_dtype, hipStream_t st, int prec = 0);

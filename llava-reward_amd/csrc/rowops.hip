@@ -29,6 +29,10 @@ template <typename OT> __device__ __forceinline__ void store4s(void* base, size_
     if (prec) *(uint2*)(dst + W) = l;
 }
 
+__device__ __forceinline__ int e8m0_of_amax(float amax) {      // 2^(E-127) puts amax into [128, 256) <= 448; E = 127 for a zero row
+    return amax > 0.f ? 127 + (ilogbf(amax) - 7) : 127;
+}
+
 // ------------------------------------------------------------------------------------------ norms
 // modeling_phi3_v.py:377-391 (RMSNorm: w * (x * rsqrt(mean(x^2) + eps))) and CLIP LayerNorm.
 constexpr int NORM_MAXC = 16;   // H <= 4096
@@ -36,7 +40,7 @@ constexpr int NORM_MAXC = 16;   // H <= 4096
 template <typename OT, bool LAYERNORM>
 __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, void* __restrict__ y, int rows,
-                                                        int H, float eps, int prec, int group) {
+                                                        int H, float eps, int prec, int group, int* __restrict__ lo8) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -82,24 +86,60 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
                 const float4 bb = ((const float4*)b)[c];
                 o0 += bb.x; o1 += bb.y; o2 += bb.z; o3 += bb.w;
             }
-            store4s<OT>(y, row / group, H * group, prec, (row % group) * H + 4 * c, o0, o1, o2, o3);
+            if (lo8) v[i] = make_float4(o0, o1, o2, o3);
+            else store4s<OT>(y, row / group, H * group, prec, (row % group) * H + 4 * c, o0, o1, o2, o3);
+        }
+    }
+    if (lo8) {
+        // default parity mode, the consumer is a GEMM with the e4m3 residual pass: write [hi | e4m3(lo)] and the row's E8M0 exponent
+        // directly (what quantize_lo_inplace_kernel would make of the [hi | lo] row, minus its extra pass over HBM; group == 1)
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < NORM_MAXC; ++i) {
+            if (lane + 64 * i < nch) {
+                const float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(o[j] - Op<OT>::to_f32(Op<OT>::from_f32(o[j]))));
+            }
+        }
+        amax = wave_max(amax);
+        const int E = e8m0_of_amax(amax);
+        if (lane == 0) lo8[row] = E;
+        unsigned short* dst = (unsigned short*)y + (size_t)row * (2 * H);
+        unsigned char* q = (unsigned char*)(dst + H);
+#pragma unroll
+        for (int i = 0; i < NORM_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                const float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+                unsigned short hb[4];
+                float r[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { hb[j] = Op<OT>::from_f32(o[j]); r[j] = ldexpf(o[j] - Op<OT>::to_f32(hb[j]), 127 - E); }
+                *(uint2*)(dst + 4 * c) = make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
+                int pk = 0;
+                pk = __builtin_amdgcn_cvt_pk_fp8_f32(r[0], r[1], pk, false);
+                pk = __builtin_amdgcn_cvt_pk_fp8_f32(r[2], r[3], pk, true);
+                *(unsigned*)(q + 4 * c) = (unsigned)pk;
+            }
         }
     }
 }
 
 void launch_norm_rows(const float* x, const float* w, const float* b, void* y, int rows, int H, float eps,
-                      int operand_dtype, hipStream_t st, int prec, int group) {
+                      int operand_dtype, hipStream_t st, int prec, int group, int* lo8) {
     if (rows <= 0) return;
     if (group < 1 || rows % group) throw std::runtime_error("norm_rows: rows must be a multiple of group");
+    if (lo8 && (!prec || group != 1)) throw std::runtime_error("norm_rows: the e4m3 residual form needs split-operand rows, group 1");
     if (H % 4 || H > NORM_MAXC * 256) throw std::runtime_error("norm_rows: H must be a multiple of 4 and <= 4096");
     dim3 g(cdiv(rows, 4)), t(256);
     const bool f16 = operand_dtype == DT_F16;
     if (b) {
-        if (f16) hipLaunchKernelGGL((norm_rows_kernel<F16, true>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group);
-        else hipLaunchKernelGGL((norm_rows_kernel<BF16, true>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group);
+        if (f16) hipLaunchKernelGGL((norm_rows_kernel<F16, true>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group, lo8);
+        else hipLaunchKernelGGL((norm_rows_kernel<BF16, true>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group, lo8);
     } else {
-        if (f16) hipLaunchKernelGGL((norm_rows_kernel<F16, false>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group);
-        else hipLaunchKernelGGL((norm_rows_kernel<BF16, false>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group);
+        if (f16) hipLaunchKernelGGL((norm_rows_kernel<F16, false>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group, lo8);
+        else hipLaunchKernelGGL((norm_rows_kernel<BF16, false>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group, lo8);
     }
 }
 
@@ -871,10 +911,6 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const unsigned s
 }
 
 // ---- split-operand mode, e4m3 residual pass: power-of-two scaled e4m3 with the scale in E8M0 form ----
-__device__ __forceinline__ int e8m0_of_amax(float amax) {      // 2^(E-127) puts amax into [128, 256) <= 448; E = 127 for a zero row
-    return amax > 0.f ? 127 + (ilogbf(amax) - 7) : 127;
-}
-
 // Rows [hi x K | lo x K] of 2-byte elements: the residual half is rewritten IN PLACE as K e4m3 bytes (the first half of its own
 // space) + one E8M0 exponent per row.  One wave per row, two sweeps (row maximum, then convert); a sweep step reads bytes
 // [1024 t, 1024 t + 1024) of the residual half and writes [512 t, 512 t + 512): only bytes that were already consumed.
