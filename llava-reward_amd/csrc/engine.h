@@ -279,6 +279,33 @@ inline bool lo8_eligible(const lr_engine* e, const GemmParams& p) {      // p af
     const bool aligned = p.N % 8 == 0 && p.ldc % 8 == 0 && (((uintptr_t)p.C) & 15) == 0 && (!p.bias || (((uintptr_t)p.bias) & 15) == 0);
     return aligned && p.kw % 128 == 0 && p.ldw == p.kw && (e->gemm_tile < 0 || e->gemm_tile == 6);
 }
+// e4m3 twin(s) of weight W [N, K] in the rows of its residual buffer; synchronous.  lr_finalize calls it for every GEMM weight it
+// knows (prepare_twins below), the launch path only as a fallback (weights re-uploaded after lr_finalize).
+inline void ensure_lo8_twin(lr_engine* e, const void* W, int N, int K, int ldw, hipStream_t st) {
+    if (e->w8exp.count(W)) return;
+    auto it = e->wbuf_of.find(W);
+    if (it == e->wbuf_of.end()) return;
+    char* twin = e->wbufs[it->second].lo;
+    const bool inexact = !e->inexact.empty() && e->inexact[it->second];
+    if (!e->amax_word) e->amax_word = (unsigned*)e->dalloc(256, false);
+    int E = 127, E2 = 127;
+    if (inexact) {
+        const size_t need = (size_t)N * ldw * 2;
+        if (need > e->w8tmp_cap) { e->w8tmp_cap = need; e->w8tmp = e->dalloc(need, false); }
+        prepare_weight_e4m3_pair(W, twin, ldw, K, N, e->w8tmp, e->op_dt, e->amax_word, st, &E, &E2);
+    } else {
+        E = prepare_weight_e4m3(W, ldw, K, N, twin, e->op_dt, e->amax_word, st);
+    }
+    e->w8exp[W] = E;
+    e->w8exp2[W] = E2;
+}
+inline void ensure_aexp(lr_engine* e, size_t rows) {
+    if (rows > e->aexp_cap) {
+        e->aexp_cap = (rows + 4095) & ~(size_t)4095;
+        e->aexp = (int*)e->dalloc(e->aexp_cap * 2 * 4, false);          // [residual rows | hi rows]
+    }
+}
+
 inline void upgrade_lo8(lr_engine* e, GemmParams& p, hipStream_t st) {
     if (p.aexp) return;
     if (lo8_eligible(e, p)) {
@@ -287,24 +314,9 @@ inline void upgrade_lo8(lr_engine* e, GemmParams& p, hipStream_t st) {
         const bool inexact = p.Wlo != nullptr;
         auto it = e->wbuf_of.find(p.W);
         char* twin = e->wbufs[it->second].lo;
+        ensure_lo8_twin(e, p.W, p.N, p.kw, p.ldw, st);
         auto w8 = e->w8exp.find(p.W);
-        if (w8 == e->w8exp.end()) {
-            if (!e->amax_word) e->amax_word = (unsigned*)e->dalloc(256, false);
-            int E = 127, E2 = 127;
-            if (inexact) {
-                const size_t need = (size_t)p.N * p.ldw * 2;
-                if (need > e->w8tmp_cap) { e->w8tmp_cap = need; e->w8tmp = e->dalloc(need, false); }
-                prepare_weight_e4m3_pair(p.W, twin, p.ldw, p.kw, p.N, e->w8tmp, e->op_dt, e->amax_word, st, &E, &E2);
-            } else {
-                E = prepare_weight_e4m3(p.W, p.ldw, p.kw, p.N, twin, e->op_dt, e->amax_word, st);
-            }
-            w8 = e->w8exp.emplace(p.W, E).first;
-            e->w8exp2[p.W] = E2;
-        }
-        if ((size_t)p.M > e->aexp_cap) {
-            e->aexp_cap = ((size_t)p.M + 4095) & ~(size_t)4095;
-            e->aexp = (int*)e->dalloc(e->aexp_cap * 2 * 4, false);          // [residual rows | hi rows]
-        }
+        ensure_aexp(e, (size_t)p.M);
         int* aexp2 = inexact ? e->aexp + e->aexp_cap : nullptr;
         if (e->pre_enc == p.A && !inexact) e->pre_enc = nullptr;          // the producer (a norm kernel) wrote [hi | e4m3(lo)] and e->aexp itself
         else launch_quantize_lo_inplace(const_cast<void*>(p.A), p.lda, p.kw, p.M, e->aexp, e->op_dt, st, aexp2);
@@ -329,10 +341,7 @@ inline int* lo8_norm_target(lr_engine* e, GemmParams probe) {
     if (!e->lo8) return nullptr;
     apply_prec_base(e, probe);
     if (!lo8_eligible(e, probe) || probe.Wlo) return nullptr;
-    if ((size_t)probe.M > e->aexp_cap) {
-        e->aexp_cap = ((size_t)probe.M + 4095) & ~(size_t)4095;
-        e->aexp = (int*)e->dalloc(e->aexp_cap * 2 * 4, false);
-    }
+    ensure_aexp(e, (size_t)probe.M);
     e->pre_enc = probe.A;
     return e->aexp;
 }
@@ -348,17 +357,35 @@ inline bool w8a8_eligible(const lr_engine* e, const GemmParams& p) {
     const bool aligned = p.N % 8 == 0 && p.ldc % 8 == 0 && (((uintptr_t)p.C) & 15) == 0 && (!p.bias || (((uintptr_t)p.bias) & 15) == 0);
     return e->w8a8 && aligned && p.K % 128 == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 && (e->gemm_tile < 0 || e->gemm_tile == 6);
 }
+inline void ensure_w8a8_twin(lr_engine* e, const void* W, int N, int K, int ldw, hipStream_t st) {
+    if (e->w8.count(W)) return;
+    lr_engine::W8 t{e->dalloc((size_t)N * K, true), (float*)e->dalloc((size_t)N * 4, true)};
+    launch_quantize_rows_fp8(W, ldw, K, N, t.q, K, t.scale, e->op_dt, st);
+    e->w8.emplace(W, t);
+}
+inline void ensure_q8(lr_engine* e, size_t rows, size_t K) {
+    const size_t need = rows * K;
+    if (need > e->q8_cap) { e->q8_cap = (need + (1u << 20)) & ~(size_t)((1u << 20) - 1); e->q8 = e->dalloc(e->q8_cap, false); }
+    if (rows > e->q8s_cap) { e->q8s_cap = (rows + 4095) & ~(size_t)4095; e->q8s = (float*)e->dalloc(e->q8s_cap * 4, false); }
+}
+// lr_finalize: twins of every GEMM weight {W, N, K} with K % 128 == 0 and scratch for `rows` operand rows, so that no forward has to
+// synchronise or allocate (weights re-uploaded afterwards fall back to preparation at their first launch).
+struct GemmWeight { const void* W; int N, K; size_t rows; };
+inline void prepare_twins(lr_engine* e, const std::vector<GemmWeight>& ws) {
+    if (!e->lo8 && !e->w8a8) return;
+    for (const GemmWeight& g : ws) {
+        if (!g.W || g.K % 128) continue;
+        if (e->lo8) { ensure_lo8_twin(e, g.W, g.N, g.K, g.K, 0); ensure_aexp(e, g.rows); }
+        else { ensure_w8a8_twin(e, g.W, g.N, g.K, g.K, 0); ensure_q8(e, g.rows, (size_t)g.K); }
+    }
+    LR_HIP_CHECK(hipStreamSynchronize(0));
+}
+
 inline bool launch_w8a8(lr_engine* e, GemmParams p, hipStream_t st) {
     if (!w8a8_eligible(e, p)) return false;
+    ensure_w8a8_twin(e, p.W, p.N, p.K, p.ldw, st);
     auto it = e->w8.find(p.W);
-    if (it == e->w8.end()) {
-        lr_engine::W8 t{e->dalloc((size_t)p.N * p.K, true), (float*)e->dalloc((size_t)p.N * 4, true)};
-        launch_quantize_rows_fp8(p.W, p.ldw, p.K, p.N, t.q, p.K, t.scale, e->op_dt, st);
-        it = e->w8.emplace(p.W, t).first;
-    }
-    const size_t need = (size_t)p.M * p.K;
-    if (need > e->q8_cap) { e->q8_cap = (need + (1u << 20)) & ~(size_t)((1u << 20) - 1); e->q8 = e->dalloc(e->q8_cap, false); }
-    if ((size_t)p.M > e->q8s_cap) { e->q8s_cap = ((size_t)p.M + 4095) & ~(size_t)4095; e->q8s = (float*)e->dalloc(e->q8s_cap * 4, false); }
+    ensure_q8(e, (size_t)p.M, (size_t)p.K);
     launch_quantize_rows_fp8(p.A, p.lda, p.K, p.M, e->q8, p.K, e->q8s, e->op_dt, st);
     p.A = e->q8; p.W = it->second.q; p.lda = p.K; p.ldw = p.K;
     p.ascale = e->q8s; p.wscale = it->second.scale;

@@ -412,6 +412,21 @@ int lr_finalize(lr_handle h) {
         h->tab_dev = (char*)W(h->tab_bytes * lr_engine::NSLOT);
         for (int i = 0; i < lr_engine::NSLOT; ++i) LR_HIP_CHECK(hipEventCreateWithFlags(&h->tab_ev[i], hipEventDisableTiming));
         LR_HIP_CHECK(hipMemset(h->tstat, 0, B * 16));
+        {   // e4m3 twins of the GEMM weights (default parity mode / W8A8 mode)
+            std::vector<GemmWeight> ws;
+            ws.push_back({h->patch_w, (int)Hc, h->Kpad, Rp});
+            for (const ClipLayer& c : h->cl) {
+                ws.push_back({c.qkv_w, (int)(3 * Hc), (int)Hc, Rc}); ws.push_back({c.out_w, (int)Hc, (int)Hc, Rc});
+                ws.push_back({c.fc1_w, (int)Mc, (int)Hc, Rc}); ws.push_back({c.fc2_w, (int)Hc, (int)Mc, Rc});
+            }
+            if (h->llava) { ws.push_back({h->p0_w, (int)D, (int)Hc, Rp}); ws.push_back({h->p2_w, (int)D, (int)D, Rp}); }
+            else { ws.push_back({h->p0_w, (int)D, (int)(4 * Hc), SV}); ws.push_back({h->p2_w, (int)D, (int)D, SV}); }
+            for (const DecLayer& L : h->dl) {
+                ws.push_back({L.qkv_w, h->Nqkv, (int)D, Rl}); ws.push_back({L.o_w, (int)D, h->Hq, Rl});
+                ws.push_back({L.gu_w, (int)(2 * I), (int)D, Rl}); ws.push_back({L.down_w, (int)D, (int)I, Rl});
+            }
+            prepare_twins(h, ws);
+        }
         h->finalized = true;
     });
 }

@@ -186,6 +186,21 @@ void finalize_qwen(lr_engine* h) {
     LR_HIP_CHECK(hipHostMalloc((void**)&h->tab_host, h->tab_bytes * lr_engine::NSLOT));
     h->tab_dev = (char*)W(h->tab_bytes * lr_engine::NSLOT);
     for (int i = 0; i < lr_engine::NSLOT; ++i) LR_HIP_CHECK(hipEventCreateWithFlags(&h->tab_ev[i], hipEventDisableTiming));
+    {   // e4m3 twins of the GEMM weights (default parity mode / W8A8 mode)
+        std::vector<GemmWeight> ws;
+        const int vH = h->vH, vHp = h->vHp, vIp = h->vIp, vHm = h->vHm;
+        ws.push_back({h->vpatch_w, vH, h->vKpad, Rv});
+        for (const VitLayer& L : h->vl) {
+            ws.push_back({L.qkv_w, 3 * vHp, vH, Rv}); ws.push_back({L.proj_w, vH, vHp, Rv});
+            ws.push_back({L.gu_w, 2 * vIp, vH, Rv}); ws.push_back({L.down_w, vH, vIp, Rv});
+        }
+        ws.push_back({h->m0_w, vHm, vHm, Rm}); ws.push_back({h->m2_w, (int)D, vHm, Rm});
+        for (const DecLayer& L : h->dl) {
+            ws.push_back({L.qkv_w, h->Nqkv, (int)D, Rl}); ws.push_back({L.o_w, (int)D, h->Hq, Rl});
+            ws.push_back({L.gu_w, (int)(2 * I), (int)D, Rl}); ws.push_back({L.down_w, (int)D, (int)I, Rl});
+        }
+        prepare_twins(h, ws);
+    }
     LR_HIP_CHECK(hipMemset(h->tstat, 0, B * 16));
     LR_HIP_CHECK(hipMemset(h->rstat, 0, B * 16));
     LR_HIP_CHECK(hipMemset(h->pos_ids, 0, Rl * 4));
