@@ -345,8 +345,20 @@ int lr_upload_weight(lr_handle h, const char* name, const void* data, const int6
             launch_cvt_to_f32(dev_src, dtype == LR_DT_F16 ? DT_F16 : DT_BF16, h->stage_f32, n, 0);
             f32 = h->stage_f32;
         }
+        if (s.wid >= 0 && s.lo_dst) {          // split-operand mode: this tensor's buffer has a residual twin
+            const lr_engine::WBuf& wb = h->wbufs[s.wid];
+            if (h->w8exp.count(wb.hi)) {       // ... which now holds e4m3 data (default parity mode, after lr_finalize)
+                const bool whole = (size_t)s.rows * s.ld_dst * 2 == wb.bytes && s.dst == wb.hi;
+                const bool was_inexact = !h->inexact.empty() && h->inexact[s.wid];
+                if (!whole && was_inexact)
+                    throw std::logic_error(std::string("lr_upload_weight: ") + name + " shares a buffer whose 16-bit residuals have been "
+                                           "converted to e4m3; create a new handle to replace part of an inexact weight group");
+                if (!whole) LR_HIP_CHECK(hipMemset(wb.lo, 0, wb.bytes));      // the other tensors of the group were exact: residuals 0
+                h->w8exp.erase(wb.hi); h->w8exp2.erase(wb.hi);
+            }
+        }
         pack_slot(h, s, f32);
-        h->w8exp.clear(); h->w8exp2.clear(); h->w8.clear();          // the e4m3 twins live in the residual buffers pack_slot has just rewritten
+        h->w8.clear();             // W8A8 twins are separate buffers, rebuilt from the packed weights at the next launch
         LR_HIP_CHECK(hipStreamSynchronize(0));
         if (h->finalized && h->inexact_dev)      // a re-upload after lr_finalize may have made a buffer inexact
             LR_HIP_CHECK(hipMemcpy(h->inexact.data(), h->inexact_dev, h->wbufs.size() * sizeof(int), hipMemcpyDeviceToHost));

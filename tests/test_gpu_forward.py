@@ -367,3 +367,33 @@ def test_w8a8_mode_against_quantisation_aware_oracle(backbone):
         print(f"[w8a8 {backbone}] CLIP tower: |hip - emulation| = {d_hip:.2e}   |fp32 - emulation| = {d_q:.2e}")
         assert d_hip < 0.25 * d_q                               # the engine reproduces the quantised tower, not merely something e4m3-ish
     assert torch.equal(got, hip("fp8")[0])                        # deterministic, twins rebuilt identically
+
+
+@pytest.mark.parametrize("dtype", ["f16x2f8", "fp8"])
+def test_weight_reupload_after_finalize_rebuilds_e4m3_twins(dtype):
+    """The e4m3 twins of the GEMM weights are built at lr_finalize; a weight uploaded afterwards must get a fresh twin (and, if it is
+    no longer bf16-valued, the third-segment form) at its next launch."""
+    cfg = synth.tiny_config()
+    seed = 29
+    batch = synth.synth_batch(cfg, seed, [6, 4], [(1, 1), (1, 2)], max_crops=4)
+    Wn = synth.make_weights(cfg, seed)
+    m = _model(cfg, seed, dtype, upload=True)
+    m.engine.set_gemm_tile(6)
+    r0 = _fwd(m, batch)
+    name = "model.layers.1.mlp.down_proj.weight"
+    g = torch.Generator().manual_seed(1)
+    w = torch.from_numpy(Wn[name])
+    m.engine.upload(name, (w * (1.0 + 0.05 * torch.randn(w.shape, generator=g))).float())       # fp32-valued: inexact in f16
+    r1 = _fwd(m, batch)
+    assert (r1 - r0).abs().max().item() > 1e-4                                                   # the new weight is in effect
+    if dtype == "f16x2f8":                                                                       # and it is computed to parity
+        W2 = orc.weights_to_torch(Wn)
+        W2[name] = (w * (1.0 + 0.05 * torch.randn(w.shape, generator=torch.Generator().manual_seed(1)))).float()
+        ref = orc.custom_forward(W2, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"])
+        assert (r1 - ref).abs().max().item() < TOL_X8
+    m.engine.upload(name, w)
+    r2 = _fwd(m, batch)
+    if dtype == "fp8":
+        assert torch.equal(r2, r0)
+    else:       # the buffer stays flagged inexact (conservative): same value to parity, not necessarily to the bit
+        assert (r2 - r0).abs().max().item() < TOL_X8
