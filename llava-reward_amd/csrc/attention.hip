@@ -339,8 +339,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
                 }
                 __syncthreads();
                 // ---- matrix segment ----
+                __builtin_amdgcn_s_setprio(1);            // the wave in its matrix segment goes first (2-4 % on every shape)
                 if (act(t)) pv(t);
                 if (t + 1 < ntiles && act(t + 1)) qk(t + 1);
+                __builtin_amdgcn_s_setprio(0);
                 if (PREC && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (t + 1 < ntiles || grp == 0) __syncthreads();
             }
