@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LR_ABI_VERSION 5
+#define LR_ABI_VERSION 6
 
 enum { LR_OK = 0, LR_EINVAL = 1, LR_EHIP = 2, LR_ESTATE = 3, LR_ENOTFOUND = 4, LR_ENOMEM = 5 };
 enum { LR_DT_BF16 = 0, LR_DT_F16 = 1, LR_DT_F32 = 2 };
@@ -103,6 +103,14 @@ typedef struct lr_model_desc {
      * v_mfma_scale_f32_16x16x128_f8f6f4 (1.9x the f16 GEMM rate).  Attention, norms and the fp32 tail are unchanged.  Rewards move
      * by ~1e-2: NOT a parity mode. */
     int32_t w8a8;
+    /* ABI 6.  Un-merged LoRA adapter on the decoder linears, rank `lora_rank` (0 = none).  The reference loads its adapter
+     * un-merged (eval/reward_adaptor_loader.py:44-45, targets llava_reward/utils/utils.py:194-262: qkv_proj / o_proj /
+     * gate_up_proj / down_proj for Phi-3-V, q/k/v/o/gate/up/down_proj for LLaVA and Qwen) and peft evaluates
+     * y = W x + (lora_alpha / r) B (A x).  Here every such linear gets two more weight tensors, `<module>.lora_A.weight` [r, in]
+     * and `<module>.lora_B.weight` [out, r], the latter uploaded PRE-SCALED by lora_alpha / r; t = x A^T is a small GEMM and
+     * t B^T rides in the K loop of the base GEMM (r rounded up to 64 extra columns), so the base weights stay bf16-exact and
+     * the layer costs ~6 % more instead of the 33-50 % of merged (inexact) weights.  Not available with w8a8. */
+    int32_t lora_rank;
 } lr_model_desc;
 
 int lr_abi_version(void);
@@ -130,7 +138,11 @@ size_t lr_workspace_bytes(lr_handle h);
 
 /* One scoring pass.  input_ids/attention_mask: device int64 [B,S] (image slots are negative ids);
  * pixel_values: device [B, n_crops, 3, img, img] of pix_dtype (F32 or BF16); image_sizes: HOST int64
- * [B,2] = HD-transformed (h, w) for Phi-3-V, ORIGINAL (h, w) for LLaVA; rewards_out: device fp32 [B, value_head_dim]. */
+ * [B,2] = HD-transformed (h, w) for Phi-3-V, ORIGINAL (h, w) for LLaVA; rewards_out: device fp32 [B, value_head_dim].
+ * Every row must hold exactly as many image slots as its image_sizes produce image tokens (the reference fails such a batch,
+ * modeling_phi3_v.py:247).  The call cannot know without synchronising, so it never reads out of bounds (surplus slots keep
+ * their text embedding) and returns NaN rewards for a row whose counts differ; callers that want the reference's exception
+ * compare the counts on the host first, as the Python wrapper does. */
 int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_mask, const void* pixel_values,
                int pix_dtype, const int64_t* image_sizes_host, int B, int S, int n_crops, int flags, float* rewards_out,
                void* hip_stream);
@@ -161,6 +173,11 @@ int lr_op_gemm_bt(const void* A, const void* W, void* C, const float* bias, int 
  * outputs (EPI_OUT_OP, EPI_SWIGLU_OP) come back as [C_hi | C_lo], twice as wide; fp32 outputs are unchanged. */
 int lr_op_gemm_bt_split(const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int epi, int act,
                         int operand_dtype, int tile, void* hip_stream);
+/* K-extension (an un-merged LoRA adapter inside the base GEMM, lr_model_desc.lora_rank): C = epi(A W^T + T B^T), W [N, K], B [N, k2]
+ * (Blo: its rounding residuals when B is not exact in the operand type, else NULL), k2 % 64 == 0.  split = 0: A [M, K], T [M, k2];
+ * split = 1: A [M, 2K] = [hi | lo], T [M, 2 k2] = [hi | lo], operand-typed outputs [C_hi | C_lo].  Deep-pipelined kernel only. */
+int lr_op_gemm_bt_ext(const void* A, const void* W, const void* T, const void* B, const void* Blo, void* C, const float* bias, int M,
+                      int N, int K, int k2, int split, int epi, int act, int operand_dtype, void* hip_stream);
 /* QKV projection with the fused RoPE epilogue: C_op[m][n] = rotate(A W^T) for n < rope_cols, pairs (2i, 2i+1) of each
  * rope_hd-wide head rotated by cs[m][i] = (cos, sin); weight rows must already be pair-interleaved. */
 int lr_op_gemm_rope(const void* A, const void* W, void* C, const float* bias, const float* cs, int M, int N, int K,

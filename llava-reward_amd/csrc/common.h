@@ -123,6 +123,24 @@ struct GemmParams {
     // residual bytes) against e4m3(W_lo) (tensor exponent wexp2, bytes behind W8 in the same rows); K = 2 kw
     const int* aexp2;
     int wexp2;
+    // K-extension (an un-merged LoRA adapter): y = x W^T + t B^T with t = s x A^T computed by a GEMM of its own.
+    // A2 = t rows [M, lda2] = [t_hi (k2) | t_lo (k2)] in split-operand mode, [t (k2)] otherwise; W2 = B [N, ldw2] (k2 columns used),
+    // W2lo = its rounding residuals when B is not exact in the operand type (else null).  k2 % 64 == 0.  All 16-bit segments.
+    const void* A2;
+    const void* W2;
+    const void* W2lo;
+    int lda2, ldw2, k2;
+    // e4m3-residual form only: 16-bit residual rows of W for an f16 segment x_hi x W_lo^T (weights inexact in the operand type whose
+    // e4m3 twin lives in a buffer of its own: the adapter's A matrix), instead of the e4m3 third segment
+    const void* Wlo16;
+    // ---- filled by the launchers of gemm8.hip (build_segments), not by callers: the K loop as a list of segments ----
+    // A K-tile (64 two-byte units of a row) of segment s comes from A (or A2) at column a_col + 64 i and from W / Wlo / Wlo16 / W2 /
+    // W2lo at column w_col + 64 i.  Segments are ordered 16-bit first (K-tiles [0, nk_f16)), then the e4m3 residual tiles
+    // [nk_f16, nk_e1) scaled by aexp / wexp, then the e4m3 tiles [nk_e1, nk) scaled by aexp2 / wexp2.
+    struct KSeg { int kt_end, src, a_col, w_col; };
+    enum : int { SRC_A2 = 1, SRC_W2 = 2, SRC_LO = 4, SRC_LO16 = 8, MAX_SEG = 8 };
+    int nseg, nk_f16, nk_e1, nk;
+    KSeg seg[MAX_SEG];
 };
 
 struct AttnParams {

@@ -49,10 +49,21 @@ struct ClipLayer {
     void *qkv_w, *out_w, *fc1_w, *fc2_w;
     float *qkv_b, *out_b, *fc1_b, *fc2_b, *ln1_w, *ln1_b, *ln2_w, *ln2_b;
 };
+// Un-merged LoRA adapter of one (fused) linear y = x W^T (peft 0.13.2 tuners/lora/layer.py Linear.forward: result + lora_B(lora_A(x)) *
+// scaling; the reference loads the adapter un-merged, eval/reward_adaptor_loader.py:44-45): t = x A^T is a GEMM of its own and
+// y += t B^T rides in the K loop of the main GEMM as k2 extra columns (GemmParams::A2 / W2).  The scaling alpha / r is folded
+// into B at upload.  A fused linear whose parts carry separate adapters (q/k/v, gate/up) stacks their A matrices (k2 = parts x
+// padded rank) and holds B block-diagonally.
+struct Lora {
+    void* A = nullptr;         // [k2, K] operand dtype
+    void* B = nullptr;         // [N, k2] operand dtype, rows packed like the base weight's
+    int k2 = 0;                // 0 = no adapter
+};
 struct DecLayer {
     void *qkv_w, *o_w, *gu_w, *down_w;
     float *ln1, *ln2;
     float* qkv_b = nullptr;    // Qwen2.5-VL: q/k/v bias, packed like the rows of qkv_w
+    Lora lqkv, lo, lgu, ldown;
 };
 struct VitLayer {              // Qwen2_5_VLVisionBlock
     void *qkv_w, *proj_w, *gu_w, *down_w;
@@ -89,6 +100,10 @@ struct lr_engine {
     std::unordered_map<const void*, int> w8exp2;     // ... and of e4m3(W_lo) for weights that are inexact in the operand type
     void* w8tmp = nullptr; size_t w8tmp_cap = 0;
     const void* pre_enc = nullptr;                   // operand buffer whose residual half its producer has already written in e4m3
+    bool pre_enc_hi8 = false;                        // ... together with the e4m3 copy of its hi half (third e4m3 segment)
+    std::unordered_map<const void*, void*> own8;     // adapter A matrices: weight base pointer -> its e4m3 twin in a buffer of its own
+    int lora_rp = 0, lora_k2max = 0;                 // adapter rank padded to a K-tile (64); widest K-extension of any linear
+    void* lt = nullptr;                              // t = x A^T of the linear being launched, [rows, k2 (x2 in split-operand mode)]
     int w8a8 = 0;              // W8A8 mode (desc.w8a8): e4m3 GEMM operands with per-row / per-channel fp32 scales
     struct W8 { void* q; float* scale; };
     std::unordered_map<const void*, W8> w8;          // weight base pointer -> its e4m3 twin (prepared on first use)
@@ -289,7 +304,10 @@ inline void ensure_lo8_twin(lr_engine* e, const void* W, int N, int K, int ldw, 
     const bool inexact = !e->inexact.empty() && e->inexact[it->second];
     if (!e->amax_word) e->amax_word = (unsigned*)e->dalloc(256, false);
     int E = 127, E2 = 127;
-    if (inexact) {
+    auto own = e->own8.find(W);
+    if (own != e->own8.end()) {          // adapter matrix: e4m3(W) in its own buffer, the 16-bit residuals stay where they are
+        E = prepare_weight_e4m3(W, ldw, K, N, own->second, e->op_dt, e->amax_word, st);
+    } else if (inexact) {
         const size_t need = (size_t)N * ldw * 2;
         if (need > e->w8tmp_cap) { e->w8tmp_cap = need; e->w8tmp = e->dalloc(need, false); }
         prepare_weight_e4m3_pair(W, twin, ldw, K, N, e->w8tmp, e->op_dt, e->amax_word, st, &E, &E2);
@@ -306,27 +324,37 @@ inline void ensure_aexp(lr_engine* e, size_t rows) {
     }
 }
 
-inline void upgrade_lo8(lr_engine* e, GemmParams& p, hipStream_t st) {
+// keep_enc: another GEMM reads the same operand buffer next (the main GEMM behind an adapter's t GEMM): leave the "already encoded"
+// mark on it.  force_hi8: that next GEMM needs the e4m3 copy of the hi half as well, so the one in-place encoding pass writes it now.
+inline void upgrade_lo8(lr_engine* e, GemmParams& p, hipStream_t st, bool keep_enc = false, bool force_hi8 = false) {
     if (p.aexp) return;
     if (lo8_eligible(e, p)) {
         // Weights inexact in the operand type (Wlo set by apply_prec_base: a merged LoRA adapter, fp32-trained weights): a third
         // e4m3 segment, A_hi8 x e4m3(W_lo)^T, replaces the 16-bit [x_hi] x [W_lo] segment (2x instead of 3x the single pass).
+        // Adapter matrices (own8) keep the 16-bit third segment: their e4m3 twin lives in a buffer of its own.
         const bool inexact = p.Wlo != nullptr;
+        auto own = e->own8.find(p.W);
+        const bool third8 = inexact && own == e->own8.end();
+        const bool hi8 = third8 || force_hi8;
         auto it = e->wbuf_of.find(p.W);
-        char* twin = e->wbufs[it->second].lo;
+        char* lo_rows = e->wbufs[it->second].lo;
         ensure_lo8_twin(e, p.W, p.N, p.kw, p.ldw, st);
         auto w8 = e->w8exp.find(p.W);
         ensure_aexp(e, (size_t)p.M);
-        int* aexp2 = inexact ? e->aexp + e->aexp_cap : nullptr;
-        if (e->pre_enc == p.A && !inexact) e->pre_enc = nullptr;          // the producer (a norm kernel) wrote [hi | e4m3(lo)] and e->aexp itself
-        else launch_quantize_lo_inplace(const_cast<void*>(p.A), p.lda, p.kw, p.M, e->aexp, e->op_dt, st, aexp2);
-        p.K = inexact ? 2 * p.kw : p.kw + p.kw / 2;
-        p.Wlo = twin;
+        int* aexp2 = e->aexp + e->aexp_cap;
+        if (!(e->pre_enc == p.A && (!hi8 || e->pre_enc_hi8))) {
+            if (e->pre_enc == p.A) throw std::logic_error("operand buffer already carries e4m3 residuals without the e4m3 copy of its hi half");
+            launch_quantize_lo_inplace(const_cast<void*>(p.A), p.lda, p.kw, p.M, e->aexp, e->op_dt, st, hi8 ? aexp2 : nullptr);
+            e->pre_enc_hi8 = hi8;
+        }
+        e->pre_enc = keep_enc ? p.A : nullptr;      // (a norm kernel may have written [hi | e4m3(lo)] and e->aexp itself: lo8_norm_target)
+        if (own != e->own8.end()) { p.Wlo16 = inexact ? lo_rows : nullptr; p.Wlo = own->second; }
+        else p.Wlo = lo_rows;
         p.aexp = e->aexp;
         p.wexp = w8->second;
-        p.aexp2 = aexp2;
+        p.aexp2 = third8 ? aexp2 : nullptr;
         p.wexp2 = e->w8exp2[p.W];
-    } else if (e->lo8 && p.Wlo && e->w8exp.count(p.W)) {
+    } else if (e->lo8 && p.Wlo && e->w8exp.count(p.W) && !e->own8.count(p.W)) {
         throw std::runtime_error("this weight's residual twin has been converted to e4m3; re-upload the weights before changing the GEMM tile");
     }
 }
@@ -343,6 +371,7 @@ inline int* lo8_norm_target(lr_engine* e, GemmParams probe) {
     if (!lo8_eligible(e, probe) || probe.Wlo) return nullptr;
     ensure_aexp(e, (size_t)probe.M);
     e->pre_enc = probe.A;
+    e->pre_enc_hi8 = false;
     return e->aexp;
 }
 inline void apply_prec(const lr_engine* e, AttnParams& p) {
@@ -393,12 +422,52 @@ inline bool launch_w8a8(lr_engine* e, GemmParams p, hipStream_t st) {
     return true;
 }
 
-inline void gemm(lr_engine* e, hipStream_t st, const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int lda,
-          int ldw, int ldc, int epi, int act) {
-    GemmParams p{A, W, C, bias, M, N, K, lda, ldw, ldc, epi, act, nullptr, 0, 0};
+// One linear layer, p in LOGICAL shapes (as gemm() takes them).  With an adapter L: t = x A^T first (always on the deep-pipelined
+// kernel, in the same operand form as the main GEMM -- they read the same rows of x), then the main GEMM with the K-extension.
+inline void gemm_p(lr_engine* e, hipStream_t st, GemmParams p, const Lora* L = nullptr) {
+    if (L && L->k2 > 0) {
+        if (e->w8a8) throw std::logic_error("W8A8 mode runs merged weights only (no un-merged adapters)");
+        GemmParams probe = p;
+        apply_prec_base(e, probe);
+        GemmParams t{p.A, L->A, e->lt, nullptr, p.M, L->k2, p.K, p.lda, p.K, L->k2, EPI_OUT_OP, ACT_NONE, nullptr, 0, 0};
+        apply_prec_base(e, t);
+        const bool both8 = lo8_eligible(e, probe) && lo8_eligible(e, t);
+        if (e->pre_enc == p.A && !both8) throw std::logic_error("operand pre-encoded in e4m3 for a GEMM that takes the 16-bit form");
+        if (both8) upgrade_lo8(e, t, st, true, probe.Wlo != nullptr);
+        launch_gemm_bt(t, e->op_dt, 6, st);
+        p.A2 = e->lt; p.lda2 = L->k2 * (1 + e->prec); p.W2 = L->B; p.ldw2 = L->k2; p.k2 = L->k2;
+        auto it = e->wbuf_of.find(L->B);
+        if (it != e->wbuf_of.end() && !e->inexact.empty() && e->inexact[it->second]) p.W2lo = e->wbufs[it->second].lo;
+        apply_prec_base(e, p);
+        if (both8) upgrade_lo8(e, p, st);
+        launch_gemm_bt(p, e->op_dt, e->gemm_tile, st);
+        return;
+    }
     if (launch_w8a8(e, p, st)) return;
     apply_prec(e, p, st);
     launch_gemm_bt(p, e->op_dt, e->gemm_tile, st);
+}
+inline void gemm(lr_engine* e, hipStream_t st, const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int lda,
+          int ldw, int ldc, int epi, int act, const Lora* L = nullptr) {
+    gemm_p(e, st, GemmParams{A, W, C, bias, M, N, K, lda, ldw, ldc, epi, act, nullptr, 0, 0}, L);
+}
+
+// Adapter slots of one linear `mod` (checkpoint names mod.lora_A.weight [r, K], mod.lora_B.weight [n_rows, r]); part / parts: this
+// adapter's place among the stacked adapters of a fused linear; b_row0: first row of the fused weight this part owns (B is block
+// diagonal); pack_mode / aux_*: the row packing of the base weight's slot.  B must arrive pre-scaled by lora_alpha / r.
+inline void register_lora(lr_engine* e, Lora& L, const std::string& mod, int N_fused, int K, int part, int parts, int n_rows, int b_row0,
+                          int pack_mode, int aux_d = 0, int aux_hd = 0) {
+    const int r = e->d.lora_rank, rp = e->lora_rp, od = e->op_dt;
+    if (part == 0) {
+        L.k2 = parts * rp;
+        L.A = oalloc(e, (size_t)L.k2 * K);
+        L.B = oalloc(e, (size_t)N_fused * L.k2);
+        if (e->lo8) e->own8[L.A] = e->dalloc((size_t)L.k2 * K * 2, true);
+        e->lora_k2max = std::max(e->lora_k2max, L.k2);
+    }
+    add_slot(e, mod + ".lora_A.weight", {r, K}, (char*)L.A + (size_t)part * rp * K * 2, K, K, od, PACK_PLAIN, 0.02, 0);
+    add_slot(e, mod + ".lora_B.weight", {n_rows, r}, (char*)L.B + ((size_t)b_row0 * L.k2 + (size_t)part * rp) * 2, L.k2, r, od, pack_mode, 0.02, 0);
+    e->slots.back().aux_d = aux_d; e->slots.back().aux_hd = aux_hd;
 }
 
 

@@ -37,6 +37,12 @@ void build_weight_table_phi(lr_engine* e) {
         vec_slot(e, p + "post_attention_layernorm.weight", {D}, L.ln2, 0.05, 1.0);
         add_slot(e, p + "mlp.gate_up_proj.weight", {2 * I, D}, L.gu_w, D, D, od, PACK_SWIGLU, 0.02, 0);
         add_slot(e, p + "mlp.down_proj.weight", {D, I}, L.down_w, I, I, od, PACK_PLAIN, 0.02, 0);
+        if (d.lora_rank > 0) {      // utils/utils.py:194-222 create_lora_config: qkv_proj, o_proj, gate_up_proj, down_proj
+            register_lora(e, L.lqkv, p + "self_attn.qkv_proj", 3 * D, D, 0, 1, 3 * D, 0, PACK_ROPE_QKV, D, e->hd);
+            register_lora(e, L.lo, p + "self_attn.o_proj", D, D, 0, 1, D, 0, PACK_PLAIN);
+            register_lora(e, L.lgu, p + "mlp.gate_up_proj", 2 * I, D, 0, 1, 2 * I, 0, PACK_SWIGLU);
+            register_lora(e, L.ldown, p + "mlp.down_proj", D, I, 0, 1, D, 0, PACK_PLAIN);
+        }
     }
     e->norm_w = falloc(e, D);
     vec_slot(e, "model.norm.weight", {D}, e->norm_w, 0.05, 1.0);
@@ -90,6 +96,15 @@ void build_weight_table_llava(lr_engine* e) {
         add_slot(e, p + "mlp.gate_proj.weight", {I, D}, L.gu_w, D, D, od, PACK_SWIGLU_GATE, 0.02, 0);
         add_slot(e, p + "mlp.up_proj.weight", {I, D}, L.gu_w, D, D, od, PACK_SWIGLU_UP, 0.02, 0);
         add_slot(e, p + "mlp.down_proj.weight", {D, I}, L.down_w, I, I, od, PACK_PLAIN, 0.02, 0);
+        if (d.lora_rank > 0) {      // utils/utils.py:243-262 create_lora_config_llava16_vicuna: q, k, v, o, gate, up, down of every layer
+            register_lora(e, L.lqkv, p + "self_attn.q_proj", e->Nqkv, D, 0, 3, Hq, 0, PACK_ROPE_QKV, Hq, hd);
+            register_lora(e, L.lqkv, p + "self_attn.k_proj", e->Nqkv, D, 1, 3, Hkv, Hq, PACK_ROPE_QKV, Hkv, hd);
+            register_lora(e, L.lqkv, p + "self_attn.v_proj", e->Nqkv, D, 2, 3, Hkv, Hq + Hkv, PACK_PLAIN);
+            register_lora(e, L.lo, p + "self_attn.o_proj", D, Hq, 0, 1, D, 0, PACK_PLAIN);
+            register_lora(e, L.lgu, p + "mlp.gate_proj", 2 * I, D, 0, 2, I, 0, PACK_SWIGLU_GATE);
+            register_lora(e, L.lgu, p + "mlp.up_proj", 2 * I, D, 1, 2, I, 0, PACK_SWIGLU_UP);
+            register_lora(e, L.ldown, p + "mlp.down_proj", D, I, 0, 1, D, 0, PACK_PLAIN);
+        }
     }
     e->norm_w = falloc(e, D);
     vec_slot(e, "language_model.model.norm.weight", {D}, e->norm_w, 0.05, 1.0);
@@ -160,6 +175,8 @@ void validate_desc(const lr_model_desc& d) {
     if (d.w8a8 != 0 && d.w8a8 != 1) bad("w8a8 must be 0 or 1");
     if (d.w8a8 && (d.precise || d.operand_dtype != LR_DT_F16)) bad("w8a8 needs precise == 0 and F16 operands");
     if (d.layers < 0 || d.clip_layers < 0) bad("layer counts must be non-negative");
+    if (d.lora_rank < 0 || d.lora_rank > 1024) bad("lora_rank out of range");
+    if (d.lora_rank > 0 && d.w8a8) bad("w8a8 runs merged weights only: merge the adapter on the host (lora_rank = 0)");
 }
 
 }  // namespace
@@ -176,16 +193,14 @@ void run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_ma
         const DecLayer& L = h->dl[l];
         {   // qkv projection with RoPE on q,k: fused in the GEMM epilogue when the deep-pipelined kernel runs
             GemmParams gp{h->h, L.qkv_w, h->qkv, L.qkv_b, Rl, Nqkv, D, D, D, Nqkv, EPI_ROPE_OP, ACT_NONE, h->cs, Hq + Hkv, h->hd};
-            launch_norm_rows(h->x, L.ln1, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st, h->prec, 1,
-                             (Hq + Hkv) % 256 == 0 ? lo8_norm_target(h, gp) : nullptr);
-            apply_prec_base(h, gp);
-            if ((Hq + Hkv) % 256 == 0 && w8a8_eligible(h, gp)) {
-                launch_w8a8(h, gp, st);
-            } else if ((Hq + Hkv) % 256 == 0 && (lo8_eligible(h, gp) || gemm_bt_is_deep(gp, h->gemm_tile))) {
-                upgrade_lo8(h, gp, st);
-                launch_gemm_bt(gp, h->op_dt, h->gemm_tile, st);
+            const bool tiles_ok = (Hq + Hkv) % 256 == 0;
+            launch_norm_rows(h->x, L.ln1, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st, h->prec, 1, tiles_ok ? lo8_norm_target(h, gp) : nullptr);
+            GemmParams probe = gp;
+            apply_prec_base(h, probe);
+            if (tiles_ok && (L.lqkv.k2 > 0 || w8a8_eligible(h, probe) || lo8_eligible(h, probe) || gemm_bt_is_deep(probe, h->gemm_tile))) {
+                gemm_p(h, st, gp, &L.lqkv);
             } else {
-                gemm(h, st, h->h, L.qkv_w, h->qkv32, L.qkv_b, Rl, Nqkv, D, D, D, Nqkv, EPI_OUT_F32, ACT_NONE);
+                gemm(h, st, h->h, L.qkv_w, h->qkv32, L.qkv_b, Rl, Nqkv, D, D, D, Nqkv, EPI_OUT_F32, ACT_NONE, &L.lqkv);
                 launch_rope_split(h->qkv32, h->cs, h->qkv, Rl, Hq + Hkv, Hkv, h->hd, h->op_dt, st, h->prec);
             }
         }
@@ -193,11 +208,11 @@ void run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_ma
                       d.heads / d.kv_heads};
         apply_prec(h, ap);
         launch_attention(ap, B, h->hd, true, h->op_dt, st);
-        gemm(h, st, h->att, L.o_w, h->x, nullptr, Rl, D, Hq, Hq, Hq, D, EPI_RESADD_F32, ACT_NONE);
+        gemm(h, st, h->att, L.o_w, h->x, nullptr, Rl, D, Hq, Hq, Hq, D, EPI_RESADD_F32, ACT_NONE, &L.lo);
         launch_norm_rows(h->x, L.ln2, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st, h->prec, 1,
                          lo8_norm_target(h, GemmParams{h->h, L.gu_w, h->ff, nullptr, Rl, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE, nullptr, 0, 0}));
-        gemm(h, st, h->h, L.gu_w, h->ff, nullptr, Rl, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE);
-        gemm(h, st, h->ff, L.down_w, h->x, nullptr, Rl, D, I, I, I, D, EPI_RESADD_F32, ACT_NONE);
+        gemm(h, st, h->h, L.gu_w, h->ff, nullptr, Rl, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE, &L.lgu);
+        gemm(h, st, h->ff, L.down_w, h->x, nullptr, Rl, D, I, I, I, D, EPI_RESADD_F32, ACT_NONE, &L.ldown);
     }
 }
 
@@ -271,6 +286,7 @@ int lr_create(const lr_model_desc* desc, int device, lr_handle* out) {
         }
         e->hd = desc->head_dim;
         e->half = e->hd / 2;
+        e->lora_rp = (desc->lora_rank + 63) / 64 * 64;
         e->Hq = desc->heads * e->hd; e->Hkv = desc->kv_heads * e->hd; e->Nqkv = e->Hq + 2 * e->Hkv;
         if (e->qwen) {
             build_weight_table_qwen(e);
@@ -347,7 +363,9 @@ int lr_upload_weight(lr_handle h, const char* name, const void* data, const int6
         }
         if (s.wid >= 0 && s.lo_dst) {          // split-operand mode: this tensor's buffer has a residual twin
             const lr_engine::WBuf& wb = h->wbufs[s.wid];
-            if (h->w8exp.count(wb.hi)) {       // ... which now holds e4m3 data (default parity mode, after lr_finalize)
+            if (h->own8.count(wb.hi)) {        // adapter matrix: its e4m3 twin is a separate buffer, rebuilt at the next launch
+                h->w8exp.erase(wb.hi); h->w8exp2.erase(wb.hi);
+            } else if (h->w8exp.count(wb.hi)) {       // ... which now holds e4m3 data (default parity mode, after lr_finalize)
                 const bool whole = (size_t)s.rows * s.ld_dst * 2 == wb.bytes && s.dst == wb.hi;
                 const bool was_inexact = !h->inexact.empty() && h->inexact[s.wid];
                 if (!whole && was_inexact)
@@ -414,6 +432,7 @@ int lr_finalize(lr_handle h) {
         h->ev = (float*)W(SV * D * 4);
         h->x = (float*)W(Rl * D * 4); h->h = W(Rl * D * ob); h->qkv32 = (float*)W(Rl * h->Nqkv * 4); h->qkv = W(Rl * h->Nqkv * ob);
         h->att = W(Rl * h->Hq * ob); h->ff = W(Rl * I * ob); h->cs = (float*)W(Rl * h->hd * 4);
+        if (h->lora_k2max > 0) h->lt = W(Rl * (size_t)h->lora_k2max * ob);
         h->pos_ids = (int*)W(Rl * 4); h->img_row = (int*)W(Rl * 4); h->tstat = (int*)W(B * 16);
         h->hL = (float*)W(B * D * 4); h->tq = (float*)W(B * D * 4); h->tkq = (float*)W(B * D * 4);
         h->tsc = (float*)W(B * (size_t)h->Vcap * 4); h->tctx = (float*)W(B * D * 4); h->tao = (float*)W(B * D * 4);
@@ -436,6 +455,10 @@ int lr_finalize(lr_handle h) {
             for (const DecLayer& L : h->dl) {
                 ws.push_back({L.qkv_w, h->Nqkv, (int)D, Rl}); ws.push_back({L.o_w, (int)D, h->Hq, Rl});
                 ws.push_back({L.gu_w, (int)(2 * I), (int)D, Rl}); ws.push_back({L.down_w, (int)D, (int)I, Rl});
+                if (L.lqkv.k2) {
+                    ws.push_back({L.lqkv.A, L.lqkv.k2, (int)D, Rl}); ws.push_back({L.lo.A, L.lo.k2, h->Hq, Rl});
+                    ws.push_back({L.lgu.A, L.lgu.k2, (int)D, Rl}); ws.push_back({L.ldown.A, L.ldown.k2, (int)I, Rl});
+                }
             }
             prepare_twins(h, ws);
         }
@@ -574,6 +597,7 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
         run_decoder_stack(h, st, attention_mask, B, S);
         if (d.mean_hidden_state) {      // rw_model:398-406: SkipCA + norm on every token, masked mean, value head
             run_mean_pool_head(h, st, attention_mask, B, S, voff, Vmax, nullptr, !(flags & LR_FWD_NO_FINAL_NORM), rewards_out);
+            launch_slot_check(h->tstat, d_voff, rewards_out, B, d.value_head_dim, st);
             LR_HIP_CHECK(hipGetLastError());
             return;
         }
@@ -591,6 +615,7 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
             ao = h->tao;
         }
         launch_reward_head(h->hL, ao, h->ca_w, d.ca_eps, h->vh, d.value_head_dim, rewards_out, B, D, st);
+        launch_slot_check(h->tstat, d_voff, rewards_out, B, d.value_head_dim, st);
         LR_HIP_CHECK(hipGetLastError());
     });
 }
@@ -645,6 +670,18 @@ int lr_op_gemm_bt_split(const void* A, const void* W, void* C, const float* bias
         const bool op_out = epi == EPI_OUT_OP || epi == EPI_SWIGLU_OP;
         GemmParams p{A, W, C, bias, M, N, 2 * K, 2 * K, K, op_out ? 2 * nout : nout, epi, act, nullptr, 0, 0, K, op_out ? nout : 0};
         launch_gemm_bt(p, operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16, tile, (hipStream_t)hip_stream);
+    });
+}
+
+int lr_op_gemm_bt_ext(const void* A, const void* W, const void* T, const void* Bm, const void* Blo, void* C, const float* bias, int M,
+                      int N, int K, int k2, int split, int epi, int act, int operand_dtype, void* hip_stream) {
+    return op_guard([&] {
+        const int nout = epi == EPI_SWIGLU_OP ? N / 2 : N;
+        const bool op_out = epi == EPI_OUT_OP || epi == EPI_SWIGLU_OP;
+        GemmParams p{A, W, C, bias, M, N, K, K, K, nout, epi, act, nullptr, 0, 0};
+        if (split) { p.K = 2 * K; p.lda = 2 * K; p.kw = K; if (op_out) { p.ldc = 2 * nout; p.split = nout; } }
+        p.A2 = T; p.lda2 = (split ? 2 : 1) * k2; p.W2 = Bm; p.W2lo = Blo; p.ldw2 = k2; p.k2 = k2;
+        launch_gemm_bt(p, operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16, 6, (hipStream_t)hip_stream);
     });
 }
 

@@ -235,10 +235,11 @@ static void launch_dt(const GemmParams& p, int tile, hipStream_t st) {
 
 static int pick_tile(const GemmParams& p, int tile) {
     if (tile >= 0) return tile;
-    // heuristic: the deep-pipelined 256x256 kernel once there is enough work to fill the chip with it
-    const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    // The deep-pipelined 256x256 kernel for every weight matrix wide and deep enough to give it a tile.  The choice looks at the
+    // WEIGHT's shape (N, K) and at alignment only, never at M: the two kernels sum in different orders, and a row's reward must be
+    // bit-identical whatever else is in the batch or however the batch is sharded (every operand mode, not only the default one).
     const bool aligned = p.N % 8 == 0 && p.ldc % 8 == 0 && (((uintptr_t)p.C) & 15) == 0 && (!p.bias || (((uintptr_t)p.bias) & 15) == 0);
-    return (t256 >= 256 && aligned) ? 6 : 0;
+    return (aligned && p.N >= 256 && p.K >= 128) ? 6 : 0;
 }
 
 bool gemm_bt_is_deep(const GemmParams& p, int tile) { return pick_tile(p, tile) >= 3; }
@@ -251,7 +252,7 @@ void launch_gemm_bt(const GemmParams& p, int operand_dtype, int tile, hipStream_
         throw std::runtime_error("gemm_bt: split-operand mode needs K == 2 kw (3 kw with Wlo), kw % 64 == 0");
     if (p.split < 0 || p.split % 8) throw std::runtime_error("gemm_bt: split must be a non-negative multiple of 8");
     if (p.epi == EPI_SWIGLU_OP && (p.N % 64) != 0) throw std::runtime_error("gemm_bt: SwiGLU needs N % 64 == 0");
-    tile = pick_tile(p, tile);
+    tile = p.A2 ? 6 : pick_tile(p, tile);          // a K-extension (un-merged adapter) exists in the deep-pipelined kernel only
     if (tile >= 3) { launch_gemm_bt8(p, operand_dtype, tile, st); return; }
     if (p.epi == EPI_ROPE_OP) throw std::runtime_error("gemm_bt: the fused RoPE epilogue exists only in the deep-pipelined kernel");
     if (operand_dtype == DT_F16) launch_dt<F16>(p, tile, st);

@@ -86,9 +86,11 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 
     const int Mt = (p.M + BM - 1) / BM, Nt = (p.N + BN - 1) / BN;
     const int nwg = Mt * Nt;
-    const int nk = p.K / BK;
-    const int nk_hi = F8 == 2 ? p.kw / BK : nk;      // K-tiles of 16-bit operands; the rest are e4m3
-    const int nk_lo = F8 == 2 ? nk_hi + p.kw / (2 * BK) : nk;      // end of the residual segment; beyond it: A_hi8 x Wlo8 (inexact weights)
+    // PB == 2 (product): the K loop is the segment list the launcher built (GemmParams::seg); the A/B variants keep the older
+    // closed-form addressing (16-bit operands only)
+    const int nk = PB == 2 ? p.nk : p.K / BK;
+    const int nk_hi = (PB == 2 && F8 == 2) ? p.nk_f16 : nk;      // K-tiles of 16-bit operands; the rest are e4m3
+    const int nk_lo = (PB == 2 && F8 == 2) ? p.nk_e1 : nk;       // end of the residual segment; beyond it: A_hi8 x Wlo8 (inexact weights)
     const int Gtot = 4 * nk;
     typedef __attribute__((address_space(3))) char lds_char;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_char*)smem;
@@ -140,8 +142,42 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         const int m0 = mi * BM, n0 = ni * BN;
 
         // ---- LDS-DMA source pointers: [half][it]; swizzle on the source side ----
+        // PB == 2: gA / gB are RUNNING pointers -- they address the K-tile that is issued next and move on by one K-tile (64 units)
+        // once its four half-tiles are out; at a segment boundary they are rebuilt for the next segment (load_seg): another
+        // operand pair (the adapter's t / B, the e4m3 twins), another row pitch, another column.  The rebuild sits inside the K
+        // loop but runs a handful of times per tile; its index arithmetic is kept from being hoisted (it would live across the
+        // loop in VGPRs the accumulators need).
         const unsigned short* gA[2][2];
         const unsigned short* gB[2][2];
+        int iseg = -1, iseg_end = 0, ikt = 0;          // segment being issued, its last K-tile + 1, K-tile being issued (uniform)
+        auto load_seg = [&]() {
+            ++iseg;
+            const GemmParams::KSeg sg = p.seg[iseg];
+            iseg_end = sg.kt_end;
+            const bool a2 = (sg.src & GemmParams::SRC_A2) != 0, w2 = (sg.src & GemmParams::SRC_W2) != 0;
+            const bool lo = (sg.src & GemmParams::SRC_LO) != 0;
+            const unsigned short* Ab = (const unsigned short*)(a2 ? p.A2 : p.A);
+            const unsigned short* Wb = (const unsigned short*)(w2 ? (lo ? p.W2lo : p.W2) : (sg.src & GemmParams::SRC_LO16) ? p.Wlo16 : lo ? p.Wlo : p.W);
+            const int la = a2 ? p.lda2 : p.lda, lw = w2 ? p.ldw2 : p.ldw;
+            int t = tid;
+            asm volatile("" : "+v"(t));
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int q = it * 512 + t;
+                const int R = q >> 4, Cp = q & 15;
+                const int C = Cp ^ (R & 15);
+                const int row = 2 * R + (C >> 3), c = C & 7;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int ga = min(m0 + h * 128 + row, p.M - 1);
+                    gA[h][it] = Ab + (size_t)ga * la + c * 8 + sg.a_col;
+                    const int wrow = (row >> 5) * 64 + h * 32 + (row & 31);
+                    const int gb = min(n0 + wrow, p.N - 1);
+                    gB[h][it] = Wb + (size_t)gb * lw + c * 8 + sg.w_col;
+                }
+            }
+        };
+        if constexpr (PB != 2) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int q = it * 512 + tid;
@@ -157,6 +193,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 gB[h][it] = (const unsigned short*)p.W + (size_t)gb * p.ldw + c * 8;
             }
         }
+        }
 
         // half-tile j of a K-tile: 0 = A0, 1 = B0, 2 = B1, 3 = A1.
         // The LDS-DMA is issued from inline asm on purpose: hipcc's waitcnt pass would otherwise put
@@ -165,21 +202,34 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         // (cdna_hip_programming.md §5.7 item 1).  M0 is saved/restored inside the statement.
         auto issue1 = [&](int j, int kt, int slot, int it) {
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * HT + wave * 1024 + it * 8192);
-            int koff = DBG == 1 ? 0 : kt * BK, koffw = koff;
-            ptrdiff_t wsel = 0;
-            if constexpr (F8 == 2) {             // A = [hi | lo8]: the row continues; W8 sits in the rows of Wlo
-                if (koff >= p.kw) { koffw = koff - p.kw; wsel = wlo_delta; }
-            } else if (p.kw > 0) {               // split-operand mode: A = [hi | lo (| hi)], W repeats along K (, then its residuals)
-                if (koff >= 2 * p.kw) { koff -= 2 * p.kw; koffw = koff; wsel = wlo_delta; }
-                else if (koff >= p.kw) koffw = koff - p.kw;
+            const unsigned short* src;
+            if constexpr (PB == 2) {             // running pointers: already at this K-tile
+                src = (j == 0) ? gA[0][it] : (j == 1) ? gB[0][it] : (j == 2) ? gB[1][it] : gA[1][it];
+            } else {
+                int koff = DBG == 1 ? 0 : kt * BK, koffw = koff;
+                ptrdiff_t wsel = 0;
+                if (p.kw > 0) {                  // split-operand mode: A = [hi | lo (| hi)], W repeats along K (, then its residuals)
+                    if (koff >= 2 * p.kw) { koff -= 2 * p.kw; koffw = koff; wsel = wlo_delta; }
+                    else if (koff >= p.kw) koffw = koff - p.kw;
+                }
+                src = (j == 0) ? gA[0][it] + koff : (j == 1) ? gB[0][it] + koffw + wsel : (j == 2) ? gB[1][it] + koffw + wsel : gA[1][it] + koff;
             }
-            const unsigned short* src = (j == 0) ? gA[0][it] + koff : (j == 1) ? gB[0][it] + koffw + wsel : (j == 2) ? gB[1][it] + koffw + wsel
-                                                                                                            : gA[1][it] + koff;
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
         };
         auto issue = [&](int j, int kt, int slot) { issue1(j, kt, slot, 0); issue1(j, kt, slot, 1); };
+        // PB == 2: in front of the first / behind the last half-tile of the K-tile being issued
+        auto ktile_begin = [&]() { if (ikt == iseg_end) load_seg(); };
+        auto ktile_end = [&]() {
+            ++ikt;
+            if constexpr (DBG != 1) {
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) { gA[h][it] += BK; gB[h][it] += BK; }
+            }
+        };
 
         f32x4 acc[4][4][2];     // [quadrant (0,0) (0,1) (1,1) (1,0)][row tile of 16][col tile of 16]
 #pragma unroll
@@ -238,7 +288,11 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         int islot = 0;
 #pragma unroll
         for (int g = 0; g < PF2; ++g) {
-            if (g < Gtot) issue(g & 3, g >> 2, islot);
+            if (g < Gtot) {
+                if ((g & 3) == 0) ktile_begin();
+                issue(g & 3, g >> 2, islot);
+                if ((g & 3) == 3) ktile_end();
+            }
             islot = (islot + 1 == NS) ? 0 : islot + 1;
         }
         if (Gtot > PF2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT2) : "memory");
@@ -276,10 +330,12 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 }
                 if (more) {
                     if constexpr (DBG != 5) {
+                        if (sp == 0) ktile_begin();
                         issue(2 * sp, kt + 2, islot);
                         islot = (islot + 1 == NS) ? 0 : islot + 1;
                         issue(2 * sp + 1, kt + 2, islot);
                         islot = (islot + 1 == NS) ? 0 : islot + 1;
+                        if (sp == 1) ktile_end();
                     }
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT2) : "memory");
                 } else {
@@ -747,14 +803,63 @@ static void launch8_epi(const GemmParams& p, bool persistent, hipStream_t st) {
     }
 }
 
+// The K loop of the product kernel as a list of segments (GemmParams::KSeg).  f8: the kernel form (0 = 16-bit, 1 = W8A8, 2 = 16-bit
+// pass + e4m3 residual pass).  Reads the caller's description -- kw / Wlo (split operands, inexact weights), aexp2 (e4m3 third
+// segment), Wlo16 (16-bit third segment beside an e4m3 residual pass), A2 / W2 / W2lo / k2 (un-merged adapter) -- and fills
+// seg / nseg / nk_f16 / nk_e1 / nk.  Columns are in 2-byte units: an e4m3 K-tile is 128 bytes = 64 units of its row.
+static void build_segments(GemmParams& p, int f8) {
+    int kt = 0, n = 0;
+    auto add = [&](int tiles, int src, int a_col, int w_col) {
+        if (tiles <= 0) return;
+        if (n >= GemmParams::MAX_SEG) throw std::runtime_error("gemm_bt8: too many K segments");
+        kt += tiles;
+        p.seg[n++] = GemmParams::KSeg{kt, src, a_col, w_col};
+    };
+    auto adapter = [&](bool split) {         // t_hi x B, t_lo x B (split operands), t_hi x B_lo (B inexact in the operand type)
+        if (!p.A2) return;
+        if (!p.W2 || p.k2 <= 0 || p.k2 % 64 || p.lda2 % 8 || p.ldw2 % 8 || p.lda2 < (split ? 2 : 1) * p.k2 || p.ldw2 < p.k2 ||
+            ((uintptr_t)p.A2 & 15) || ((uintptr_t)p.W2 & 15) || ((uintptr_t)p.W2lo & 15))
+            throw std::runtime_error("gemm_bt8: bad K-extension (adapter) operands");
+        add(p.k2 / 64, GemmParams::SRC_A2 | GemmParams::SRC_W2, 0, 0);
+        if (split) add(p.k2 / 64, GemmParams::SRC_A2 | GemmParams::SRC_W2, p.k2, 0);
+        if (p.W2lo) add(p.k2 / 64, GemmParams::SRC_A2 | GemmParams::SRC_W2 | GemmParams::SRC_LO, 0, 0);
+    };
+    if (f8 == 2) {
+        const bool third8 = p.aexp2 != nullptr;
+        add(p.kw / 64, 0, 0, 0);                                             // x_hi x W
+        if (p.Wlo16) add(p.kw / 64, GemmParams::SRC_LO16, 0, 0);              // x_hi x W_lo, 16-bit
+        adapter(true);
+        p.nk_f16 = kt;
+        add(p.kw / 128, GemmParams::SRC_LO, p.kw, 0);                        // e4m3(x_lo) x e4m3(W)
+        p.nk_e1 = kt;
+        if (third8) add(p.kw / 128, GemmParams::SRC_LO, p.kw + p.kw / 2, p.kw / 2);      // e4m3(x_hi) x e4m3(W_lo)
+    } else if (f8 == 1) {
+        if (p.A2) throw std::runtime_error("gemm_bt8_fp8: no K-extension in the W8A8 form (merge the adapter)");
+        add(p.K / 64, 0, 0, 0);
+        p.nk_f16 = p.nk_e1 = kt;
+    } else if (p.kw > 0) {
+        add(p.kw / 64, 0, 0, 0);                                             // x_hi x W
+        add(p.kw / 64, 0, p.kw, 0);                                          // x_lo x W
+        if (p.Wlo) add(p.kw / 64, GemmParams::SRC_LO, 0, 0);                  // x_hi x W_lo
+        adapter(true);
+        p.nk_f16 = p.nk_e1 = kt;
+    } else {
+        add(p.K / 64, 0, 0, 0);
+        adapter(false);
+        p.nk_f16 = p.nk_e1 = kt;
+    }
+    p.nseg = n;
+    p.nk = kt;
+}
+
 template <typename OT>
 static void launch8_variant(const GemmParams& p, int variant, hipStream_t st) {
     switch (variant) {
         case 3: case 5: launch8_epi<OT, 5, 0>(p, false, st); break;
         case 4: launch8_epi<OT, 5, 0>(p, true, st); break;               // persistent walk, B fragments read in the LOAD segments (A/B)
-        case 6: launch8_epi<OT, 6, 0, 2>(p, true, st); break;            // product: persistent walk, super-phase schedule
+        case 6: { GemmParams q = p; build_segments(q, 0); launch8_epi<OT, 6, 0, 2>(q, true, st); break; }   // product: persistent walk, super-phase schedule
         case 10: launch8_epi<OT, 6, 0, 1>(p, true, st); break;           // A/B: 4-phase schedule + B fragments prefetched inside COMPUTE
-        case 13: launch8<OT, 6, 3, EPI_OUT_F32, 2>(p, false, st); break;  // diagnostic only: stamps of the super-phase schedule
+        case 13: { GemmParams q = p; build_segments(q, 0); launch8<OT, 6, 3, EPI_OUT_F32, 2>(q, false, st); break; }  // diagnostic only: stamps of the super-phase schedule
         case 7: launch8<OT, 5, 1, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: cache-resident operands
         case 8: launch8<OT, 5, 2, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: no epilogue
         case 9: launch8<OT, 5, 3, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: in-kernel stamps -> `bias` buffer
@@ -778,16 +883,19 @@ void launch_gemm_bt8_fp8(GemmParams p, int operand_dtype, hipStream_t st) {
     if (p.epi == EPI_ROPE_OP && (!p.rope_cs || p.rope_hd % 16 || p.rope_cols % 256 || p.rope_cols % p.rope_hd || ((uintptr_t)p.rope_cs & 15)))
         throw std::runtime_error("gemm_bt8_fp8: bad RoPE epilogue parameters");
     p.K /= 2; p.lda /= 2; p.ldw /= 2;
+    build_segments(p, 1);
     if (operand_dtype == DT_F16) launch8_epi<F16, 6, 0, 2, 1>(p, true, st);
     else launch8_epi<BF16, 6, 0, 2, 1>(p, true, st);
 }
 
 // Split-operand mode with the e4m3 residual pass (kernel form F8 == 2, see there).  p as for the 16-bit split form but
 // K = kw + kw / 2 (2-byte units), Wlo = the rows that hold W8, aexp / wexp = the E8M0 scales.
-void launch_gemm_bt8_mixed(const GemmParams& p, int operand_dtype, hipStream_t st) {
-    if (p.M <= 0) return;
-    if (p.kw <= 0 || p.kw % 128 || (p.K != p.kw + p.kw / 2 && p.K != 2 * p.kw) || !p.Wlo || !p.aexp || (p.K == 2 * p.kw && !p.aexp2))
-        throw std::runtime_error("gemm_bt8_mixed: needs kw % 128 == 0, K == 1.5 kw (2 kw with the A_hi8 x Wlo8 segment), W8 rows and row exponents");
+void launch_gemm_bt8_mixed(const GemmParams& p0, int operand_dtype, hipStream_t st) {
+    if (p0.M <= 0) return;
+    GemmParams p = p0;
+    if (p.kw <= 0 || p.kw % 128 || !p.Wlo || !p.aexp || (p.aexp2 && p.Wlo16))
+        throw std::runtime_error("gemm_bt8_mixed: needs kw % 128 == 0, W8 rows and row exponents (third segment: e4m3 OR 16-bit, not both)");
+    build_segments(p, 2);
     if (p.N % 8 || p.ldc % 8 || ((uintptr_t)p.C & 15) || (p.bias && ((uintptr_t)p.bias & 15)))
         throw std::runtime_error("gemm_bt8_mixed: N and ldc must be multiples of 8 and C/bias 16-byte aligned");
     if (p.epi == EPI_ROPE_OP && (!p.rope_cs || p.rope_hd % 16 || p.rope_cols % 256 || p.rope_cols % p.rope_hd || ((uintptr_t)p.rope_cs & 15)))
@@ -800,6 +908,7 @@ void launch_gemm_bt8(const GemmParams& p, int operand_dtype, int variant, hipStr
     if (p.N % 8 || p.ldc % 8 || ((uintptr_t)p.C & 15) || (p.bias && ((uintptr_t)p.bias & 15)))
         throw std::runtime_error("gemm_bt8: N and ldc must be multiples of 8 and C/bias 16-byte aligned");
     if (p.kw > 0 && (p.kw % 64 || p.K != (p.Wlo ? 3 : 2) * p.kw)) throw std::runtime_error("gemm_bt8: split-operand mode needs K == 2 kw (3 kw with Wlo)");
+    if (p.A2 && variant != 6) throw std::runtime_error("gemm_bt8: the K-extension exists in the product schedule only");
     if (p.epi == EPI_ROPE_OP && (!p.rope_cs || p.rope_hd % 16 || p.rope_cols % 256 || p.rope_cols % p.rope_hd || ((uintptr_t)p.rope_cs & 15)))
         throw std::runtime_error("gemm_bt8: bad RoPE epilogue parameters");
     if (operand_dtype == DT_F16) launch8_variant<F16>(p, variant, st);

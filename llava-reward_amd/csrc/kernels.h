@@ -40,10 +40,13 @@ void launch_clip_embed(const float* patch_out, const float* cls, const float* po
 // positions: cumsum(mask)-1 with pads -> 1 (rw_model:344-345) or arange(S) when pos_arange (no position_ids passed)
 void launch_token_plan(const int64_t* ids, const int64_t* mask, int B, int S, const int* voff, int* img_row, int* pos,
                        int* tstat, hipStream_t st, long image_token_id = -1, int pos_arange = 0);
+// rewards[b][:] = NaN where the image-slot count of row b (tstat) differs from its image-token count voff[b+1] - voff[b]
+void launch_slot_check(const int* tstat, const int* voff, float* rewards, int B, int d, hipStream_t st);
 // x[b*S+s] = img_row >= 0 ? ev[img_row] : wte[clamp(id)]
 void launch_embed(const int64_t* ids, const int* img_row, const unsigned short* wte_bf16, const float* ev, float* x,
                   int rows, int D, int vocab, hipStream_t st);
-// cos/sin table [rows][hd/2][2] = (cos, sin) pairs from positions (su-scaled RoPE); picks long factors if max(pos)+1 > orig_max
+// cos/sin table [rows][hd/2][2] = (cos, sin) pairs from positions (su-scaled RoPE); long factors iff S > orig_max (the reference
+// passes seq_len = the padded length, modeling_phi3_v.py:673)
 void launch_rope_table(const int* pos, const int* tstat, int B, int S, const float* inv_freq_short,
                        const float* inv_freq_long, float scaling, int orig_max_pos, int half, float* cs, hipStream_t st);
 // qkv32 [rows, 3D] fp32 -> qkv operand dtype with RoPE applied to q and k heads (pair-interleaved head dims)

@@ -140,6 +140,14 @@ void build_weight_table_qwen(lr_engine* e) {
         add_slot(e, p + "mlp.gate_proj.weight", {I, D}, L.gu_w, D, D, od, PACK_SWIGLU_GATE, 0.02, 0);
         add_slot(e, p + "mlp.up_proj.weight", {I, D}, L.gu_w, D, D, od, PACK_SWIGLU_UP, 0.02, 0);
         add_slot(e, p + "mlp.down_proj.weight", {D, I}, L.down_w, I, I, od, PACK_PLAIN, 0.02, 0);
+        if (d.lora_rank > 0) {      // utils/utils.py:223-242 create_lora_config_qwen: q, k, v, o, gate, up, down of every decoder layer
+            for (int i = 0; i < 3; ++i)
+                register_lora(e, L.lqkv, p + "self_attn." + nm[i], e->Nqkv, D, i, 3, n[i], off[i], i < 2 ? PACK_ROPE_QKV : PACK_PLAIN, n[i], hd);
+            register_lora(e, L.lo, p + "self_attn.o_proj", D, Hq, 0, 1, D, 0, PACK_PLAIN);
+            register_lora(e, L.lgu, p + "mlp.gate_proj", 2 * I, D, 0, 2, I, 0, PACK_SWIGLU_GATE);
+            register_lora(e, L.lgu, p + "mlp.up_proj", 2 * I, D, 1, 2, I, 0, PACK_SWIGLU_UP);
+            register_lora(e, L.ldown, p + "mlp.down_proj", D, I, 0, 1, D, 0, PACK_PLAIN);
+        }
     }
     e->norm_w = falloc(e, D);
     vec_slot(e, "model.norm.weight", {D}, e->norm_w, 0.05, 1.0);
@@ -178,6 +186,7 @@ void finalize_qwen(lr_engine* h) {
     h->ev = (float*)W(Rm * D * 4);
     h->x = (float*)W(Rl * D * 4); h->h = W(Rl * D * ob); h->qkv32 = (float*)W(Rl * h->Nqkv * 4); h->qkv = W(Rl * h->Nqkv * ob);
     h->att = W(Rl * h->Hq * ob); h->ff = W(Rl * I * ob); h->cs = (float*)W(Rl * h->hd * 4);
+    if (h->lora_k2max > 0) h->lt = W(Rl * (size_t)h->lora_k2max * ob);
     h->pos_ids = (int*)W(Rl * 4); h->img_row = (int*)W(Rl * 4); h->pos3 = (int*)W(3 * Rl * 4);
     h->tstat = (int*)W(B * 16); h->rstat = (int*)W(B * 16);
     h->hL = (float*)W(B * D * 4); h->tao = (float*)W(B * D * 4);
@@ -198,6 +207,10 @@ void finalize_qwen(lr_engine* h) {
         for (const DecLayer& L : h->dl) {
             ws.push_back({L.qkv_w, h->Nqkv, (int)D, Rl}); ws.push_back({L.o_w, (int)D, h->Hq, Rl});
             ws.push_back({L.gu_w, (int)(2 * I), (int)D, Rl}); ws.push_back({L.down_w, (int)D, (int)I, Rl});
+            if (L.lqkv.k2) {
+                ws.push_back({L.lqkv.A, L.lqkv.k2, (int)D, Rl}); ws.push_back({L.lo.A, L.lo.k2, h->Hq, Rl});
+                ws.push_back({L.lgu.A, L.lgu.k2, (int)D, Rl}); ws.push_back({L.ldown.A, L.ldown.k2, (int)I, Rl});
+            }
         }
         prepare_twins(h, ws);
     }

@@ -269,7 +269,9 @@ __global__ __launch_bounds__(256) void token_plan_kernel(const int64_t* __restri
         }
         if (s < S) {
             pos[(size_t)b * S + s] = pos_arange ? s : (m ? (om + pm) : 1);     // arange | cumsum(mask) - 1, pads -> 1
-            img_row[(size_t)b * S + s] = n ? (voff[b] + on + pn) : -1;
+            // a slot beyond the image tokens this row's image_sizes produce would read another row's features (or past the buffer):
+            // it keeps the text embedding instead, and slot_check_kernel turns the row's reward into NaN
+            img_row[(size_t)b * S + s] = (n && on + pn < voff[b + 1] - voff[b]) ? (voff[b] + on + pn) : -1;
             if (m) { last = s; if (s < first) first = s; }
         }
         run_m += tm; run_n += tn;
@@ -295,6 +297,21 @@ void launch_token_plan(const int64_t* ids, const int64_t* mask, int B, int S, co
                        int* tstat, hipStream_t st, long image_token_id, int pos_arange) {
     if (B <= 0) return;
     hipLaunchKernelGGL(token_plan_kernel, dim3(B), dim3(256), 0, st, ids, mask, S, voff, img_row, pos, tstat, image_token_id, pos_arange);
+}
+
+// The reference fails such a batch (index_put shape mismatch, modeling_phi3_v.py:247; "Image features and image tokens do not
+// match", modeling_llava_next.py); the Python wrapper raises the same errors before the launch.  For direct C-ABI callers, who
+// get no host-side check (it would cost a device sync per pass), a row whose image-slot count differs from the number of image
+// tokens its image_sizes produce comes back as NaN instead of a silently wrong reward.
+__global__ void slot_check_kernel(const int* __restrict__ tstat, const int* __restrict__ voff, float* __restrict__ rewards, int B, int d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * d) return;
+    const int b = i / d;
+    if (tstat[b * 4 + 2] != voff[b + 1] - voff[b]) rewards[i] = __builtin_nanf("");
+}
+void launch_slot_check(const int* tstat, const int* voff, float* rewards, int B, int d, hipStream_t st) {
+    if (B <= 0) return;
+    hipLaunchKernelGGL(slot_check_kernel, dim3(cdiv(B * d, 64)), dim3(64), 0, st, tstat, voff, rewards, B, d);
 }
 
 // --------------------------------------------------------------------------------------- embedding
@@ -329,15 +346,15 @@ void launch_embed(const int64_t* ids, const int* img_row, const unsigned short* 
 }
 
 // ------------------------------------------------------------------------------------------ RoPE
-// modeling_phi3_v.py:446-476: freqs = pos * inv_freq; cos/sin scaled by sqrt(1 + ln(s)/ln(orig)); long
-// factors when max(pos)+1 > original_max_position_embeddings.  cs layout: [row][2][half].
-__global__ __launch_bounds__(256) void rope_table_kernel(const int* __restrict__ pos, const int* __restrict__ tstat, int B,
+// modeling_phi3_v.py:446-476: freqs = pos * inv_freq; cos/sin scaled by sqrt(1 + ln(s)/ln(orig)); long factors when
+// seq_len > original_max_position_embeddings.  The attention layers call it with seq_len = kv_seq_len = the PADDED length S
+// (:673 eager, :1081 sdpa; no KV cache on this path), so the `seq_len or max(position_ids)+1` fallback of :448 is never taken:
+// the switch depends on S alone, not on how many tokens of a row are valid.  cs layout: [row][half][2].
+__global__ __launch_bounds__(256) void rope_table_kernel(const int* __restrict__ pos, int S,
                                                          int rows, const float* __restrict__ inv_s,
                                                          const float* __restrict__ inv_l, float scaling, int orig_max,
                                                          int half, float* __restrict__ cs) {
-    int nv = 0;
-    for (int b = 0; b < B; ++b) nv = max(nv, tstat[b * 4 + 3]);
-    const float* inv = (max(nv, 2) > orig_max) ? inv_l : inv_s;
+    const float* inv = (S > orig_max) ? inv_l : inv_s;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)rows * half) return;
     const int row = (int)(i / half), k = (int)(i - (size_t)row * half);
@@ -349,8 +366,9 @@ __global__ __launch_bounds__(256) void rope_table_kernel(const int* __restrict__
 void launch_rope_table(const int* pos, const int* tstat, int B, int S, const float* inv_freq_short,
                        const float* inv_freq_long, float scaling, int orig_max_pos, int half, float* cs, hipStream_t st) {
     const int rows = B * S;
+    (void)tstat;
     if (rows <= 0) return;
-    hipLaunchKernelGGL(rope_table_kernel, dim3(cdiv((long)rows * half, 256)), dim3(256), 0, st, pos, tstat, B, rows,
+    hipLaunchKernelGGL(rope_table_kernel, dim3(cdiv((long)rows * half, 256)), dim3(256), 0, st, pos, S, rows,
                        inv_freq_short, inv_freq_long, scaling, orig_max_pos, half, cs);
 }
 

@@ -13,7 +13,7 @@ LR_MAX_HALF_HEAD = 64
 LR_MAX_PINPOINTS = 8
 LR_MAX_FULLATT = 8
 LR_BACKBONE_PHI3V, LR_BACKBONE_LLAVA_NEXT, LR_BACKBONE_QWEN2_5_VL = 0, 1, 2
-LR_ABI_VERSION = 5
+LR_ABI_VERSION = 6
 EPI_OUT_OP, EPI_OUT_F32, EPI_RESADD_F32, EPI_SWIGLU_OP, EPI_ROPE_OP = 0, 1, 2, 3, 4
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2
 
@@ -47,6 +47,7 @@ class ModelDesc(C.Structure):
         ("precise", C.c_int32),
         ("mean_hidden_state", C.c_int32),
         ("w8a8", C.c_int32),
+        ("lora_rank", C.c_int32),
     ]
 
 
@@ -73,6 +74,7 @@ _SIGS = {
     "lr_set_gemm_tile": (C.c_int, [C.c_void_p, C.c_int]),
     "lr_op_gemm_bt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]),
     "lr_op_gemm_bt_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),
+    "lr_op_gemm_bt_ext": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 8 + [C.c_void_p]),
     "lr_op_gemm_rope": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p]),
     "lr_op_attention": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 11 + [C.c_float, C.c_int, C.c_void_p]),
     "lr_op_attention_split": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 13 + [C.c_float, C.c_int, C.c_void_p]),

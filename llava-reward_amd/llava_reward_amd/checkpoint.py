@@ -5,9 +5,9 @@
     <pm_path>/pytorch_model.bin                    value_head / W_q / W_k / W_v / ca_layernorm / img_projection
     <pm_path>/lora/adapter_config.json + adapter_model.{bin,safetensors}   PEFT LoRA adapter
 
-LoRA is merged on the host in fp32, W' = W + (alpha/r) * B @ A, and rounded once when the engine
-packs it into its operand dtype (the reference runs the adapter un-merged in bf16,
-eval/reward_adaptor_loader.py:44-45; merged == un-merged in exact arithmetic).
+The LoRA adapter of the decoder linears stays UN-MERGED, as the reference runs it (eval/reward_adaptor_loader.py:44-45):
+A and (alpha/r) * B go to the engine as tensors of their own (lr_model_desc.lora_rank); adapters on other modules, and
+everything with merge=True (debug switch; the W8A8 mode), are merged on the host in fp32, W' = W + (alpha/r) * B @ A.
 """
 from __future__ import annotations
 
@@ -164,13 +164,23 @@ def read_base_weights(path: str, wanted, canon=None) -> Dict[str, torch.Tensor]:
 
 
 _LORA_RE = re.compile(r"^(?:base_model\.model\.)?(.+)\.lora_([AB])(?:\.[^.]+)?\.weight$")
+# adapter_config.json switches that change the arithmetic of peft's Linear.forward and are not implemented here
+_LORA_UNSUPPORTED = ("use_rslora", "use_dora", "fan_in_fan_out", "rank_pattern", "alpha_pattern", "layer_replication", "megatron_config")
 
 
-def read_lora(lora_dir: str) -> Tuple[Dict[str, Tuple[torch.Tensor, torch.Tensor]], float]:
-    """-> ({module name: (A [r,in], B [out,r])}, alpha/r)."""
+def read_lora(lora_dir: str) -> Tuple[Dict[str, Tuple[torch.Tensor, torch.Tensor]], float, int]:
+    """-> ({module name: (A [r,in], B [out,r])}, lora_alpha / r, r).  Layout written by DeepspeedStrategy.save_model_lora
+    (utils/deepspeed.py:386-398: LoraConfig.save_pretrained + get_peft_model_state_dict -> keys `<module>.lora_A.weight`, with or
+    without the `base_model.model.` prefix and the adapter name)."""
     with open(os.path.join(lora_dir, "adapter_config.json")) as f:
         ac = json.load(f)
-    scale = float(ac["lora_alpha"]) / float(ac["r"])
+    for k in _LORA_UNSUPPORTED:
+        if ac.get(k):
+            raise NotImplementedError(f"adapter_config.json: {k}={ac[k]!r} is not implemented (plain LoRA, scaling = lora_alpha / r, only)")
+    if ac.get("bias", "none") != "none" or ac.get("modules_to_save"):
+        raise NotImplementedError("adapter_config.json: LoRA bias terms / modules_to_save are not implemented")
+    r = int(ac["r"])
+    scale = float(ac["lora_alpha"]) / float(r)
     st = os.path.join(lora_dir, "adapter_model.safetensors")
     if os.path.exists(st):
         from safetensors.torch import load_file
@@ -178,30 +188,72 @@ def read_lora(lora_dir: str) -> Tuple[Dict[str, Tuple[torch.Tensor, torch.Tensor
     else:
         sd = torch.load(os.path.join(lora_dir, "adapter_model.bin"), map_location="cpu")
     pairs: Dict[str, dict] = {}
+    stray = []
     for k, v in sd.items():
         m = _LORA_RE.match(k)
         if m:
             pairs.setdefault(m.group(1), {})[m.group(2)] = v
+        else:
+            stray.append(k)
+    if stray:
+        raise KeyError(f"LoRA adapter: tensors that are not lora_A / lora_B weights: {stray[:4]}")
     out = {}
     for mod, ab in pairs.items():
         if "A" not in ab or "B" not in ab:
             raise KeyError(f"LoRA adapter: incomplete pair for {mod}")
+        if ab["A"].shape[0] != r or ab["B"].shape[1] != r:
+            raise ValueError(f"LoRA adapter: {mod} has rank {ab['A'].shape[0]}, adapter_config.json says {r}")
         out[mod] = (ab["A"], ab["B"])
-    return out, scale
+    if not out:
+        raise KeyError(f"{lora_dir}: the adapter holds no lora_A / lora_B tensors")
+    return out, scale, r
 
 
-def merge_lora(weights: Dict[str, torch.Tensor], lora: Dict[str, Tuple[torch.Tensor, torch.Tensor]], scale: float, canon=None) -> int:
-    """In place: weights[mod + '.weight'] += scale * B @ A (fp32).  Returns the number of merged modules."""
-    n = 0
+# Adapter modules that exist in a checkpoint but not on the scoring path: the CLIP layer patch_clip_for_lora deletes
+# (utils/utils.py:277-281 keeps layers [0, layer_idx]) and heads the reward model never evaluates.
+_OFF_PATH = re.compile(r"(?:^|\.)(?:lm_head|post_layernorm|encoder\.layers\.(\d+)\..*)$")
+
+
+def _off_path(mod: str, clip_layers_used: int) -> bool:
+    m = _OFF_PATH.search(mod)
+    if not m:
+        return False
+    return m.group(1) is None or int(m.group(1)) >= clip_layers_used
+
+
+def attach_lora(weights: Dict[str, torch.Tensor], lora: Dict[str, Tuple[torch.Tensor, torch.Tensor]], scale: float, rank: int,
+                engine_names, canon=None, merge: bool = False, clip_layers_used: int = 1 << 30) -> Dict[str, int]:
+    """Put a PEFT adapter into `weights` (in place).  Decoder linears the engine runs un-merged (names `<module>.lora_A.weight` /
+    `.lora_B.weight` in `engine_names`, i.e. weight_specs of a config with lora_rank = rank) get A and the PRE-SCALED scale * B as
+    tensors of their own, which is how the reference runs them (eval/reward_adaptor_loader.py:44-45) and keeps the bf16 base
+    weights exact; un-targeted engine slots are zero-filled.  Other adapted modules on the path (vision tower, projector: only
+    when the run did not freeze the vision model, utils/utils.py:203-214) and everything when merge=True are merged in fp32,
+    W + scale * B @ A.  A module that resolves to nothing raises unless it is known to be off the scoring path.
+    Returns {"unmerged": n, "merged": n, "skipped": n}."""
+    engine_names = set(engine_names)
+    n = {"unmerged": 0, "merged": 0, "skipped": 0}
     for mod, (A, B) in lora.items():
-        key = mod + ".weight"
-        if canon:
-            key = canon(key)
-        if key not in weights:
-            continue                 # adapter targets outside the scoring path (e.g. CLIP layer 24)
-        w = weights[key].float()
-        weights[key] = w + scale * (B.float() @ A.float())
-        n += 1
+        cm = canon(mod + ".weight")[: -len(".weight")] if canon else mod
+        if not merge and cm + ".lora_A.weight" in engine_names:
+            weights[cm + ".lora_A.weight"] = A.float()
+            weights[cm + ".lora_B.weight"] = scale * B.float()
+            n["unmerged"] += 1
+        elif cm + ".weight" in weights:
+            weights[cm + ".weight"] = weights[cm + ".weight"].float() + scale * (B.float() @ A.float())
+            n["merged"] += 1
+        elif _off_path(cm, clip_layers_used):
+            n["skipped"] += 1
+        else:
+            raise KeyError(f"LoRA adapter module {mod!r} matches no weight of the scoring path (canonical name {cm!r}); "
+                           "refusing to load a model with part of its adapter silently dropped")
+    if n["unmerged"] + n["merged"] == 0:
+        raise KeyError("LoRA adapter: no module of the adapter applies to the scoring path")
+    if not merge:
+        for name in engine_names:                      # engine slots of linears this adapter does not target
+            if name.endswith(".lora_A.weight") and name not in weights:
+                base = weights[name[: -len(".lora_A.weight")] + ".weight"]
+                weights[name] = torch.zeros(rank, base.shape[1])
+                weights[name[: -len("A.weight")] + "B.weight"] = torch.zeros(base.shape[0], rank)
     return n
 
 

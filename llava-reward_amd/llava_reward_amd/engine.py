@@ -90,6 +90,9 @@ def make_desc(cfg, max_batch: int, max_seq: int, max_crops: int, operand_dtype: 
     d.precise = _PRECISE.get(operand_dtype, 0)
     d.mean_hidden_state = 1 if mean_hidden_state else 0
     d.w8a8 = 1 if operand_dtype == "fp8" else 0
+    d.lora_rank = int(getattr(cfg, "lora_rank", 0))
+    if d.lora_rank and d.w8a8:
+        raise ValueError("operand_dtype='fp8' (W8A8) runs merged weights only: load the adapter with merge=True")
     return d
 
 

@@ -18,6 +18,20 @@ class UnknownModelType(UnboundLocalError, ValueError):
     """The reference falls off its if/elif chain and dies with UnboundLocalError (:156)."""
 
 
+def _attach_adapter(args, cfg, weights, spec_fn, canon=None):
+    """<pm_path>/lora -> `weights` (checkpoint.attach_lora).  The decoder adapter stays un-merged, as the reference runs it
+    (:44-45); `args.merge_lora = True` (debug switch) or the W8A8 operand mode merges everything on the host instead."""
+    lora, scale, rank = ckpt.read_lora(os.path.join(args.pm_path, "lora"))
+    merge = bool(getattr(args, "merge_lora", False)) or getattr(args, "operand_dtype", "f16x2f8") == "fp8"
+    if not merge:
+        cfg.lora_rank = rank
+    clip = getattr(cfg, "clip", None)
+    stats = ckpt.attach_lora(weights, lora, scale, rank, [n for n, *_ in spec_fn(cfg)], canon=canon, merge=merge,
+                             clip_layers_used=clip.layers_used if clip is not None else 1 << 30)
+    args.lora_modules = stats             # {"unmerged", "merged", "skipped"}: how the adapter's modules were applied
+    return stats
+
+
 def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=False):
     with open(reward_config_path) as f:
         reward_cfg = yaml.safe_load(f)
@@ -33,9 +47,7 @@ def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=Fal
         names = [n for n, *_ in weight_specs(cfg)]
         head_names = {n for n in names if n.split(".")[0] in ("value_head", "W_q", "W_k", "W_v", "ca_layernorm")}
         weights = ckpt.read_base_weights(args.pretrain, [n for n in names if n not in head_names])
-        lora_dir = os.path.join(args.pm_path, "lora")
-        lora, scale = ckpt.read_lora(lora_dir)
-        ckpt.merge_lora(weights, lora, scale)
+        _attach_adapter(args, cfg, weights, weight_specs)
         heads = ckpt.read_heads(args.pm_path, cfg, getattr(args, "ft_projector", False))
         weights.update(heads)
         model = RewardModel(cfg, weights=weights,
@@ -61,8 +73,7 @@ def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=Fal
         cfg = ckpt.llava_config_from_hf(args.pretrain, reward_cfg)
         names = [n for n, *_ in llava_weight_specs(cfg)]
         weights = ckpt.read_base_weights(args.pretrain, [n for n in names if n != "value_head.weight"], canon=ckpt.canon_llava_key)
-        lora, scale = ckpt.read_lora(os.path.join(args.pm_path, "lora"))
-        ckpt.merge_lora(weights, lora, scale, canon=ckpt.canon_llava_key)
+        _attach_adapter(args, cfg, weights, llava_weight_specs, canon=ckpt.canon_llava_key)
         weights.update(ckpt.read_heads(args.pm_path, cfg, getattr(args, "ft_projector", False)))
         model = RewardModel(cfg, weights=weights, max_batch=getattr(args, "max_batch", 32),
                             max_seq=getattr(args, "max_seq", 4096), max_crops=getattr(args, "max_crops", 5),
@@ -84,8 +95,7 @@ def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=Fal
         names = [n for n, *_ in qwen_weight_specs(cfg)]
         head_names = {n for n in names if n.split(".")[0] in ("value_head", "W_q", "W_k", "W_v", "ca_layernorm")}
         weights = ckpt.read_base_weights(args.pretrain, [n for n in names if n not in head_names], canon=ckpt.canon_qwen_key)
-        lora, scale = ckpt.read_lora(os.path.join(args.pm_path, "lora"))
-        ckpt.merge_lora(weights, lora, scale, canon=ckpt.canon_qwen_key)
+        _attach_adapter(args, cfg, weights, qwen_weight_specs, canon=ckpt.canon_qwen_key)
         weights.update(ckpt.read_heads(args.pm_path, cfg, getattr(args, "ft_projector", False)))
         model = RewardModel(cfg, weights=weights, max_batch=getattr(args, "max_batch", 32),
                             max_seq=getattr(args, "max_seq", 2048), max_patches=getattr(args, "max_patches", 0),

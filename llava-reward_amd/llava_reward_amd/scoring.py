@@ -85,6 +85,10 @@ def shard_qwen_batch(b: Dict[str, torch.Tensor], rows: slice, image_token_id: in
 def _forward_rows(model, b, rows: slice, device):
     """custom_forward on rows [rows] of a collated batch, whichever backbone the model is (rw_model:343-375)."""
     mt = getattr(model, "model_type", "phi3v")
+    if rows.stop <= rows.start:
+        # fewer rows than ranks (the last partial batch of a drop_last=False loader): this rank has nothing to score, but it must
+        # still enter the all-gather; lr_forward rejects B = 0, so the empty result is made here
+        return torch.empty((0, int(getattr(model, "value_head_dim", 1))), dtype=torch.float32, device=device)
     if mt == "phi3v":
         return model.custom_forward(*_squeeze(b, rows, device))[0]
     if mt == "qwen":

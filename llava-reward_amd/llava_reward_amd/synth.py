@@ -78,6 +78,8 @@ class RewardConfig:
     value_head_dim: int = 1
     general_preference_tau: float = 0.1
     ca_eps: float = 1e-5          # RMSNorm_class_eps passed by load_reward_adaptor (:32)
+    # un-merged LoRA adapter on the decoder linears (eval/reward_adaptor_loader.py:44-45; scripts: --lora_rank 128 --lora_alpha 256)
+    lora_rank: int = 0
 
     def __post_init__(self):
         if not self.short_factor:
@@ -217,6 +219,12 @@ CLIP_PREFIX = "model.vision_embed_tokens.img_processor.vision_model."
 EMB_PREFIX = "model.vision_embed_tokens."
 
 
+def lora_specs(mod: str, n_out: int, n_in: int, rank: int) -> List[Tuple[str, Tuple[int, ...], float, float]]:
+    """The two tensors of an un-merged adapter on linear `mod` (peft LoraLayer: lora_A [r, in], lora_B [out, r]).  The engine
+    takes lora_B PRE-SCALED by lora_alpha / r (include/llava_reward_hip.h `lora_rank`); synthetic tensors are that product."""
+    return [(mod + ".lora_A.weight", (rank, n_in), 0.02, 0.0), (mod + ".lora_B.weight", (n_out, rank), 0.02, 0.0)]
+
+
 def weight_specs(cfg: RewardConfig) -> List[Tuple[str, Tuple[int, ...], float, float]]:
     """(name, shape, std, offset) for every tensor the path reads.  Linear/embedding std 0.02
     mirrors _init_weights (modeling_phi3_v.py:1241-1250); norm weights are 1 + small noise so
@@ -260,6 +268,11 @@ def weight_specs(cfg: RewardConfig) -> List[Tuple[str, Tuple[int, ...], float, f
         s.append((p + "post_attention_layernorm.weight", (D,), 0.05, 1.0))
         s.append((p + "mlp.gate_up_proj.weight", (2 * I, D), 0.02, 0.0))
         s.append((p + "mlp.down_proj.weight", (D, I), 0.02, 0.0))
+        if cfg.lora_rank > 0:           # utils/utils.py:194-222 (LLM targets; the recipes freeze the vision tower)
+            s += lora_specs(p + "self_attn.qkv_proj", 3 * D, D, cfg.lora_rank)
+            s += lora_specs(p + "self_attn.o_proj", D, D, cfg.lora_rank)
+            s += lora_specs(p + "mlp.gate_up_proj", 2 * I, D, cfg.lora_rank)
+            s += lora_specs(p + "mlp.down_proj", D, I, cfg.lora_rank)
     s.append(("model.norm.weight", (D,), 0.05, 1.0))
     # reward heads (rw_model_general_preference.py:314-326)
     if cfg.add_cross_attention:
@@ -323,6 +336,47 @@ def synth_image(seed: int, name: str, h: int, w: int, smooth: bool = False) -> n
     yy, xx = np.mgrid[0:h, 0:w]
     base = np.stack([yy * 255 // max(h - 1, 1), xx * 255 // max(w - 1, 1), (yy + 2 * xx) % 256], axis=-1)
     return ((base & 0xF8) | (noise & 7)).astype(np.uint8)
+
+
+def pad_left(batch: Dict[str, np.ndarray], k: int, pad_token_id: int = None) -> Dict[str, np.ndarray]:
+    """k more LEFT-padding columns on every row of a synth_batch (mask 0): a collated batch never looks like this (its longest
+    row is un-padded) but custom_forward accepts it, and it is the case where `S` and `max(position_ids) + 1` differ."""
+    if k <= 0:
+        return batch
+    ids, mask = batch["input_ids"], batch["attention_mask"]
+    pad = ids[mask == 0][0] if (mask == 0).any() and pad_token_id is None else (0 if pad_token_id is None else pad_token_id)
+    out = dict(batch)
+    out["input_ids"] = np.concatenate([np.full((ids.shape[0], k), pad, dtype=ids.dtype), ids], axis=1)
+    out["attention_mask"] = np.concatenate([np.zeros((ids.shape[0], k), dtype=mask.dtype), mask], axis=1)
+    return out
+
+
+class StandInTokenizer:
+    """Deterministic stand-in for the Phi-3.5-V tokenizer (no tokenizer files exist offline) with the three members
+    inference_process_phi3v uses (eval/reward_adaptor_loader.py:163-167): `apply_chat_template`, `eos_token`, `__call__`.
+    One token per character, ids in [3, 203); the 22 characters the caller strips are the real template's
+    `<|end|>\n<|assistant|>\n`.  Used by tests/golden/make_goldens.py `pair_sample` and the GPU test that replays it."""
+    eos_token = "<|endoftext|>"
+    pad_token = "<|endoftext|>"
+    pad_token_id = 32000
+    eos_token_id = 32000
+    padding_side = "left"
+
+    def apply_chat_template(self, messages, tokenize=False, add_generation_prompt=True):
+        return "<|user|>\n" + messages[0]["content"] + "<|end|>\n<|assistant|>\n"
+
+    def __call__(self, text):
+        class _Enc:
+            pass
+        r = _Enc()
+        r.input_ids = [3 + (ord(ch) % 200) for ch in text]
+        return r
+
+
+# the caption of the reference's own sample pair (eval/simple_inference.py:21, data/sample_test/pairwise_sample.json): input data
+SAMPLE_CAPTION = ("perfect white haired egyptian goddess wearing white dove wings, warframe armor, regal, attractive, ornate, sultry, "
+                  "beautiful, ice queen, half asian, pretty face, blue eyes, detailed, scifi platform, 4 k, ultra realistic, epic "
+                  "lighting, illuminated, cinematic, masterpiece, art by akihito tsukushi, voidstar")
 
 
 def synth_batch(cfg: RewardConfig, seed: int, caption_lens: List[int], grids, max_crops: int = None,
@@ -393,6 +447,7 @@ class LlavaConfig:
     add_cross_attention: bool = False          # the llava branch has no SkipCA (rw_model:376-397)
     value_head_dim: int = 1
     general_preference_tau: float = 0.1
+    lora_rank: int = 0                         # un-merged adapter on q/k/v/o/gate/up/down of every layer (utils/utils.py:243-262)
 
     def __post_init__(self):
         if not self.is_general_preference:
@@ -503,6 +558,11 @@ def llava_weight_specs(cfg: LlavaConfig) -> List[Tuple[str, Tuple[int, ...], flo
         s.append((q + "mlp.gate_proj.weight", (I, D), 0.02, 0.0))
         s.append((q + "mlp.up_proj.weight", (I, D), 0.02, 0.0))
         s.append((q + "mlp.down_proj.weight", (D, I), 0.02, 0.0))
+        if cfg.lora_rank > 0:
+            for nm, n_out, n_in in (("self_attn.q_proj", cfg.heads * hd, D), ("self_attn.k_proj", cfg.kv_heads * hd, D),
+                                    ("self_attn.v_proj", cfg.kv_heads * hd, D), ("self_attn.o_proj", D, cfg.heads * hd),
+                                    ("mlp.gate_proj", I, D), ("mlp.up_proj", I, D), ("mlp.down_proj", D, I)):
+                s += lora_specs(q + nm, n_out, n_in, cfg.lora_rank)
     s.append(("language_model.model.norm.weight", (D,), 0.05, 1.0))
     s.append(("value_head.weight", (cfg.value_head_dim, D), 1.0 / math.sqrt(D), 0.0))
     return s
@@ -604,6 +664,7 @@ class QwenConfig:
     value_head_dim: int = 1
     general_preference_tau: float = 0.1
     ca_eps: float = 1e-6              # RMSNorm_class_eps for qwen (eval/reward_adaptor_loader.py:68)
+    lora_rank: int = 0                # un-merged adapter on q/k/v/o/gate/up/down of every decoder layer (utils/utils.py:223-242)
 
     def __post_init__(self):
         if not self.is_general_preference:
@@ -759,6 +820,11 @@ def qwen_weight_specs(cfg: QwenConfig) -> List[Tuple[str, Tuple[int, ...], float
         s.append((q + "mlp.gate_proj.weight", (I, D), 0.02, 0.0))
         s.append((q + "mlp.up_proj.weight", (I, D), 0.02, 0.0))
         s.append((q + "mlp.down_proj.weight", (D, I), 0.02, 0.0))
+        if cfg.lora_rank > 0:
+            for nm, n_out, n_in in (("self_attn.q_proj", cfg.heads * hd, D), ("self_attn.k_proj", cfg.kv_heads * hd, D),
+                                    ("self_attn.v_proj", cfg.kv_heads * hd, D), ("self_attn.o_proj", D, cfg.heads * hd),
+                                    ("mlp.gate_proj", I, D), ("mlp.up_proj", I, D), ("mlp.down_proj", D, I)):
+                s += lora_specs(q + nm, n_out, n_in, cfg.lora_rank)
     s.append(("model.norm.weight", (D,), 0.05, 1.0))
     if cfg.add_cross_attention:
         # W_q / W_k exist in the checkpoint but cannot influence the reward: every un-masked K row is the same

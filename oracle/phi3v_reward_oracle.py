@@ -40,6 +40,18 @@ def _lin(x, w, b=None, opr=Ident):
     return F.linear(opr(x), opr(w), b)
 
 
+def proj(W, name: str, x, b=None, opr=Ident):
+    """Linear layer `name`, plus its LoRA adapter when W carries one, evaluated UN-MERGED as the reference runs it
+    (eval/reward_adaptor_loader.py:44-45 model.load_adapter; third party peft==0.13.2, tuners/lora/layer.py Linear.forward:
+    result = base_layer(x) + lora_B(lora_A(dropout(x))) * scaling, dropout inactive in eval, scaling = lora_alpha / r).
+    W["lora_scaling"] holds the scaling (absent = 1.0: lora_B already multiplied by it, as the engine takes it)."""
+    y = _lin(x, W[name + ".weight"], b, opr)
+    a = W.get(name + ".lora_A.weight")
+    if a is not None:
+        y = y + F.linear(F.linear(x, a), W[name + ".lora_B.weight"]) * float(W.get("lora_scaling", 1.0))
+    return y
+
+
 class W8A8Round:
     """Operand rounding of the W8A8 mode (lr_model_desc.w8a8, BASELINE configs[4]): activations are stored in f16 (`act`), and in
     front of every GEMM with K % 128 == 0 the rows of both operands go to OCP e4m3 with one fp32 scale per row, max|x| / 448
@@ -148,11 +160,12 @@ def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
     return w * (x * torch.rsqrt(var + eps))
 
 
-def su_rope_cos_sin(position_ids: torch.Tensor, cfg):
-    """PHI:446-476 Phi3SuScaledRotaryEmbedding.forward: short factors unless max(pos)+1 > original max;
-    cos/sin of cat(freqs,freqs) scaled by sqrt(1 + ln(max_pos/orig)/ln(orig))."""
+def su_rope_cos_sin(position_ids: torch.Tensor, cfg, seq_len: Optional[int] = None):
+    """PHI:446-476 Phi3SuScaledRotaryEmbedding.forward: short factors unless seq_len > original max; the attention layers pass
+    seq_len = kv_seq_len = the padded length S (PHI:673, :1081; use_cache=False), so `max(position_ids)+1` (PHI:448) is only the
+    fallback for callers that pass none; cos/sin of cat(freqs,freqs) scaled by sqrt(1 + ln(max_pos/orig)/ln(orig))."""
     hd = cfg.head_dim
-    seq_len = int(position_ids.max()) + 1
+    seq_len = seq_len or int(position_ids.max()) + 1
     fac = cfg.long_factor if seq_len > cfg.orig_max_pos else cfg.short_factor
     ext = torch.tensor(fac, dtype=torch.float32)
     inv_shape = torch.arange(0, hd, 2, dtype=torch.int64).float() / hd
@@ -187,7 +200,7 @@ def decoder_layer(W, l: int, x, mask4d, cos, sin, cfg, opr=Ident):
     B, S, D = x.shape
     nh, hd = cfg.heads, cfg.head_dim
     h = rms_norm(x, W[p + "input_layernorm.weight"], cfg.rms_eps)
-    qkv = _lin(h, W[p + "self_attn.qkv_proj.weight"], None, opr)
+    qkv = proj(W, p + "self_attn.qkv_proj", h, None, opr)
     q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
     q = q.view(B, S, nh, hd).transpose(1, 2)
     k = k.view(B, S, nh, hd).transpose(1, 2)
@@ -198,11 +211,11 @@ def decoder_layer(W, l: int, x, mask4d, cos, sin, cfg, opr=Ident):
     att = torch.matmul(opr(q), opr(k).transpose(2, 3)) / math.sqrt(hd) + mask4d
     att = torch.softmax(att, dim=-1, dtype=torch.float32)
     o = torch.matmul(opr(att), opr(v)).transpose(1, 2).reshape(B, S, D)
-    x = x + _lin(o, W[p + "self_attn.o_proj.weight"], None, opr)
+    x = x + proj(W, p + "self_attn.o_proj", o, None, opr)
     h = rms_norm(x, W[p + "post_attention_layernorm.weight"], cfg.rms_eps)
-    gu = _lin(h, W[p + "mlp.gate_up_proj.weight"], None, opr)
+    gu = proj(W, p + "mlp.gate_up_proj", h, None, opr)
     gate, up = gu.chunk(2, dim=-1)
-    x = x + _lin(up * F.silu(gate), W[p + "mlp.down_proj.weight"], None, opr)
+    x = x + proj(W, p + "mlp.down_proj", up * F.silu(gate), None, opr)
     return x
 
 
@@ -244,7 +257,7 @@ def custom_forward(W: Dict[str, torch.Tensor], cfg, input_ids, attention_mask, p
         taps["clip_out"], taps["proj"], taps["embeds"] = feats, proj, x.clone()
     # PHI:1468-1500 decoder stack + final norm
     mask4d = causal_padding_mask(attention_mask)
-    cos, sin = su_rope_cos_sin(position_ids, cfg)
+    cos, sin = su_rope_cos_sin(position_ids, cfg, seq_len=S)
     states = []
     for l in range(cfg.layers):
         states.append(x)

@@ -102,9 +102,9 @@ def decoder_layer(W, l, x, mask4d, cos, sin, cfg, opr=Ident):
     B, S, D = x.shape
     H, KV, hd = cfg.heads, cfg.kv_heads, cfg.head_dim
     h = po.rms_norm(x, W[p + "input_layernorm.weight"], cfg.rms_eps)
-    q = po._lin(h, W[p + "self_attn.q_proj.weight"], W[p + "self_attn.q_proj.bias"], opr).view(B, S, H, hd).transpose(1, 2)
-    k = po._lin(h, W[p + "self_attn.k_proj.weight"], W[p + "self_attn.k_proj.bias"], opr).view(B, S, KV, hd).transpose(1, 2)
-    v = po._lin(h, W[p + "self_attn.v_proj.weight"], W[p + "self_attn.v_proj.bias"], opr).view(B, S, KV, hd).transpose(1, 2)
+    q = po.proj(W, p + "self_attn.q_proj", h, W[p + "self_attn.q_proj.bias"], opr).view(B, S, H, hd).transpose(1, 2)
+    k = po.proj(W, p + "self_attn.k_proj", h, W[p + "self_attn.k_proj.bias"], opr).view(B, S, KV, hd).transpose(1, 2)
+    v = po.proj(W, p + "self_attn.v_proj", h, W[p + "self_attn.v_proj.bias"], opr).view(B, S, KV, hd).transpose(1, 2)
     c, s = cos[:, None], sin[:, None]
     q = q * c + po.rotate_half(q) * s
     k = k * c + po.rotate_half(k) * s
@@ -113,11 +113,11 @@ def decoder_layer(W, l, x, mask4d, cos, sin, cfg, opr=Ident):
     att = torch.matmul(opr(q), opr(k).transpose(2, 3)) * hd ** -0.5 + mask4d
     att = torch.softmax(att, dim=-1, dtype=torch.float32)
     o = torch.matmul(opr(att), opr(v)).transpose(1, 2).reshape(B, S, H * hd)
-    x = x + po._lin(o, W[p + "self_attn.o_proj.weight"], None, opr)
+    x = x + po.proj(W, p + "self_attn.o_proj", o, None, opr)
     h = po.rms_norm(x, W[p + "post_attention_layernorm.weight"], cfg.rms_eps)
-    gate = po._lin(h, W[p + "mlp.gate_proj.weight"], None, opr)
-    up = po._lin(h, W[p + "mlp.up_proj.weight"], None, opr)
-    return x + po._lin(F.silu(gate) * up, W[p + "mlp.down_proj.weight"], None, opr)
+    gate = po.proj(W, p + "mlp.gate_proj", h, None, opr)
+    up = po.proj(W, p + "mlp.up_proj", h, None, opr)
+    return x + po.proj(W, p + "mlp.down_proj", F.silu(gate) * up, None, opr)
 
 
 def skip_ca(W, cfg, last: torch.Tensor, embeds: torch.Tensor, input_ids: torch.Tensor) -> torch.Tensor:

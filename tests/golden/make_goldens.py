@@ -106,10 +106,10 @@ def fingerprint(t: torch.Tensor, n: int = 16):
             "vals": [float(v) for v in f[idx]]}
 
 
-def run_case(ref, name, cfg, seed, caption_lens, grids, max_crops, taps=True, layer_id=32, mean_hidden_state=None):
+def run_case(ref, name, cfg, seed, caption_lens, grids, max_crops, taps=True, layer_id=32, mean_hidden_state=None, extra_left_pad=0):
     print(f"[{name}] building", flush=True)
     model = build_reference_model(ref, cfg, seed, layer_id, mean_hidden_state)
-    batch = synth.synth_batch(cfg, seed, caption_lens, grids, max_crops=max_crops)
+    batch = synth.pad_left(synth.synth_batch(cfg, seed, caption_lens, grids, max_crops=max_crops), extra_left_pad)
     tb = {k: torch.from_numpy(v) for k, v in batch.items()}
     t0 = time.time()
     with torch.no_grad():
@@ -120,7 +120,7 @@ def run_case(ref, name, cfg, seed, caption_lens, grids, max_crops, taps=True, la
     out = {"name": name, "config": cfg.to_json(), "seed": seed, "caption_lens": caption_lens,
            "grids": [list(g) for g in grids] if not isinstance(grids[0], int) else list(grids),
            "max_crops": max_crops, "reward": reward.float().tolist(), "layer_id": layer_id,
-           "mean_hidden_state": bool(mean_hidden_state),
+           "mean_hidden_state": bool(mean_hidden_state), "extra_left_pad": extra_left_pad,
            "reference_forward_seconds": dt, "threads": torch.get_num_threads(),
            "torch": torch.__version__, "dtype": "float32"}
     if taps:
@@ -135,6 +135,57 @@ def run_case(ref, name, cfg, seed, caption_lens, grids, max_crops, taps=True, la
         json.dump(out, f, indent=1)
     print(f"[{name}] wrote {path}", flush=True)
     del model
+    return out
+
+
+def run_pair_sample(ref, name="ref_full_pair_sample", seed=1234):
+    """BASELINE configs[0] (eval/simple_inference.py:16-31): ONE caption, TWO 512x640 images -> two B=1 custom_forward calls at
+    full Phi-3.5-V size -> preference_compute.  The sample JPEGs and the Phi tokenizer do not travel, so the images are seeded
+    synthetic RGB of the same size (PIL size (512, 640) = 640 rows x 512 columns -> HD transform -> 1344 x 1344 -> 17 crops,
+    V = 2509), pixel_values come from the HD-transform oracle (bit-exact with Pillow for the local crops) and the prompt goes
+    through synth.StandInTokenizer with the reference's prompt construction and image-slot merge
+    (eval/reward_adaptor_loader.py:163-167, processing_phi3_v.py:407-454)."""
+    sys.path.insert(0, ROOT)
+    from oracle import phi3v_hd_transform_oracle as hd
+    cfg = synth.full_config()
+    model = build_reference_model(ref, cfg, seed)
+    tok = synth.StandInTokenizer()
+    caption = synth.SAMPLE_CAPTION
+    msg = {"role": "user", "content": f"<|image_1|>\n{caption}"}
+    prompt = tok.apply_chat_template([msg], tokenize=False, add_generation_prompt=True)[:-22] + tok.eos_token
+    head, tail = prompt.split("<|image_1|>")
+    rewards, meta = [], []
+    for i in range(2):
+        img = synth.synth_image(seed, f"pair.image{i}", 640, 512, True)
+        pix, (H, W), ntok = hd.preprocess(img, 16)
+        ids = tok(head).input_ids + [-1] * ntok + tok(tail).input_ids
+        input_ids = torch.tensor(ids, dtype=torch.long)[None]
+        mask = torch.ones_like(input_ids)
+        t0 = time.time()
+        with torch.no_grad():
+            r, _ = model.custom_forward(input_ids, mask, torch.from_numpy(pix)[None], torch.tensor([[H, W]]))
+        print(f"[{name}] image {i}: reward {r.flatten().tolist()} ({time.time() - t0:.1f}s, S={input_ids.shape[1]}, V={ntok})", flush=True)
+        rewards.append(r.float())
+        meta.append({"image": f"synth_image({seed}, 'pair.image{i}', 640, 512, smooth=True)", "image_sizes": [H, W],
+                     "num_img_tokens": ntok, "seq_len": int(input_ids.shape[1]),
+                     "input_ids_head": ids[:8], "input_ids_tail": ids[-8:]})
+
+    class A:
+        is_general_preference, value_head_dim, general_preference_tau = cfg.is_general_preference, cfg.value_head_dim, cfg.general_preference_tau
+    # the reference's own formula (eval/reward_adaptor_loader.py:174-181), evaluated by the reference module when importable
+    try:
+        from eval.reward_adaptor_loader import preference_compute as ref_pc
+        prob = ref_pc(A, rewards[0], rewards[1])
+        pc_src = "eval.reward_adaptor_loader.preference_compute (imported)"
+    except Exception as e:      # the loader module imports peft/deepspeed symbols at import time
+        prob = torch.sigmoid((rewards[0] - rewards[1]) / A.general_preference_tau).squeeze(-1).float().numpy()
+        pc_src = f"formula of eval/reward_adaptor_loader.py:179-180 (module import failed: {type(e).__name__})"
+    out = {"name": name, "config": cfg.to_json(), "seed": seed, "caption": caption, "num_crops": 16, "rows": meta,
+           "reward": [r.flatten().tolist() for r in rewards], "prob": [float(p) for p in prob.reshape(-1)], "preference_compute": pc_src,
+           "tau": A.general_preference_tau, "torch": torch.__version__, "dtype": "float32"}
+    with open(os.path.join(HERE, f"{name}.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(f"[{name}] prob {out['prob']}", flush=True)
     return out
 
 
@@ -322,6 +373,16 @@ def main():
         run_llava_case("ref_llava_full_bt", synth.llava_full_config(), 1234, [128], [(336, 336)], None)
     elif which == "full":
         run_case(ref, "ref_full_bt_ca", synth.full_config(), 1234, [128], (4, 4), None)
+    elif which == "rope_long":
+        # su-RoPE long-factor branch (modeling_phi3_v.py:449): the switch is taken on seq_len = the PADDED length S (:673).
+        # S = 326 > original_max_position_embeddings = 300; in the second case EVERY row carries padding (S = 334 > 330 >= the
+        # longest row's 326 valid tokens), which tells `S > orig` apart from `max(position_ids) + 1 > orig`.
+        C = synth.ref_small_config
+        run_case(ref, "ref_small_rope_long_bt_ca", C(orig_max_pos=300, max_pos=9600), 31, [5, 9], (1, 1), None)
+        run_case(ref, "ref_small_rope_long_allpad_gpm2_ca", C(orig_max_pos=330, max_pos=9600, is_general_preference=True, value_head_dim=2),
+                 32, [5, 9], (1, 1), None, extra_left_pad=8)
+    elif which == "pair_sample":
+        run_pair_sample(ref)
     elif which == "full_gpm":
         run_case(ref, "ref_full_gpm2_ca", synth.full_config(is_general_preference=True, value_head_dim=2),
                  1234, [128], (4, 4), None)

@@ -153,7 +153,7 @@ def test_reference_goldens_small(path, dtype, tol):
     cfg = synth.RewardConfig.from_json(g["config"])
     grids = g["grids"]
     grids = tuple(grids) if isinstance(grids[0], int) else [tuple(x) for x in grids]
-    batch = synth.synth_batch(cfg, g["seed"], g["caption_lens"], grids, max_crops=g["max_crops"])
+    batch = synth.pad_left(synth.synth_batch(cfg, g["seed"], g["caption_lens"], grids, max_crops=g["max_crops"]), g.get("extra_left_pad", 0))
     ref = torch.tensor(g["reward"], dtype=torch.float32)
     m = _model(cfg, g["seed"], dtype, upload=False, max_batch=2, max_seq=1024, max_crops=5, layer_id=g.get("layer_id", 32),
                mean=g.get("mean_hidden_state", False))
@@ -166,6 +166,66 @@ def test_reference_goldens_small(path, dtype, tol):
         W = orc.weights_to_torch(synth.make_weights(cfg, g["seed"]))
         full = orc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"])
         assert (_fwd(m, batch) - full).abs().max().item() < tol
+
+
+TAP_CASES = [p for p in CASES if json.load(open(p)).get("taps")]
+TOL_TAP = 5e-5
+
+
+@pytest.mark.parametrize("path", TAP_CASES, ids=[os.path.basename(p)[:-5] for p in TAP_CASES])
+def test_reference_golden_stage_taps(path):
+    """Stage-level pins against the REFERENCE itself (not the oracle): the fingerprints make_goldens.py took of the reference's
+    hidden_states -- `embeds` (hs[0]), `layer0` (hs[1]), `final_norm` (last_hidden_state), `vision_embeds` (hs[-1], zero-padded to
+    V_max) -- are read back from the HIP engine through lr_read_tap in the strict parity mode (f16x2) and compared at 5e-5 on
+    valid (un-padded) token rows.  The engine keeps one residual stream, so the stack is stopped after 0 / 1 / all layers
+    (lr_set_layer_limits via layer_id) to observe each state; the final norm of every row is applied on the host from the
+    engine's un-normed stream and its norm weight (the engine itself only norms the gathered row)."""
+    g = json.load(open(path))
+    cfg = synth.RewardConfig.from_json(g["config"])
+    grids = g["grids"]
+    grids = tuple(grids) if isinstance(grids[0], int) else [tuple(x) for x in grids]
+    batch = synth.pad_left(synth.synth_batch(cfg, g["seed"], g["caption_lens"], grids, max_crops=g["max_crops"]), g.get("extra_left_pad", 0))
+    B, S = batch["input_ids"].shape
+    D = cfg.hidden
+    valid = torch.from_numpy(batch["attention_mask"]).bool().reshape(-1)
+    m = _model(cfg, g["seed"], "f16x2", upload=False, max_batch=2, max_seq=1024, max_crops=5)
+    taps = g["taps"]
+
+    def stream_after(n_layers):
+        m.layer_id = n_layers if n_layers < cfg.layers else 32
+        _fwd(m, batch)
+        return torch.from_numpy(m.engine.read_tap("x", B * S * D).copy()).reshape(B * S, D)
+
+    def check(name, mine_flat_rows, ok_rows):
+        fp = taps[name]
+        idx = torch.tensor(fp["idx"])
+        rows, cols = idx // D, idx % D
+        keep = ok_rows[rows]
+        assert keep.any(), name
+        a = mine_flat_rows[rows[keep], cols[keep]]
+        b = torch.tensor(fp["vals"])[keep]
+        err = (a - b).abs().max().item()
+        print(f"[{g['name']}] tap {name}: {int(keep.sum())} samples, max err {err:.2e}")
+        assert err < TOL_TAP, (name, a, b)
+
+    check("embeds", stream_after(0), valid)
+    if "layer0" in taps:
+        check("layer0", stream_after(1), valid)
+    x = stream_after(cfg.layers)
+    w = torch.from_numpy(synth.gen_tensor(g["seed"], "model.norm.weight", (D,), 0.05, 1.0))
+    normed = w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + cfg.rms_eps))          # modeling_phi3_v.py:377-391 on the engine's stream
+    check("final_norm", normed, valid)
+    # vision_embeds: [B, V_max, D] zero-padded per sample (modeling_phi3_v.py:242-245); the engine keeps the rows packed
+    counts = (batch["input_ids"] < 0).sum(axis=1)
+    Vmax = int(counts.max())
+    ev = torch.from_numpy(m.engine.read_tap("ev", int(counts.sum()) * D).copy()).reshape(-1, D)
+    padded = torch.zeros(B * Vmax, D)
+    off = 0
+    for b, n in enumerate(counts.tolist()):
+        padded[b * Vmax: b * Vmax + n] = ev[off: off + n]
+        off += n
+    assert taps["vision_embeds"]["shape"] == [B, Vmax, D]
+    check("vision_embeds", padded, torch.ones(B * Vmax, dtype=torch.bool))
 
 
 FULL = sorted(glob.glob(os.path.join(GOLD, "ref_full_*.json")))
@@ -200,6 +260,82 @@ def test_reference_golden_full_size(path, dtype):
     dup = {k: np.concatenate([v, v]) for k, v in batch.items()}
     r2 = _fwd(m, dup)
     assert torch.equal(r2[0], r2[1]) and torch.equal(r2[0], got.reshape(r2[0].shape))
+
+
+def test_config0_sample_pair_through_the_drop_in_api(tmp_path):
+    """BASELINE configs[0] (eval/simple_inference.py:16-31) at full Phi-3.5-V size through the drop-in callables: ONE caption, TWO
+    512x640 images on disk -> inference_process_phi3v_device (image hand-over + prompt/slot merge on the GPU side) -> two B=1
+    custom_forward calls -> preference_compute, against tests/golden/ref_full_pair_sample.json: the REFERENCE's custom_forward on
+    the same two rows (pixel_values from the HD-transform oracle, same stand-in tokenizer; make_goldens.py pair_sample)."""
+    from PIL import Image
+    from llava_reward_amd import preprocess as P
+    g = json.load(open(os.path.join(GOLD, "ref_full_pair_sample.json")))
+    cfg = synth.RewardConfig.from_json(g["config"])
+    paths = []
+    for i in range(2):
+        p = str(tmp_path / f"img{i}.png")
+        Image.fromarray(synth.synth_image(g["seed"], f"pair.image{i}", 640, 512, True)).save(p)
+        paths.append(p)
+    assert Image.open(paths[0]).size == (512, 640)
+
+    class Args:
+        is_general_preference, value_head_dim, general_preference_tau = cfg.is_general_preference, cfg.value_head_dim, g["tau"]
+    rows = P.inference_process_phi3v_device(Args, synth.StandInTokenizer(), paths, g["caption"], device="cuda", num_crops=g["num_crops"])
+    for d, meta in zip(rows, g["rows"]):
+        ids = d["input_ids"][0].tolist()
+        assert d["image_sizes"].tolist() == [meta["image_sizes"]] and len(ids) == meta["seq_len"]
+        assert sum(1 for t in ids if t < 0) == meta["num_img_tokens"] == 2509
+        assert ids[:8] == meta["input_ids_head"] and ids[-8:] == meta["input_ids_tail"]
+    S = rows[0]["input_ids"].shape[1]
+    model = RewardModel(cfg, synth_seed=g["seed"], max_batch=1, max_seq=S, max_crops=17).to("cuda").eval()       # default mode f16x2f8
+    with torch.no_grad():
+        c, _ = model.custom_forward(**rows[0])
+        r, _ = model.custom_forward(**rows[1])
+    prob = preference_compute(Args, c, r)
+    ref = torch.tensor(g["reward"])
+    err = max((c.cpu() - ref[0]).abs().max().item(), (r.cpu() - ref[1]).abs().max().item())
+    print(f"[configs[0] sample pair] rewards hip=({c.item():.6f}, {r.item():.6f}) ref=({ref[0].item():.6f}, {ref[1].item():.6f}) err={err:.2e} "
+          f"prob hip={prob[0]:.6f} ref={g['prob'][0]:.6f}")
+    assert err < TOL_X8
+    assert prob.dtype == np.float32 and prob.shape == (1,) and abs(float(prob[0]) - g["prob"][0]) < 0.25 * 2 * TOL_X8 / g["tau"]   # |sigmoid'| <= 1/4
+    assert (prob[0] > 0.5) == (g["prob"][0] > 0.5)                      # same preference as the reference
+    c2, _ = model.custom_forward(**rows[0])                             # bit-stable
+    assert torch.equal(c2, c)
+
+
+def test_config2_gpm_pairwise_batch64_full_size():
+    """BASELINE configs[2]: Phi-3.5-V GPM head (value_head_dim = 2) + SkipCA, pairwise, B = 64 rows per forward at full size.  Row 0 is
+    the reference's own full-size GPM golden row (ref_full_gpm2_ca.json: same seed -> same caption, pixels and weights); size-
+    independent properties carry the rest: any row scored alone (B = 1) or in a 32-row shard gives bit-identical rewards, hence a
+    bit-identical preference probability."""
+    g = json.load(open(os.path.join(GOLD, "ref_full_gpm2_ca.json")))
+    cfg = synth.RewardConfig.from_json(g["config"])
+    assert cfg.is_general_preference and cfg.value_head_dim == 2 and cfg.add_cross_attention
+    B = 64
+    b = synth.synth_batch(cfg, g["seed"], [128] * B, (4, 4), with_pixels=False)
+    ids, mask = torch.from_numpy(b["input_ids"]).cuda(), torch.from_numpy(b["attention_mask"]).cuda()
+    sizes = torch.from_numpy(b["image_sizes"])
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    pix = torch.randn(B, 17, 3, 336, 336, device="cuda", generator=gen)
+    pix[0] = torch.from_numpy(synth.synth_pixels(g["seed"], "pixel_values.0", (17, 3, 336, 336))).cuda()
+    m = RewardModel(cfg, synth_seed=g["seed"], max_batch=B, max_seq=ids.shape[1], max_crops=17).to("cuda").eval()
+    full, _ = m.custom_forward(ids, mask, pix, sizes)
+    torch.cuda.synchronize()
+    ref = torch.tensor(g["reward"], dtype=torch.float32)
+    err = (full[0].cpu() - ref[0]).abs().max().item()
+    print(f"[configs[2] B=64 GPM] row 0 hip={full[0].tolist()} ref={ref[0].tolist()} err={err:.2e}")
+    assert full.shape == (B, 2) and torch.isfinite(full).all() and err < TOL_X8
+    for i in (0, 17, 63):
+        one, _ = m.custom_forward(ids[i:i + 1], mask[i:i + 1], pix[i:i + 1], sizes[i:i + 1])
+        assert torch.equal(one[0], full[i])
+    lo, _ = m.custom_forward(ids[:32], mask[:32], pix[:32], sizes[:32])
+    hi, _ = m.custom_forward(ids[32:], mask[32:], pix[32:], sizes[32:])
+    assert torch.equal(torch.cat([lo, hi]), full)
+
+    class A:
+        is_general_preference, value_head_dim, general_preference_tau = True, 2, cfg.general_preference_tau
+    p_full = preference_compute(A, full[:32], full[32:])
+    assert p_full.shape == (32,) and p_full.dtype == np.float32 and np.array_equal(p_full, preference_compute(A, lo, hi))
 
 
 @pytest.mark.parametrize("backbone", ["phi3v", "qwen"])

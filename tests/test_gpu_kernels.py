@@ -320,6 +320,47 @@ def test_gemm_split_operand_matches_fp32(lib, tile):
     assert (got - sref).abs().max().item() < 4e-6 * sref.abs().max().item() + 1e-6
 
 
+@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("k2,b_exact", [(64, True), (128, True), (128, False)])
+def test_gemm_k_extension_adapter(lib, split, k2, b_exact):
+    """K-extension of the deep-pipelined GEMM (un-merged LoRA adapter, lr_model_desc.lora_rank): C = A W^T + T B^T with T, B
+    walked as extra K segments from their own buffers (t_hi x B, t_lo x B, t_hi x B_lo).  Against fp64 on the un-rounded
+    operands; shapes with more tiles than one workgroup walks and K segments of 1-2 K-tiles between long ones."""
+    code, tdt = L.LR_DT_F16, torch.float16
+    for (M, N, K) in [(700, 512, 384), (4100, 768, 1024)]:
+        A32, T32 = rnd((M, K), 71), rnd((M, k2), 72, 0.7)
+        W = rnd((N, K), 73, 0.05).to(torch.bfloat16).to(tdt)
+        B32 = rnd((N, k2), 74, 0.05)
+        if b_exact:
+            B32 = B32.to(torch.bfloat16).float()
+        Bh, Bl = _split(B32, tdt)
+        bias = rnd((N,), 75)
+        if split:
+            ah, al = _split(A32, tdt)
+            th, tl = _split(T32, tdt)
+            A, T = torch.cat([ah, al], dim=1).contiguous(), torch.cat([th, tl], dim=1).contiguous()
+            Aeff, Teff = A32.double(), T32.double()
+        else:
+            A, T = A32.to(tdt), T32.to(tdt)
+            Aeff, Teff = A.double(), T.double()
+        Beff = B32.double() if (split and not b_exact) else Bh.double()
+        ref = (Aeff @ W.double().t() + Teff @ Beff.t() + bias.double()).float()
+        out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+        Blo = P(Bl) if (split and not b_exact) else P(None)
+        assert lib.lr_op_gemm_bt_ext(P(A), P(W), P(T), P(Bh.contiguous()), Blo, P(out), P(bias), M, N, K, k2, split, L.EPI_OUT_F32, 0, code, stream()) == 0
+        err = (out - ref).abs().max().item() / ref.abs().max().item()
+        print(f"[k-extension split={split} k2={k2} exact={b_exact} {M}x{N}x{K}] rel err {err:.2e}")
+        assert err < (3e-6 if split else 2e-5)          # single-pass: operands rounded identically, only the summation order differs
+        # the extension is really in: without it the result is far away
+        base = (Aeff @ W.double().t() + bias.double()).float()
+        assert (out - base).abs().max().item() > 100 * (out - ref).abs().max().item()
+        if split:                                        # operand-typed output [hi | lo] through the same K loop
+            o2 = torch.zeros(M, 2 * N, device="cuda", dtype=tdt)
+            assert lib.lr_op_gemm_bt_ext(P(A), P(W), P(T), P(Bh.contiguous()), Blo, P(o2), P(bias), M, N, K, k2, 1, L.EPI_OUT_OP, 0, code, stream()) == 0
+            got = o2[:, :N].float() + o2[:, N:].float()
+            assert (got - ref).abs().max().item() < 4e-6 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("S", [333, 1300])                # >= 1024: ping-pong schedule (head_dim 64 / 96)
 @pytest.mark.parametrize("hd,causal,group", [(96, True, 1), (64, False, 1), (128, True, 4), (96, False, 1)])
 def test_attention_split_operand_matches_fp32(lib, hd, causal, group, S):

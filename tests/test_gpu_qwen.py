@@ -171,7 +171,7 @@ def test_qwen_training_flag_and_errors():
 CASES = sorted(glob.glob(os.path.join(GOLD, "ref_qwen_tiny_*.json")) + glob.glob(os.path.join(GOLD, "ref_qwen_quirk_*.json")))
 
 
-@pytest.mark.parametrize("dtype", ["f16x2", "f16"])
+@pytest.mark.parametrize("dtype", ["f16x2", "f16x2f8", "f16"])
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-5] for p in CASES])
 def test_qwen_reference_goldens(path, dtype):
     g = json.load(open(path))
@@ -182,7 +182,8 @@ def test_qwen_reference_goldens(path, dtype):
     got = _fwd(m, batch).reshape(ref.shape)
     err = (got - ref).abs().max().item()
     print(f"[{g['name']} {dtype}] max |reward err| vs reference = {err:.3e}")
-    assert err < 1e-4 if dtype == "f16x2" else _close(got, ref)
+    # f16x2f8 is the shipped default: e4m3 residual pass wherever K % 128 == 0 on the deep-pipelined kernel (3e-4 bar)
+    assert err < 1e-4 if dtype == "f16x2" else err < 3e-4 if dtype == "f16x2f8" else _close(got, ref)
 
 
 FULL = sorted(glob.glob(os.path.join(GOLD, "ref_qwen_full_*.json")))

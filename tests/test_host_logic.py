@@ -24,7 +24,7 @@ def test_header_symbols_are_exported():
     declared = set(re.findall(r"^(?:int|size_t|const char\*)\s+(lr_\w+)\(", hdr, flags=re.M))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     lib = _lib.load()                      # resolves every symbol; no compute without a GPU
-    assert lib.lr_abi_version() == 5
+    assert lib.lr_abi_version() == 6
     assert _lib.ModelDesc.struct_size.offset == 0
 
 
@@ -92,15 +92,48 @@ def test_load_reward_adaptor_contract(tmp_path):
     assert model.model_type == "phi3v" and model.device.type == "cpu"
     assert model.eval() is model and model.to("cpu") is model
     w = model._weights
-    # LoRA merged: W + (alpha/r) B A
+    # the decoder adapter stays UN-MERGED, as the reference runs it (:44-45): A as is, B pre-scaled by alpha / r, base weights untouched
     mod = "model.layers.0.self_attn.qkv_proj"
-    exp = W[mod + ".weight"] + 2.0 * lora[f"base_model.model.{mod}.lora_B.weight"] @ lora[f"base_model.model.{mod}.lora_A.weight"]
-    assert torch.allclose(w[mod + ".weight"], exp, atol=1e-6)
+    A, Bm = lora[f"base_model.model.{mod}.lora_A.weight"], lora[f"base_model.model.{mod}.lora_B.weight"]
+    assert model.config.lora_rank == 4 and args.lora_modules == {"unmerged": 2, "merged": 0, "skipped": 0}
+    assert torch.equal(w[mod + ".lora_A.weight"], A) and torch.equal(w[mod + ".lora_B.weight"], 2.0 * Bm)
+    assert torch.equal(w[mod + ".weight"].float(), W[mod + ".weight"])
     assert torch.equal(w["model.layers.1.self_attn.qkv_proj.weight"].float(), W["model.layers.1.self_attn.qkv_proj.weight"])
+    # linears the adapter does not target: zero adapters (the engine expects every slot)
+    z = w["model.layers.1.self_attn.qkv_proj.lora_B.weight"]
+    assert z.shape == (3 * cfg.hidden, 4) and not z.any() and not w["model.layers.0.mlp.gate_up_proj.lora_A.weight"].any()
+    # debug switch: merged on the host in fp32, W + (alpha/r) B A, no adapter tensors
+    args_m = types.SimpleNamespace(pm_path=pm, pretrain=pre, cache_dir=None, ft_projector=True, disable_fast_tokenizer=False, merge_lora=True)
+    wm = load_reward_adaptor(args_m, "phi3v", os.path.join(pm, "reward_config.yaml"))[1]._weights
+    assert torch.allclose(wm[mod + ".weight"], W[mod + ".weight"] + 2.0 * Bm @ A, atol=1e-6) and mod + ".lora_A.weight" not in wm
+    assert args_m.lora_modules == {"unmerged": 0, "merged": 2, "skipped": 0}
     # ft_projector override and heads (substring-filtered, reward_adaptor_loader.py:46-60)
     assert torch.equal(w["model.vision_embed_tokens.img_projection.2.bias"], proj["base_model.model.model.vision_embed_tokens.img_projection.2.bias"])
     assert torch.equal(w["value_head.weight"], W["value_head.weight"]) and w["W_k.weight"].shape == (cfg.hidden, cfg.hidden)
     assert set(n for n, *_ in synth.weight_specs(model.config)) <= set(w)
+    # an adapter module that resolves to nothing must not be dropped silently; off-path modules (deleted CLIP layer 24, lm_head) may
+    lora_file = os.path.join(pm, "lora", "adapter_model.bin")
+    good = torch.load(lora_file)
+    torch.save(dict(good, **{"base_model.model.model.layers.0.self_attn.qkvproj.lora_A.weight": A,
+                             "base_model.model.model.layers.0.self_attn.qkvproj.lora_B.weight": Bm}), lora_file)
+    with pytest.raises(KeyError, match="matches no weight"):
+        load_reward_adaptor(args, "phi3v", os.path.join(pm, "reward_config.yaml"))
+    clip24 = "model.vision_embed_tokens.img_processor.vision_model.encoder.layers.%d.mlp.fc1" % cfg.clip.layers_used
+    clip0 = "model.vision_embed_tokens.img_processor.vision_model.encoder.layers.0.mlp.fc1"
+    extra = {}
+    for m in (clip24, clip0):
+        extra[f"base_model.model.{m}.lora_A.default.weight"] = torch.ones(4, cfg.clip.hidden) * 0.01      # adapter-name infix accepted
+        extra[f"base_model.model.{m}.lora_B.default.weight"] = torch.ones(cfg.clip.mlp, 4) * 0.01
+    torch.save(dict(good, **extra), lora_file)
+    w2 = load_reward_adaptor(args, "phi3v", os.path.join(pm, "reward_config.yaml"))[1]._weights
+    assert args.lora_modules == {"unmerged": 2, "merged": 1, "skipped": 1}        # vision-tower adapter: merged; deleted layer: skipped
+    assert torch.allclose(w2[clip0 + ".weight"], W[clip0 + ".weight"] + 2.0 * 4 * 1e-4, atol=1e-6)
+    torch.save(good, lora_file)
+    for bad_cfg in ({"use_rslora": True}, {"rank_pattern": {"qkv_proj": 8}}, {"fan_in_fan_out": True}, {"alpha_pattern": {"x": 1}}):
+        json.dump(dict({"r": 4, "lora_alpha": 8}, **bad_cfg), open(os.path.join(pm, "lora", "adapter_config.json"), "w"))
+        with pytest.raises(NotImplementedError):
+            load_reward_adaptor(args, "phi3v", os.path.join(pm, "reward_config.yaml"))
+    json.dump({"r": 4, "lora_alpha": 8, "target_modules": ["qkv_proj", "down_proj"]}, open(os.path.join(pm, "lora", "adapter_config.json"), "w"))
     # fails loudly on CPU: no fallback path
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model.custom_forward(torch.zeros(1, 4, dtype=torch.long), torch.ones(1, 4, dtype=torch.long), torch.zeros(1, 2, 3, 336, 336), torch.tensor([[336, 336]]))
@@ -148,9 +181,11 @@ class _FakeModel:
     device = torch.device("cpu")
 
     def __init__(self, d):
-        self.d = d
+        self.d = self.value_head_dim = d
 
     def custom_forward(self, ids, mask, pix, sizes, return_output=False, inputs_batch=None):
+        if ids.shape[0] < 1:          # the engine's contract: lr_forward rejects B < 1 (engine.hip "batch exceeds max_batch")
+            raise RuntimeError("lr_forward failed (code 1): lr_forward: batch exceeds max_batch")
         base = (ids.float() * mask.float()).sum(dim=1, keepdim=True) * 1e-3 + pix.flatten(1).sum(dim=1, keepdim=True)
         return torch.cat([base * (k + 1) for k in range(self.d)], dim=1), None
 
@@ -172,7 +207,9 @@ def _worker(rank, ws, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=ws)
     args = types.SimpleNamespace(is_general_preference=True, value_head_dim=2, general_preference_tau=0.1)
-    res = score_pairwise(_FakeModel(2), args, _batches(3, 5, 0))          # 5 rows over 2 ranks: ragged shards
+    # 5 rows over 2 ranks: ragged shards; then a last partial batch of ONE row (n < world_size, drop_last=False): rank 1 scores
+    # nothing but must still enter the all-gather
+    res = score_pairwise(_FakeModel(2), args, _batches(3, 5, 0) + _batches(1, 1, 7))
     local = torch.arange(4, dtype=torch.float32).reshape(2, 2) + 10 * rank
     g = gather_rewards(local)
     q.put((rank, res["probs"], g.tolist()))
@@ -183,7 +220,7 @@ def _worker(rank, ws, port, q):
 def test_two_process_shard_and_gather_equals_single_process():
     import torch.multiprocessing as mp
     args = types.SimpleNamespace(is_general_preference=True, value_head_dim=2, general_preference_tau=0.1)
-    single = score_pairwise(_FakeModel(2), args, _batches(3, 5, 0))
+    single = score_pairwise(_FakeModel(2), args, _batches(3, 5, 0) + _batches(1, 1, 7))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000
@@ -197,7 +234,7 @@ def test_two_process_shard_and_gather_equals_single_process():
     for rank, probs, g in got:
         assert probs == single["probs"]                       # bit-identical on every rank
         assert g == [[0.0, 1.0], [2.0, 3.0], [10.0, 11.0], [12.0, 13.0]]
-    assert 0.0 <= single["proportion"] <= 1.0 and len(single["probs"]) == 15
+    assert 0.0 <= single["proportion"] <= 1.0 and len(single["probs"]) == 16
 
 
 def test_score_single_metrics():
@@ -252,8 +289,12 @@ def test_load_reward_adaptor_llava(tmp_path):
     args = types.SimpleNamespace(pm_path=pm, pretrain=pre, cache_dir=None, ft_projector=False, disable_fast_tokenizer=False)
     args, model = load_reward_adaptor(args, "llava", os.path.join(pm, "reward_config.yaml"))
     assert model.model_type == "llava" and model.config.kv_heads == cfg.kv_heads and model.config.clip.layers_used == c.layers_used
-    assert set(n for n, *_ in synth.llava_weight_specs(cfg)) <= set(model._weights)
-    assert torch.allclose(model._weights[mod + ".weight"], W[mod + ".weight"] + 2.0 * Bm @ A, atol=1e-6)
+    assert model.config.lora_rank == 4 and set(n for n, *_ in synth.llava_weight_specs(model.config)) == set(model._weights)
+    assert torch.equal(model._weights[mod + ".lora_A.weight"], A) and torch.equal(model._weights[mod + ".lora_B.weight"], 2.0 * Bm)
+    assert torch.equal(model._weights[mod + ".weight"].float(), W[mod + ".weight"])
+    args.merge_lora = True
+    merged = load_reward_adaptor(args, "llava", os.path.join(pm, "reward_config.yaml"))[1]
+    assert merged.config.lora_rank == 0 and torch.allclose(merged._weights[mod + ".weight"], W[mod + ".weight"] + 2.0 * Bm @ A, atol=1e-6)
     yaml.safe_dump({"is_general_preference": False, "add_cross_attention": True, "value_head_dim": 1, "general_preference_tau": 0.1},
                    open(os.path.join(pm, "reward_config.yaml"), "w"))
     with pytest.raises(AttributeError):          # the reference dies the same way (rw_model:315)
@@ -303,8 +344,11 @@ def test_load_reward_adaptor_qwen(tmp_path):
     args, model = load_reward_adaptor(args, "qwen", os.path.join(pm, "reward_config.yaml"))
     assert model.model_type == "qwen" and args.add_cross_attention is True and args.value_head_dim == 2
     assert model.config.vision.fullatt == v.fullatt and model.config.mrope_section == cfg.mrope_section and model.config.ca_eps == 1e-6
-    assert set(n for n, *_ in synth.qwen_weight_specs(cfg2)) == set(model._weights)
-    assert torch.allclose(model._weights[mod + ".weight"], W[mod + ".weight"] + 2.0 * Bm @ A, atol=1e-6)
+    assert model.config.lora_rank == 4 and set(n for n, *_ in synth.qwen_weight_specs(model.config)) == set(model._weights)
+    assert torch.equal(model._weights[mod + ".lora_A.weight"], A) and torch.equal(model._weights[mod + ".lora_B.weight"], 2.0 * Bm)
+    args.operand_dtype = "fp8"                       # W8A8 runs merged weights only
+    merged = load_reward_adaptor(args, "qwen", os.path.join(pm, "reward_config.yaml"))[1]
+    assert merged.config.lora_rank == 0 and torch.allclose(merged._weights[mod + ".weight"], W[mod + ".weight"] + 2.0 * Bm @ A, atol=1e-6)
     assert torch.equal(model._weights["visual.merger.ln_q.weight"], W["visual.merger.ln_q.weight"] + 1.0)      # ft_projector wins
     with pytest.raises(RuntimeError):                # no GPU here: the product path refuses, it does not fall back
         model.custom_forward(inputs_batch={})

@@ -30,7 +30,7 @@ def test_oracle_matches_reference(path):
     W = orc.weights_to_torch(synth.make_weights(cfg, g["seed"]))
     grids = g["grids"]
     grids = tuple(grids) if isinstance(grids[0], int) else [tuple(x) for x in grids]
-    batch = synth.synth_batch(cfg, g["seed"], g["caption_lens"], grids, max_crops=g["max_crops"])
+    batch = synth.pad_left(synth.synth_batch(cfg, g["seed"], g["caption_lens"], grids, max_crops=g["max_crops"]), g.get("extra_left_pad", 0))
     taps = {}
     r = orc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"],
                            batch["image_sizes"], taps=taps, layer_id=g.get("layer_id", 32),
