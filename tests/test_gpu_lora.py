@@ -78,11 +78,15 @@ def test_unmerged_adapter_vs_oracle(backbone, rank, dtype):
     if dtype == "f16x2":
         up, _ = _hip(cfg, batch, dtype, weights={k: torch.from_numpy(v) for k, v in Wn.items()})
         assert torch.equal(up, got)
-        # a row's reward does not depend on its batch (the t GEMM and the K-extension keep the fixed reduction order)
+        # a row's reward does not depend on its batch (the t GEMM and the K-extension keep the fixed reduction order).  Row 2 carries
+        # the batch's V_max image tokens; rows with fewer see V_max through the un-masked zero-padded SkipCA rows (rw_model:381-385),
+        # in the reference as here, so only their V_max-preserving regroupings are bit-stable.
         tb = {k: torch.from_numpy(v) for k, v in batch.items()}
         if backbone == "phi3v":
-            one, _ = m.custom_forward(tb["input_ids"][1:2].cuda(), tb["attention_mask"][1:2].cuda(), tb["pixel_values"][1:2].cuda(), tb["image_sizes"][1:2])
-            assert torch.equal(one.cpu()[0], got[1])
+            one, _ = m.custom_forward(tb["input_ids"][2:3].cuda(), tb["attention_mask"][2:3].cuda(), tb["pixel_values"][2:3].cuda(), tb["image_sizes"][2:3])
+            assert torch.equal(one.cpu()[0], got[2])
+            two, _ = m.custom_forward(tb["input_ids"][1:3].cuda(), tb["attention_mask"][1:3].cuda(), tb["pixel_values"][1:3].cuda(), tb["image_sizes"][1:3])
+            assert torch.equal(two.cpu(), got[1:3])
 
 
 @pytest.mark.parametrize("dtype", ["f16x2", "f16x2f8"])
