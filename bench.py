@@ -14,6 +14,7 @@ offline); rank 0 at N=1 also times the CPU oracle on a bounded sample (cpu_basel
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -30,15 +31,14 @@ PEAK_TFLOPS = 2500.0              # dense bf16/f16 MFMA, MI355X_MICROARCH.md "Ch
 
 
 def cpu_baseline(cfg_full):
-    """Time the CPU oracle (oracle/phi3v_reward_oracle.py, 'port') on a bounded sample of the same
-    workload (10-30 s of CPU work): ONE row at full shapes, run with 2 and with 6 layers of each tower; the
-    per-layer cost is a quarter of the difference of the two runs and is scaled to the full depth (every layer of
-    a tower has identical shapes)."""
-    import dataclasses
+    """Time the CPU oracle (oracle/phi3v_reward_oracle.py, kind 'port') on the GPU box's host cores: ONE row of the headline
+    workload at full shapes and FULL depth (17 crops x 23 CLIP layers, S = 2642 x 32 decoder layers, SkipCA, value head), fp32
+    torch, nothing extrapolated.  The weights of one layer of each tower are random tensors shared by all of its
+    layers: the time depends on shapes only, and 16.7 GB of distinct random fp32 weights would cost more to generate than the
+    forward takes.  Threads: the count that runs a decoder-sized GEMM fastest (torch oversubscribes SMT boxes)."""
     from llava_reward_amd import synth
     from oracle import phi3v_reward_oracle as orc
     g = torch.Generator().manual_seed(0)
-    # pick the thread count that runs one decoder-layer-sized GEMM fastest (torch oversubscribes SMT boxes)
     ncpu = os.cpu_count() or 1
     probe_a, probe_w = torch.randn(2642, 3072, generator=g), torch.randn(16384, 3072, generator=g)
     best = (1e9, ncpu)
@@ -49,38 +49,24 @@ def cpu_baseline(cfg_full):
         torch.nn.functional.linear(probe_a, probe_w)
         best = min(best, (time.time() - t0, nt))
     torch.set_num_threads(best[1])
-    cores = torch.get_num_threads()
+    threads = torch.get_num_threads()
     del probe_a, probe_w
-
-    def weights(cfg):
-        W = {}
-        for name, shape, std, off in synth.weight_specs(cfg):
-            W[name] = torch.randn(shape, generator=g) * std + off
-        return W
-
+    W, shared = {}, {}
+    for name, shape, std, off in synth.weight_specs(cfg_full):
+        key = re.sub(r"layers\.\d+\.", "layers.N.", name)      # one tensor per layer-local name
+        if key not in shared:
+            shared[key] = torch.randn(shape, generator=g) * std + off
+        W[name] = shared[key]
     batch = synth.synth_batch(cfg_full, 1234, [128], (4, 4), with_pixels=False)
     pix = torch.randn(1, 17, 3, 336, 336, generator=g)
-    times = {}
-    for nl in (2, 6):
-        cfg = dataclasses.replace(cfg_full, layers=nl, clip=dataclasses.replace(cfg_full.clip, layers_used=nl))
-        W = weights(cfg)
-        t0 = time.time()
-        feats = orc.clip_tower(W, pix.flatten(0, 1), cfg.clip)
-        t1 = time.time()
-        orc.custom_forward(W, dataclasses.replace(cfg, clip=dataclasses.replace(cfg.clip, layers_used=0)),
-                           batch["input_ids"], batch["attention_mask"], pix, batch["image_sizes"])
-        t2 = time.time()
-        times[nl] = (t1 - t0, t2 - t1)
-        del W, feats
-    clip_layer = max((times[6][0] - times[2][0]) / 4, 1e-6)
-    clip_base = max(times[2][0] - 2 * clip_layer, 0.0)
-    dec_layer = max((times[6][1] - times[2][1]) / 4, 1e-6)
-    dec_base = max(times[2][1] - 2 * dec_layer, 0.0)
-    total = clip_base + cfg_full.clip.layers_used * clip_layer + dec_base + cfg_full.layers * dec_layer
-    spent = sum(a + b for a, b in times.values())
-    return {"value": 1.0 / total, "unit": "reward-pairs/sec", "cores": cores, "kind": "port",
-            "sample": f"1 row at full shapes (17 crops, S={batch['input_ids'].shape[1]}); 2 + 6 of 23 CLIP and 2 + 6 of 32 decoder layers "
-                      f"timed ({spent:.1f}s CPU), per-layer cost scaled to full depth -> {total:.1f}s per row, fp32 torch"}
+    t0 = time.time()
+    r = orc.custom_forward(W, cfg_full, batch["input_ids"], batch["attention_mask"], pix, batch["image_sizes"])
+    total = time.time() - t0
+    assert torch.isfinite(r).all()
+    return {"value": 1.0 / total, "unit": "reward-pairs/sec", "cores": threads, "host_cpus": ncpu, "kind": "port",
+            "seconds_per_row": total,
+            "sample": f"1 row at full shapes and full depth (17 crops x {cfg_full.clip.layers_used} CLIP layers, S={batch['input_ids'].shape[1]} x "
+                      f"{cfg_full.layers} decoder layers), measured end to end ({total:.1f}s), fp32 torch, {threads} threads of {ncpu} host CPUs"}
 
 
 def qwen_flop_per_row(cfg, grid, S):
@@ -99,6 +85,37 @@ def qwen_flop_per_row(cfg, grid, S):
     dec = 2 * S * (D * (cfg.heads + 2 * cfg.kv_heads) * cfg.head_dim + cfg.heads * cfg.head_dim * D + 3 * D * I) * cfg.layers
     datt = 4 * (S * S // 2) * cfg.head_dim * cfg.heads * cfg.layers
     return float(lin + att + patch + merger + dec + datt)
+
+
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r2_pmc_gemm_gate_up.json")
+KERNEL_SOURCES = ("llava-reward_amd/csrc/gemm8.hip", "llava-reward_amd/csrc/common.h")
+
+
+def kernel_source_sha16():
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_for(form):
+    """PMC figures of the dominant kernel (HBM-side bytes per launch, MFMA-pipe busy fraction, effective clock) from the committed
+    rocprofv3 summary profiles/r2_pmc_gemm_gate_up.json (tools/pmc_summary.py writes it from separate --pmc passes of
+    tools/gemm_one.py).  They describe THIS build only if the kernel sources are the ones that were profiled: the file records
+    their hash and the kernel's template signature; on any mismatch the fields are null (stale profile) instead of a stale number."""
+    none = {"traffic": None, "mfma_busy": None, "clock_ghz": None, "pmc_source": None}
+    try:
+        prof = json.load(open(PMC_PROFILE))
+    except Exception as e:
+        return dict(none, pmc_note=f"no committed PMC profile ({type(e).__name__})")
+    ent = prof.get("forms", {}).get(form)
+    if not ent:
+        return dict(none, pmc_note=f"profile has no entry for the '{form}' form")
+    if prof.get("source_sha16") != kernel_source_sha16():
+        return dict(none, pmc_note=f"stale PMC profile: kernel sources changed since {os.path.basename(PMC_PROFILE)} was collected")
+    return {"traffic": ent["traffic_bytes_per_launch"], "mfma_busy": ent["mfma_busy_frac"], "clock_ghz": ent["effective_clock_ghz"],
+            "pmc_source": os.path.relpath(PMC_PROFILE, ROOT), "pmc_kernel": ent["kernel_name"], "pmc_avg_ms": ent["avg_ms"]}
 
 
 def dominant_kernel_probe(dtype_code, tile, steps=5, split=False, lo8=False):
@@ -139,20 +156,18 @@ def dominant_kernel_probe(dtype_code, tile, steps=5, split=False, lo8=False):
     e1.record(st)
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    # PMC passes of these exact launches (profiles/r1_pmc_gemm_gate_up.md): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE
-    pmc = ({"traffic": 23.9e9, "mfma_busy": 0.659, "clock_ghz": 1.75} if lo8 else
-           {"traffic": 32.9e9, "mfma_busy": 0.652, "clock_ghz": 1.73} if split else {"traffic": 14.6e9, "mfma_busy": 0.626, "clock_ghz": 1.75})
-    form = ", split-operand form, e4m3 residual pass" if lo8 else ", split-operand form" if split else ""
-    return {"kernel": "gemm_bt8_kernel<SwiGLU> decoder gate_up" + form, "shape": [M, N, K],
-            "avg_ms": ms, "tflops": 2.0 * M * N * K / (ms * 1e-3) / 1e12, "mfma_work_factor": 1.5 if lo8 else w,
-            "algorithmic_bytes": 2.0 * ((1.5 if lo8 else w) * M * K + (1.5 if lo8 else 1) * N * K + w * M * N // 2), "traffic_bytes_pmc": pmc["traffic"],
-            "mfma_busy_frac_pmc": pmc["mfma_busy"], "effective_clock_ghz_pmc": pmc["clock_ghz"]}
+    form = "mixed" if lo8 else "split" if split else "single"
+    pmc = pmc_for(form)
+    label = ", split-operand form, e4m3 residual pass" if lo8 else ", split-operand form" if split else ""
+    return dict({"kernel": "gemm_bt8_kernel<SwiGLU> decoder gate_up" + label, "shape": [M, N, K],
+                 "avg_ms": ms, "tflops": 2.0 * M * N * K / (ms * 1e-3) / 1e12, "mfma_work_factor": 1.5 if lo8 else w,
+                 "algorithmic_bytes": 2.0 * ((1.5 if lo8 else w) * M * K + (1.5 if lo8 else 1) * N * K + w * M * N // 2)}, **pmc)
 
 
-def golden_check(model, model_name):
+def golden_check(model, model_name, name=None):
     """Score the committed full-size golden row of this backbone (produced by the REFERENCE itself, tests/golden/make_goldens.py)
     with the engine that was just timed -- same synthetic weights (seed 1234) -- and report |reward - reference|."""
-    name = {"phi3v": "ref_full_bt_ca", "llava": "ref_llava_full_bt", "qwen": "ref_qwen_full_bt"}[model_name]
+    name = name or {"phi3v": "ref_full_bt_ca", "llava": "ref_llava_full_bt", "qwen": "ref_qwen_full_bt"}[model_name]
     path = os.path.join(ROOT, "tests", "golden", name + ".json")
     if not os.path.exists(path):
         return None
@@ -185,12 +200,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32, help="rows per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="rows per GPU (default 32; 64 for --config gpm_pairwise)")
     ap.add_argument("--dtype", default="f16x2f8", choices=["f16x2", "f16x2f8", "f16", "bf16", "bf16x2", "fp8"],
                     help="MFMA operands: f16x2f8 = split-operand parity mode with the residual pass of the big GEMMs in e4m3 (default, rewards "
                          "within 1e-3 of the fp32 reference with > 10x margin); f16x2 = the same with 16-bit residual passes (strict); "
-                         "f16 / bf16 = single-pass fast modes (noise-limited, DESIGN.md §4)")
+                         "f16 / bf16 = single-pass modes (NOT parity modes: noise-limited, DESIGN.md §4)")
+    ap.add_argument("--config", default="bt", choices=["bt", "gpm_pairwise"],
+                    help="bt = BASELINE configs[1] (BT head, B=32): the metric; gpm_pairwise = configs[2]: GPM head d=2 + SkipCA, a step = chosen and "
+                         "rejected forward of B=64 rows each + preference_compute (reports preference-pairs/s beside reward-pairs/s)")
+    ap.add_argument("--lora-rank", type=int, default=0, help="run the main workload with an un-merged rank-r adapter on the decoder linears")
+    ap.add_argument("--quick", action="store_true", help="main line only: no secondary legs (for profiler runs)")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the secondary single-pass f16 measurement")
+    ap.add_argument("--no-other-backbones", action="store_true", help="skip the Qwen2.5-VL-7B / LLaVA-1.6-7B sub-lines of the default run")
     ap.add_argument("--tile", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="phi3v", choices=["phi3v", "llava", "qwen"],
@@ -219,58 +240,67 @@ def main():
         else:
             dist.init_process_group(a.backend)
 
+    import dataclasses
     from llava_reward_amd import synth, _lib as L
     from llava_reward_amd.model import RewardModel
+    from llava_reward_amd.reward_adaptor_loader import preference_compute
     from llava_reward_amd.scoring import gather_rewards
 
-    B = a.batch
-    rows = slice(rank * B, (rank + 1) * B)          # contiguous shard: gathered order == input order
-    gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
-    if a.model == "qwen":
-        cfg = synth.qwen_full_config()              # Qwen2.5-VL-7B, BT head + the as-written SkipCA
-        # 336^2 image -> 448^2 after the reference's min_pixels = 256*28^2 floor (utils/utils.py:35) -> 32x32 patches, 256 slots
-        gb = synth.qwen_synth_batch(cfg, 1234, [128] * (B * world), [(32, 32)] * (B * world), with_pixels=False)
-        ncrop, flop_per_pair = 0, qwen_flop_per_row(cfg, (32, 32), gb["input_ids"].shape[1])
-        workload = "BASELINE configs[3] shapes: Qwen2.5-VL-7B, 448x448 px (32x32 patches, 256 image tokens), BT head + SkipCA"
-    elif a.model == "llava":
-        cfg = synth.llava_full_config()             # Mistral-7B decoder + CLIP-L, BT head, no SkipCA on this branch
-        gb = synth.llava_synth_batch(cfg, 1234, [128] * (B * world), [(336, 336)] * (B * world), with_pixels=False)
-        ncrop, flop_per_pair = 3, 19.9e12           # 3 crops -> 1176 image tokens; see DESIGN.md §8
-        workload = "LLaVA-v1.6-Mistral-7B (BASELINE configs[4] shapes, 16-bit operands), 3 crops/img, V=1176"
-    else:
-        cfg = synth.full_config()                   # BT head (d=1) + SkipCA
-        if a.num_crops == 16:
-            gb = synth.synth_batch(cfg, 1234, [128] * (B * world), (4, 4), with_pixels=False)
-            ncrop, flop_per_pair = 17, FLOP_PER_PAIR
-            workload = "BASELINE configs[1]: Phi-3.5-V BT head + SkipCA, 17 crops/img, V=2509"
-        else:
-            gb = synth.synth_batch(cfg, 1234, [128] * (B * world), (2, 2), with_pixels=False)
-            ncrop, flop_per_pair = 5, 8.48e12
-            workload = "BASELINE configs[1] at num_crops=4: Phi-3.5-V BT head + SkipCA, 5 crops/img, V=757"
-    S = gb["input_ids"].shape[1]
-    ids = torch.from_numpy(gb["input_ids"][rows]).cuda()
-    mask = torch.from_numpy(gb["attention_mask"][rows]).cuda()
-    precise = "x2" in a.dtype
-    if a.model == "qwen":
-        sizes = torch.from_numpy(gb["image_grid_thw"][rows])
-        pix = torch.randn(B * 32 * 32, cfg.vision.patch_dim, device="cuda", generator=gen)   # normalised pixel noise, fp32
-    else:
-        sizes = torch.from_numpy(gb["image_sizes"][rows])
-        pix = torch.randn(B, ncrop, 3, 336, 336, device="cuda", generator=gen)      # CLIP-normalised pixel noise, fp32
+    pairwise = a.config == "gpm_pairwise"
+    if pairwise and a.model != "phi3v":
+        raise SystemExit("--config gpm_pairwise is BASELINE configs[2]: Phi-3.5-V")
 
-    def build_model(dtype, fp32_valued=False):
-        if a.model == "qwen":
+    def workload(model_name, B, num_crops=16, gpm=False, lora_rank=0):
+        """Inputs (resident in HBM) and geometry of `B` rows per GPU of one backbone's headline workload."""
+        rows = slice(rank * B, (rank + 1) * B)          # contiguous shard: gathered order == input order
+        gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+        if model_name == "qwen":
+            cfg = synth.qwen_full_config(lora_rank=lora_rank)              # Qwen2.5-VL-7B, BT head + the as-written SkipCA
+            # 336^2 image -> 448^2 after the reference's min_pixels = 256*28^2 floor (utils/utils.py:35) -> 32x32 patches, 256 slots
+            gb = synth.qwen_synth_batch(cfg, 1234, [128] * (B * world), [(32, 32)] * (B * world), with_pixels=False)
+            ncrop, flop = 0, qwen_flop_per_row(cfg, (32, 32), gb["input_ids"].shape[1])
+            name = "BASELINE configs[3] shapes: Qwen2.5-VL-7B, 448x448 px (32x32 patches, 256 image tokens), BT head + SkipCA"
+            sizes = torch.from_numpy(gb["image_grid_thw"][rows])
+            pix = torch.randn(B * 32 * 32, cfg.vision.patch_dim, device="cuda", generator=gen)   # normalised pixel noise, fp32
+        elif model_name == "llava":
+            cfg = synth.llava_full_config(lora_rank=lora_rank)             # Mistral-7B decoder + CLIP-L, BT head, no SkipCA on this branch
+            gb = synth.llava_synth_batch(cfg, 1234, [128] * (B * world), [(336, 336)] * (B * world), with_pixels=False)
+            ncrop, flop = 3, 19.9e12                    # 3 crops -> 1176 image tokens; see DESIGN.md §8
+            name = "LLaVA-v1.6-Mistral-7B (BASELINE configs[4] shapes, 16-bit operands), 3 crops/img, V=1176"
+            sizes = torch.from_numpy(gb["image_sizes"][rows])
+            pix = torch.randn(B, ncrop, 3, 336, 336, device="cuda", generator=gen)
+        else:
+            cfg = synth.full_config(lora_rank=lora_rank, **(dict(is_general_preference=True, value_head_dim=2) if gpm else {}))
+            head = "GPM head d=2 + SkipCA, pairwise" if gpm else "BT head + SkipCA"
+            if num_crops == 16:
+                gb = synth.synth_batch(cfg, 1234, [128] * (B * world), (4, 4), with_pixels=False)
+                ncrop, flop = 17, FLOP_PER_PAIR
+                name = f"BASELINE configs[{2 if gpm else 1}]: Phi-3.5-V {head}, 17 crops/img, V=2509"
+            else:
+                gb = synth.synth_batch(cfg, 1234, [128] * (B * world), (2, 2), with_pixels=False)
+                ncrop, flop = 5, 8.48e12                # SURVEY.md §8d
+                name = f"BASELINE configs[1] at num_crops=4: Phi-3.5-V {head}, 5 crops/img, V=757"
+            sizes = torch.from_numpy(gb["image_sizes"][rows])
+            pix = torch.randn(B, ncrop, 3, 336, 336, device="cuda", generator=gen)      # CLIP-normalised pixel noise, fp32
+        ids = torch.from_numpy(gb["input_ids"][rows]).cuda()
+        mask = torch.from_numpy(gb["attention_mask"][rows]).cuda()
+        return dict(model=model_name, cfg=cfg, B=B, S=ids.shape[1], ids=ids, mask=mask, pix=pix, sizes=sizes, ncrop=ncrop, flop=flop, name=name)
+
+    def build_model(w, dtype, fp32_valued=False):
+        cfg, B, S = w["cfg"], w["B"], w["S"]
+        if w["model"] == "qwen":
             m = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=S, max_patches=B * 32 * 32, operand_dtype=dtype)
         else:
-            m = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=S, max_crops=max(ncrop, 5 if a.model == 'llava' else 17), operand_dtype=dtype)
+            m = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=S, max_crops=max(w["ncrop"], 5 if w["model"] == "llava" else 17), operand_dtype=dtype)
         m.synth_fp32_valued = fp32_valued
         m = m.to(f"cuda:{local}").eval()
         if a.tile >= 0:
             m.engine.set_gemm_tile(a.tile)
         return m
 
-    def run_forward(m):
-        return m.engine.forward_qwen(ids, mask, pix, sizes) if a.model == "qwen" else m.engine.forward(ids, mask, pix, sizes)
+    def forward(m, w, pix=None):
+        pix = w["pix"] if pix is None else pix
+        return m.engine.forward_qwen(w["ids"], w["mask"], pix, w["sizes"]) if w["model"] == "qwen" else m.engine.forward(w["ids"], w["mask"], pix, w["sizes"])
 
     def timed_steps(fn, warmup, steps):
         for _ in range(warmup):
@@ -282,10 +312,27 @@ def main():
         torch.cuda.synchronize()
         return 1e3 * (time.perf_counter() - t0) / steps
 
-    model = build_model(a.dtype)
+    def release(m):
+        m.engine.close()
+        torch.cuda.empty_cache()
+
+    B = a.batch if a.batch is not None else (64 if pairwise else 32)
+    w = workload(a.model, B, a.num_crops, gpm=pairwise, lora_rank=a.lora_rank)
+    cfg, S, flop_per_pair = w["cfg"], w["S"], w["flop"]
+    precise = "x2" in a.dtype
+    model = build_model(w, a.dtype)
+    if pairwise:       # the rejected image of every pair: other pixels, same caption
+        pix_r = torch.randn(w["pix"].shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4321 + rank))
+    pargs = type("A", (), dict(is_general_preference=cfg.is_general_preference, value_head_dim=cfg.value_head_dim,
+                               general_preference_tau=cfg.general_preference_tau))
 
     def step():
-        r = run_forward(model)
+        r = forward(model, w)
+        if pairwise:       # eval/batch_inference_rm_phi.py:92-108: chosen forward, rejected forward, preference probability
+            rr = forward(model, w, pix_r)
+            if world > 1:
+                r, rr = (gather_rewards(r), gather_rewards(rr)) if a.backend == "nccl" else (gather_rewards(r.cpu()), gather_rewards(rr.cpu()))
+            return torch.from_numpy(preference_compute(pargs, r, rr))
         if world == 1:
             return r
         if a.backend != "nccl":               # gloo smoke path: collectives on host tensors
@@ -313,7 +360,8 @@ def main():
     assert torch.isfinite(out).all(), "non-finite rewards"
 
     if rank == 0:
-        value = world * B * a.steps / dt
+        rows_per_step = world * B * (2 if pairwise else 1)
+        value = rows_per_step * a.steps / dt
         tf_per_gpu = value * flop_per_pair / world / 1e12
         res = {
             "metric": "reward-pairs/sec (336px img, 128-tok caption) " + {"phi3v": "Phi-3.5-V", "llava": "LLaVA-v1.6-Mistral-7B", "qwen": "Qwen2.5-VL-7B"}[a.model], "value": value, "unit": "reward-pairs/sec",
@@ -321,71 +369,106 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": f"{a.dtype} MFMA operands (bf16-valued weights), f32 accumulate/residual/softmax",
             "data": "synthetic (seeded weights and inputs; no checkpoint offline)",
-            "config": {"workload": workload + ", S=%d" % S,
+            "config": {"workload": w["name"] + ", S=%d" % S + (", un-merged LoRA adapter r=%d on the decoder linears" % a.lora_rank if a.lora_rank else ""),
                        "rows_per_gpu": B, "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
-                       "collective": "all_gather rewards [B,1] fp32" if world > 1 else "none"},
+                       "collective": "all_gather rewards [B,%d] fp32" % cfg.value_head_dim if world > 1 else "none"},
             "roofline": {"bound": "mfma", "achieved": tf_per_gpu, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf_per_gpu / PEAK_TFLOPS, "traffic": None,
                          "note": "whole pass: pairs/s x %.2f TFLOP ALGORITHMIC per pair, per GPU%s" % (
                              flop_per_pair / 1e12, ("; the split-operand mode executes 1.5x (linears: f16 pass + e4m3 residual pass at twice the rate) / 3x (attention) that MFMA time"
                               if a.dtype == "f16x2f8" else "; the split-operand mode executes 2x (linears) / 3x (attention) that MFMA work") if precise else "")},
         }
+        if pairwise:
+            res["preference_pairs_per_sec"] = world * B * a.steps / dt
+            res["config"]["step"] = "chosen forward + rejected forward (B rows each) + preference_compute (GPM d=2 formula)"
+        headline = a.model == "phi3v" and a.num_crops == 16 and not pairwise and not a.lora_rank
         if world == 1:
-            full = a.model != "phi3v" or a.num_crops == 16      # the golden row is a 17-crop image: it does not fit the 5-crop engine
-            res["parity_check"] = golden_check(model, a.model) if full else None
+            full = (a.model != "phi3v" or a.num_crops == 16) and not a.lora_rank      # the golden rows: 17-crop images, no adapter
+            gname = "ref_full_gpm2_ca" if pairwise else None
+            res["parity_check"] = golden_check(model, a.model, gname) if full else None
             if a.model == "phi3v" and a.num_crops == 16:
                 dk = dominant_kernel_probe(L.LR_DT_F16 if a.dtype.startswith("f16") else L.LR_DT_BF16, a.tile, split=precise, lo8=a.dtype == "f16x2f8")
                 # the roofline object proper: the dominant kernel, algorithmic FLOPs per launch / its live HIP-event duration
-                res["roofline"].update({"achieved": dk["tflops"], "frac": dk["tflops"] / PEAK_TFLOPS, "traffic": dk["traffic_bytes_pmc"],
+                res["roofline"].update({"achieved": dk["tflops"], "frac": dk["tflops"] / PEAK_TFLOPS, "traffic": dk["traffic"],
                                         "kernel": dk["kernel"], "dominant_kernel": dk,
                                         "whole_pass": {"achieved": tf_per_gpu, "frac": tf_per_gpu / PEAK_TFLOPS},
-                                        "note": res["roofline"]["note"] + "; achieved/frac/traffic = the dominant kernel (algorithmic FLOPs per launch / HIP-event "
-                                                "time; traffic = PMC bytes per launch, profiles/r1_pmc_gemm_gate_up.md); whole_pass = the same ratio for the step"})
+                                        "note": res["roofline"]["note"] + "; achieved/frac = the dominant kernel (algorithmic FLOPs per launch / HIP-event "
+                                                "time, measured by this run); traffic / mfma_busy / clock_ghz = PMC figures of the committed rocprofv3 summary, null "
+                                                "unless its recorded kernel sources are this build's; whole_pass = the same ratio for the step"})
+        if world == 1 and not a.quick:
             # the same step with the pixel hand-over included: fp32 pixels start in pinned host memory (what the processor
             # returns) and cross PCIe on the forward's stream every step.  Reported beside `value`, never as `value`.
-            pix_host = pix.cpu().pin_memory()
+            sub_steps = min(a.steps, 3)
+            pix_host = w["pix"].cpu().pin_memory()
             def step_h2d():
-                pix.copy_(pix_host, non_blocking=True)
-                return run_forward(model)
-            ms_h2d = timed_steps(step_h2d, 1, a.steps)
+                w["pix"].copy_(pix_host, non_blocking=True)
+                return forward(model, w)
+            ms_h2d = timed_steps(step_h2d, 1, sub_steps)
             res["h2d_inclusive"] = {"value": B / (ms_h2d * 1e-3), "unit": "reward-pairs/sec", "ms_per_step": ms_h2d,
-                                    "pixel_bytes_per_step": pix.numel() * 4, "note": "pinned host fp32 pixels copied in every step"}
-            del model, pix_host
-            torch.cuda.empty_cache()
+                                    "pixel_bytes_per_step": w["pix"].numel() * 4, "note": "pinned host fp32 pixels copied in every step (one forward of B rows)"}
+            del pix_host
             if a.model == "phi3v":
                 # the image hand-over in front of the path: decoded uint8 336 px image -> pixel_values rows
                 from llava_reward_amd import preprocess
                 img = torch.from_numpy(synth.synth_image(1234, "bench.image", 336, 336)).cuda()
-                preprocess.hd_transform_batch([img] * B, a.num_crops, out=pix)
+                preprocess.hd_transform_batch([img] * B, a.num_crops, out=w["pix"])
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 for _ in range(5):
-                    preprocess.hd_transform_batch([img] * B, a.num_crops, out=pix)
+                    preprocess.hd_transform_batch([img] * B, a.num_crops, out=w["pix"])
                 torch.cuda.synchronize()
                 us = 1e6 * (time.perf_counter() - t1) / (5 * B)
-                res["input_handover"] = {"kernel": "lr_hd_transform (uint8 336x336 -> [%d,3,336,336] fp32, local crops bit-exact with Pillow)" % (ncrop),
+                res["input_handover"] = {"kernel": "lr_hd_transform (uint8 336x336 -> [%d,3,336,336] fp32, local crops bit-exact with Pillow)" % (w["ncrop"]),
                                          "us_per_image": us, "images_per_sec": 1e6 / us,
-                                         "hbm_GBps_algorithmic": (ncrop * 3 * 336 * 336 * 4 + 336 * 336 * 3) / us / 1e3}
+                                         "hbm_GBps_algorithmic": (w["ncrop"] * 3 * 336 * 336 * 4 + 336 * 336 * 3) / us / 1e3}
+            release(model)
+            del model
+
+            def leg(wl, dtype, steps=sub_steps, fp32_valued=False, golden=None):
+                m = build_model(wl, dtype, fp32_valued)
+                ms = timed_steps(lambda: forward(m, wl), 1, steps)
+                out = {"dtype": dtype, "value": wl["B"] / (ms * 1e-3), "unit": "reward-pairs/sec", "ms_per_step": ms, "rows_per_step": wl["B"],
+                       "roofline_frac_whole_pass": wl["B"] / (ms * 1e-3) * wl["flop"] / 1e12 / PEAK_TFLOPS}
+                if golden:
+                    out["parity_check"] = golden_check(m, wl["model"], golden if isinstance(golden, str) else None)
+                release(m)
+                return out
+
+            if headline and precise:
+                # what a real LLaVA-Reward checkpoint costs: every decoder linear carries the un-merged rank-128 adapter of the training
+                # recipes (scripts/run_train_rm_single_lora_phi.sh: --lora_rank 128 --lora_alpha 256, vision tower frozen)
+                wl = workload(a.model, B, a.num_crops, lora_rank=128)
+                res["lora_unmerged"] = dict(leg(wl, a.dtype), rank=128,
+                                            note="un-merged adapter: t = x A^T per linear + 128 extra K columns (x2: hi, lo) in the base GEMM; base weights stay bf16-exact")
+                res["lora_unmerged"]["vs_headline"] = res["lora_unmerged"]["value"] / value
+                # the fallback for adapters the engine does not run un-merged (vision-tower adapters, merge_lora=True): merged weights are
+                # not bf16-valued any more, every GEMM carries a third K segment
+                res["merged_lora_weights"] = dict(leg(w, a.dtype, steps=2, fp32_valued=True),
+                                                  note="fallback: merged (fp32-valued) weights, third K segment per GEMM")
+                # BASELINE configs[2]: GPM d=2 + SkipCA, pairwise, B=64 rows per forward
+                wg = workload("phi3v", 64, 16, gpm=True)
+                mg = build_model(wg, a.dtype)
+                pg = torch.randn(wg["pix"].shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4321))
+                ga = type("A", (), dict(is_general_preference=True, value_head_dim=2, general_preference_tau=wg["cfg"].general_preference_tau))
+                msg = timed_steps(lambda: preference_compute(ga, forward(mg, wg), forward(mg, wg, pg)), 1, 2)
+                res["gpm_pairwise"] = {"workload": wg["name"] + ", B=64 rows per forward", "dtype": a.dtype, "value": 128 / (msg * 1e-3), "unit": "reward-pairs/sec",
+                                       "preference_pairs_per_sec": 64 / (msg * 1e-3), "ms_per_step": msg,
+                                       "step": "chosen forward + rejected forward + preference_compute", "parity_check": golden_check(mg, "phi3v", "ref_full_gpm2_ca")}
+                release(mg)
+                del mg, pg
+            if headline and not a.no_other_backbones:
+                for mname, bb in (("qwen", 32), ("llava", 64)):          # BASELINE configs[3] / [4] at their per-GPU batch
+                    wl = workload(mname, bb)
+                    res[mname] = dict(leg(wl, a.dtype, golden=True), workload=wl["name"] + ", S=%d, B=%d" % (wl["S"], bb))
             if precise and not a.no_fast_mode:
-                # secondary figure: the single-pass f16 mode of the same workload (noise-limited parity)
-                fm = build_model("f16")
-                ms = timed_steps(lambda: run_forward(fm), a.warmup, a.steps)
-                fv = B * a.steps / (ms * 1e-3 * a.steps)
-                res["fast_mode"] = {"dtype": "f16 single-pass MFMA operands", "value": fv, "unit": "reward-pairs/sec", "ms_per_step": ms,
-                                    "roofline_frac_whole_pass": fv * flop_per_pair / 1e12 / PEAK_TFLOPS,
-                                    "parity_check": golden_check(fm, a.model) if full else None}
-                del fm
-                torch.cuda.empty_cache()
-            if precise and not a.no_fast_mode:
-                # the same parity mode on weights that are NOT bf16-valued (fp32-valued synthetic weights): what a real LLaVA-Reward
-                # checkpoint looks like once its all-linear LoRA adapter is merged (every GEMM carries the weights' residuals too)
-                mm = build_model(a.dtype, fp32_valued=True)
-                ms = timed_steps(lambda: run_forward(mm), a.warmup, a.steps)
-                res["merged_lora_weights"] = {"dtype": a.dtype, "value": B / (ms * 1e-3), "unit": "reward-pairs/sec", "ms_per_step": ms,
-                                              "note": "weights inexact in f16: third K segment per GEMM (e4m3 A_hi x e4m3 W_lo in f16x2f8; 16-bit in f16x2)"}
-                del mm
-                torch.cuda.empty_cache()
-            if a.model == "phi3v" and a.num_crops == 16 and not a.no_cpu_baseline:
+                # secondary figure: the single-pass f16 mode of the same workload.  NOT a parity mode (noise-limited):
+                # it counts as a product number only where its live golden check says PASS.
+                fm = leg(w, "f16", golden=(("ref_full_gpm2_ca" if pairwise else True) if (a.model != "phi3v" or a.num_crops == 16) and not a.lora_rank else None))
+                pc = fm.get("parity_check")
+                fm["parity"] = None if not pc else ("PASS" if pc["abs_err"] <= pc["tolerance"] else "FAIL")
+                fm["counts_as_product_number"] = fm["parity"] == "PASS"
+                res["fast_mode"] = fm
+            if headline and not a.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(res), flush=True)
     if world > 1:
