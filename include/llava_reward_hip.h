@@ -156,6 +156,12 @@ int lr_forward_qwen(lr_handle h, const int64_t* input_ids, const int64_t* attent
                     int pix_dtype, const int64_t* image_grid_thw_host, int n_images, int B, int S, int flags,
                     float* rewards_out, void* hip_stream);
 
+/* `outputs["last_hidden_state"]` of the last forward on this handle (rw_model_general_preference.py:347-353, returned by
+ * custom_forward(return_output=True) and read by the trainer's evaluate, rm_trainer_general_preference.py:414-418): the final
+ * RMSNorm of every token's residual stream (or the stream itself with no_final_norm, i.e. hidden_states[layer_id]), fp32
+ * [B*S, hidden] written to DEVICE memory `out_dev` on `stream`.  Off the scoring path: the forward itself only norms the row
+ * it gathers.  Valid until the next forward on the handle. */
+int lr_last_hidden_state(lr_handle h, float* out_dev, size_t capacity, int no_final_norm, void* hip_stream);
 /* Debug taps: copy an internal fp32 buffer of the last forward to host (synchronises).  Names:
  * "clip_x" [crops*T, Hc], "ev" [sumV, D], "x" [B*S, D] (residual stream after the last layer),
  * "hL" [B, D]; Qwen: "vit_x" [patches, vit_hidden] (window order), "ev" [patches/merge^2, D] (window order),

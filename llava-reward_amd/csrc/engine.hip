@@ -620,6 +620,19 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
     });
 }
 
+int lr_last_hidden_state(lr_handle h, float* out_dev, size_t capacity, int no_final_norm, void* hip_stream) {
+    if (!h || !out_dev) return LR_EINVAL;
+    return guarded(h, [&] {
+        if (!h->finalized || h->lastB <= 0) throw std::logic_error("lr_last_hidden_state: no forward has run on this handle");
+        const size_t rows = (size_t)h->lastB * h->lastS, D = (size_t)h->d.hidden;
+        if (capacity < rows * D) throw std::invalid_argument("lr_last_hidden_state: buffer too small");
+        hipStream_t st = (hipStream_t)hip_stream;
+        if (no_final_norm) LR_HIP_CHECK(hipMemcpyAsync(out_dev, h->x, rows * D * 4, hipMemcpyDeviceToDevice, st));
+        else launch_rms_rows_f32(h->x, h->norm_w, h->d.rms_eps, out_dev, (int)rows, (int)D, st);
+        LR_HIP_CHECK(hipGetLastError());
+    });
+}
+
 int lr_read_tap(lr_handle h, const char* name, float* host_out, size_t capacity, size_t* n) {
     if (!h || !name || !host_out || !n) return LR_EINVAL;
     return guarded(h, [&] {

@@ -69,6 +69,7 @@ _SIGS = {
                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "lr_forward_qwen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64),
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "lr_last_hidden_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "lr_read_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "lr_set_layer_limits": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "lr_set_gemm_tile": (C.c_int, [C.c_void_p, C.c_int]),

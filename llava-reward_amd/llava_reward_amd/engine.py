@@ -215,6 +215,15 @@ class RewardEngine:
             t.record_stream(torch.cuda.current_stream(dev))
         return out
 
+    def last_hidden_state(self, B: int, S: int, no_final_norm: bool = False) -> torch.Tensor:
+        """[B, S, hidden] fp32 on the device: final-norm output of every token of the last forward (lr_last_hidden_state)."""
+        dev = torch.device("cuda", self.device)
+        out = torch.empty(B, S, self.cfg.hidden, device=dev, dtype=torch.float32)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        L.check(self.lib, self.lib.lr_last_hidden_state(self.h, C.c_void_p(out.data_ptr()), out.numel(), 1 if no_final_norm else 0,
+                                                        C.c_void_p(stream)), self.h, "lr_last_hidden_state")
+        return out
+
     def read_tap(self, name: str, numel: int) -> np.ndarray:
         buf = np.empty(numel, dtype=np.float32)
         n = C.c_size_t(0)

@@ -6,7 +6,8 @@ Weights live on the host until `.to('cuda')`, which creates the HIP engine on th
 reference's `load_reward_adaptor` also returns a CPU model that the caller moves).
 Deviations, on purpose: rewards come back in fp32 (the reference returns the model dtype, bf16;
 SURVEY.md §7 shows bf16 rounding alone costs up to 2e-3); `outputs` for return_output=True holds
-only the tensors the engine keeps (final hidden row + projected vision tokens)."""
+`last_hidden_state` (what the reference's callers read) and the hidden row behind the reward, not the
+33 per-layer hidden states the backbone's output object carries."""
 from __future__ import annotations
 
 from typing import Dict, Optional
@@ -116,11 +117,24 @@ class RewardModel:
         inner = self.model_type == "phi3v" and self.layer_id != 32 and self.layer_id < self.config.layers
         self.engine.set_layer_limits(-1, self.layer_id if inner else -1)
         reward = self.engine.forward(input_ids, attention_mask, pixel_values, sz, training=self.training, no_final_norm=inner)
-        if return_output:
-            B, D = reward.shape[0], self.config.hidden
-            hl = torch.from_numpy(self.engine.read_tap("hL", B * D).reshape(B, D).copy())
-            return reward, {"last_hidden_state_at_reward_token": hl}
-        return reward, None
+        return self._finish(reward, input_ids.shape, return_output, inner)
+
+    def _finish(self, reward, shape, return_output, inner=False):
+        """Return convention of rw_model:407-448.  Train mode without mean pooling reads the LAST position (left-padded batches) and
+        the BT head then returns [B] (`values.squeeze(-1)[:, -1]`, :413-415) where eval returns [B, 1] (:420-421); GPM returns
+        [B, d] in both (:434, :439-444).  `outputs` (return_output=True, :422-425): the reference hands back the backbone's whole
+        output object; its callers read `last_hidden_state` (trainer evaluate, rm_trainer_general_preference.py:414), so that is
+        what is materialised here -- [B, S, hidden] fp32, made on demand from the engine's residual stream -- beside the hidden row
+        the reward was read from."""
+        if self.training and not self.is_general_preference and not self.mean_hidden_state:
+            reward = reward.squeeze(-1)
+        if not return_output:
+            return reward, None
+        B, S = int(shape[0]), int(shape[1])
+        D = self.config.hidden
+        hl = torch.from_numpy(self.engine.read_tap("hL", B * D).reshape(B, D).copy())
+        return reward, {"last_hidden_state": self.engine.last_hidden_state(B, S, no_final_norm=inner),
+                        "last_hidden_state_at_reward_token": hl}
 
     def _custom_forward_qwen(self, inputs_batch, return_output):
         """rw_model_general_preference.py:354-371: the qwen branch reads everything from `inputs_batch` (the
@@ -137,10 +151,6 @@ class RewardModel:
         if n_slots != n_feat:
             raise ValueError(f"Image features and image tokens do not match, tokens: {n_slots}, features: {n_feat}")
         reward = self.engine.forward_qwen(ids, mask, pix, grid, training=self.training)
-        if return_output:
-            B, D = reward.shape[0], self.config.hidden
-            hl = torch.from_numpy(self.engine.read_tap("hL", B * D).reshape(B, D).copy())
-            return reward, {"last_hidden_state_at_reward_token": hl}
-        return reward, None
+        return self._finish(reward, ids.shape, return_output)
 
     __call__ = custom_forward

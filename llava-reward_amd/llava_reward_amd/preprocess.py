@@ -164,3 +164,53 @@ def inference_process_phi3v_device(args, tokenizer, img_dir_list, caption, devic
         out.append({"input_ids": ids.to(device), "attention_mask": mask.to(device), "pixel_values": pix[b:b + 1],
                     "image_sizes": sizes[b:b + 1].to(device)})
     return out
+
+
+def zero_pad_sequences(sequences, side: str = "left", value=0):
+    """llava_reward/datasets/utils.py:5-13: rows of different length (last dim) -> one stacked tensor, padded with `value` on `side`.
+    Works on host or device tensors; one output allocation, one copy per row."""
+    assert side in ("left", "right")
+    max_len = max(int(seq.size(-1)) for seq in sequences)
+    first = sequences[0]
+    out = torch.full((len(sequences),) + tuple(first.shape[:-1]) + (max_len,), value, dtype=first.dtype, device=first.device)
+    for i, seq in enumerate(sequences):
+        n = int(seq.size(-1))
+        if side == "left":
+            out[i, ..., max_len - n:] = seq
+        else:
+            out[i, ..., :n] = seq
+    return out
+
+
+def collate_rows(rows, pad_token_id: int, squeeze: bool = True):
+    """The batch builder of the reference's dataset (reward_dataset.py:164-179 / :196-202) over per-row dicts as
+    inference_process_phi3v[_device] returns them (input_ids / attention_mask [1, S_i], pixel_values [1, C, 3, 336, 336],
+    image_sizes [1, 2]): ids LEFT-padded with the tokenizer's pad id, masks with 0, pixel tensors stacked -- on whatever device the
+    rows live, so rows prepared on the GPU never go back to the host.  The reference's collate keeps the singleton dim and its
+    callers squeeze it (eval/batch_inference_rm_phi.py:82-90); squeeze=True returns [B, S] / [B, C, 3, 336, 336] / [B, 2] directly."""
+    ids = zero_pad_sequences([r["input_ids"] for r in rows], value=pad_token_id)
+    mask = zero_pad_sequences([r["attention_mask"] for r in rows])
+    pix = torch.stack([r["pixel_values"] for r in rows], dim=0)
+    sizes = torch.stack([torch.as_tensor(r["image_sizes"]) for r in rows], dim=0)
+    out = {"input_ids": ids, "attention_mask": mask, "pixel_values": pix, "image_sizes": sizes}
+    if squeeze:
+        out = {k: (v.squeeze(1) if v.dim() > 1 and v.shape[1] == 1 else v) for k, v in out.items()}
+    return out
+
+
+def batch_inference_process_phi3v_device(args, tokenizer, items, device="cuda", num_crops: int = 16, pad_token_id: int = None):
+    """Rows for ONE batched custom_forward from (image path, caption) pairs with captions of any length: every image goes through
+    lr_hd_transform into one [B, num_crops+1, 3, 336, 336] tensor, every prompt is built and merged with its image slots as
+    inference_process_phi3v does (eval/reward_adaptor_loader.py:163-167), and the rows are left-padded into [B, S]
+    (collate_rows).  Returns the dict custom_forward(**batch) takes."""
+    from PIL import Image
+    imgs = [np.asarray(Image.open(path).convert("RGB")) for path, _ in items]
+    pix, sizes, ntok = hd_transform_batch(imgs, num_crops, device)
+    rows = []
+    for b, (_, caption) in enumerate(items):
+        msg = {"role": "user", "content": f"<|image_1|>\n{caption}"}
+        prompt = tokenizer.apply_chat_template([msg], tokenize=False, add_generation_prompt=True)[:-22] + tokenizer.eos_token
+        ids, mask = merge_text_and_image_slots(tokenizer, prompt, [ntok[b]])
+        rows.append({"input_ids": ids.to(device), "attention_mask": mask.to(device), "pixel_values": pix[b:b + 1], "image_sizes": sizes[b:b + 1]})
+    pad = pad_token_id if pad_token_id is not None else tokenizer.pad_token_id
+    return collate_rows(rows, pad)

@@ -31,12 +31,7 @@ def shard_rows(n: int, rank: int, world_size: int) -> slice:
     return slice(lo, lo + base + (1 if rank < rem else 0))
 
 
-def gather_rewards(local: torch.Tensor, n_total: Optional[int] = None) -> torch.Tensor:
-    """All-gather per-rank rewards [n_r, d] -> [n_total, d] on every rank (RCCL over xGMI on GPUs,
-    gloo on CPU tensors).  Ragged shards are padded to the largest shard for the collective."""
-    rank, ws = world()
-    if ws == 1:
-        return local
+def _all_gather(local: torch.Tensor, n_total: Optional[int], ws: int) -> torch.Tensor:
     n_local = local.shape[0]
     if n_total is None:
         out = torch.empty((ws * n_local,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -49,6 +44,52 @@ def gather_rewards(local: torch.Tensor, n_total: Optional[int] = None) -> torch.
     outs = [torch.empty_like(buf) for _ in range(ws)]
     dist.all_gather(outs, buf)
     return torch.cat([o[: s.stop - s.start] for o, s in zip(outs, sizes)], dim=0)
+
+
+_side_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+
+class GatherHandle:
+    """An all-gather of rewards in flight on the collective stream; `.wait()` makes the caller's stream depend on it and returns
+    the gathered [n_total, d] tensor."""
+
+    def __init__(self, out, stream=None):
+        self._out, self._stream = out, stream
+
+    def wait(self) -> torch.Tensor:
+        if self._stream is not None:
+            cur = torch.cuda.current_stream(self._out.device)
+            cur.wait_stream(self._stream)
+            self._out.record_stream(cur)
+            self._stream = None
+        return self._out
+
+
+def gather_rewards_async(local: torch.Tensor, n_total: Optional[int] = None) -> GatherHandle:
+    """All-gather per-rank rewards [n_r, d] -> [n_total, d] on every rank; ragged shards are padded to the largest shard for the
+    collective.  Device tensors under RCCL (backend "nccl"): the collective is enqueued on a dedicated stream behind an event of the
+    compute stream, so the next forward (the rejected rows of a pair) is not ordered behind it.  Device tensors
+    under a backend without device collectives (gloo) are staged through the host; host tensors gather as they are."""
+    rank, ws = world()
+    if ws == 1:
+        return GatherHandle(local)
+    if local.is_cuda and dist.get_backend() != "nccl":
+        return GatherHandle(_all_gather(local.cpu(), n_total, ws).to(local.device))
+    if not local.is_cuda:
+        return GatherHandle(_all_gather(local, n_total, ws))
+    dev = local.device
+    side = _side_streams.get(dev.index)
+    if side is None:
+        side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        out = _all_gather(local, n_total, ws)
+    local.record_stream(side)
+    return GatherHandle(out, side)
+
+
+def gather_rewards(local: torch.Tensor, n_total: Optional[int] = None) -> torch.Tensor:
+    return gather_rewards_async(local, n_total).wait()
 
 
 def _squeeze(b: Dict[str, torch.Tensor], rows: slice, device) -> Tuple[torch.Tensor, ...]:
@@ -112,8 +153,9 @@ def score_pairwise(model, args, batches: Iterable, device=None) -> Dict[str, obj
         n = inputs_c["input_ids"].shape[0]
         rows = shard_rows(n, rank, ws)
         c = _forward_rows(model, inputs_c, rows, device)
+        hc = gather_rewards_async(c, n)                  # in flight while the rejected rows are scored
         r = _forward_rows(model, inputs_r, rows, device)
-        c, r = gather_rewards(c, n), gather_rewards(r, n)
+        c, r = hc.wait(), gather_rewards(r, n)
         if not args.is_general_preference:
             chosen_list.extend(c.squeeze(-1).tolist())
             reject_list.extend(r.squeeze(-1).tolist())

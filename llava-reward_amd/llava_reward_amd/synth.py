@@ -351,6 +351,19 @@ def pad_left(batch: Dict[str, np.ndarray], k: int, pad_token_id: int = None) -> 
     return out
 
 
+def right_pad(batch: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """The same rows with their padding moved to the RIGHT (valid tokens first): what a right-padding tokenizer would collate."""
+    ids, mask = batch["input_ids"], batch["attention_mask"]
+    out = dict(batch)
+    out["input_ids"], out["attention_mask"] = ids.copy(), mask.copy()
+    for b in range(ids.shape[0]):
+        v = mask[b] == 1
+        n = int(v.sum())
+        out["input_ids"][b] = np.concatenate([ids[b][v], ids[b][~v]])
+        out["attention_mask"][b] = np.concatenate([np.ones(n, dtype=mask.dtype), np.zeros(len(v) - n, dtype=mask.dtype)])
+    return out
+
+
 class StandInTokenizer:
     """Deterministic stand-in for the Phi-3.5-V tokenizer (no tokenizer files exist offline) with the three members
     inference_process_phi3v uses (eval/reward_adaptor_loader.py:163-167): `apply_chat_template`, `eos_token`, `__call__`.

@@ -106,10 +106,15 @@ def fingerprint(t: torch.Tensor, n: int = 16):
             "vals": [float(v) for v in f[idx]]}
 
 
-def run_case(ref, name, cfg, seed, caption_lens, grids, max_crops, taps=True, layer_id=32, mean_hidden_state=None, extra_left_pad=0):
+def run_case(ref, name, cfg, seed, caption_lens, grids, max_crops, taps=True, layer_id=32, mean_hidden_state=None, extra_left_pad=0,
+             train=False, right_padded=False):
     print(f"[{name}] building", flush=True)
     model = build_reference_model(ref, cfg, seed, layer_id, mean_hidden_state)
+    if train:
+        model.train()          # rw_model:410-415 / :429-434: reward read at the last position; every dropout of the path has p = 0
     batch = synth.pad_left(synth.synth_batch(cfg, seed, caption_lens, grids, max_crops=max_crops), extra_left_pad)
+    if right_padded:
+        batch = synth.right_pad(batch)
     tb = {k: torch.from_numpy(v) for k, v in batch.items()}
     t0 = time.time()
     with torch.no_grad():
@@ -120,7 +125,8 @@ def run_case(ref, name, cfg, seed, caption_lens, grids, max_crops, taps=True, la
     out = {"name": name, "config": cfg.to_json(), "seed": seed, "caption_lens": caption_lens,
            "grids": [list(g) for g in grids] if not isinstance(grids[0], int) else list(grids),
            "max_crops": max_crops, "reward": reward.float().tolist(), "layer_id": layer_id,
-           "mean_hidden_state": bool(mean_hidden_state), "extra_left_pad": extra_left_pad,
+           "mean_hidden_state": bool(mean_hidden_state), "extra_left_pad": extra_left_pad, "train": train, "right_padded": right_padded,
+           "reward_shape": list(reward.shape),
            "reference_forward_seconds": dt, "threads": torch.get_num_threads(),
            "torch": torch.__version__, "dtype": "float32"}
     if taps:
@@ -381,6 +387,14 @@ def main():
         run_case(ref, "ref_small_rope_long_bt_ca", C(orig_max_pos=300, max_pos=9600), 31, [5, 9], (1, 1), None)
         run_case(ref, "ref_small_rope_long_allpad_gpm2_ca", C(orig_max_pos=330, max_pos=9600, is_general_preference=True, value_head_dim=2),
                  32, [5, 9], (1, 1), None, extra_left_pad=8)
+    elif which == "train":
+        # model.train(): the reward of the LAST position (rw_model:410-415 BT -> [B]; :429-434 GPM -> [B, d]), with left-padded rows (the
+        # trainer's collate) and with right-padded rows (the last position is then a pad position of the shorter row)
+        C = synth.ref_small_config
+        run_case(ref, "ref_small_train_bt_ca", C(), 41, [6, 3], (1, 1), None, taps=False, train=True)
+        run_case(ref, "ref_small_train_gpm2_ca_rightpad", C(is_general_preference=True, value_head_dim=2), 42, [6, 3], (1, 1), None, taps=False,
+                 train=True, right_padded=True)
+        run_case(ref, "ref_small_eval_bt_ca_rightpad", C(), 43, [2, 7], (1, 1), None, taps=False, right_padded=True)
     elif which == "pair_sample":
         run_pair_sample(ref)
     elif which == "full_gpm":

@@ -154,10 +154,16 @@ def test_reference_goldens_small(path, dtype, tol):
     grids = g["grids"]
     grids = tuple(grids) if isinstance(grids[0], int) else [tuple(x) for x in grids]
     batch = synth.pad_left(synth.synth_batch(cfg, g["seed"], g["caption_lens"], grids, max_crops=g["max_crops"]), g.get("extra_left_pad", 0))
+    if g.get("right_padded"):
+        batch = synth.right_pad(batch)
     ref = torch.tensor(g["reward"], dtype=torch.float32)
     m = _model(cfg, g["seed"], dtype, upload=False, max_batch=2, max_seq=1024, max_crops=5, layer_id=g.get("layer_id", 32),
                mean=g.get("mean_hidden_state", False))
-    got = _fwd(m, batch).reshape(ref.shape)
+    if g.get("train"):          # model.train(): reward of the last position; the BT head returns [B] (rw_model:413-415), GPM [B, d]
+        m.train()
+    got = _fwd(m, batch)
+    assert list(got.shape) == g.get("reward_shape", list(ref.shape))
+    got = got.reshape(ref.shape)
     err = (got - ref).abs().max().item()
     print(f"[{g['name']} {dtype}] max |reward err| vs reference = {err:.3e}")
     assert err < tol

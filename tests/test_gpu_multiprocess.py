@@ -1,0 +1,49 @@
+"""The multi-process path as far as ONE GPU allows (the driver owns the 8-GPU runs): two fresh rank processes share cuda:0, the real
+engine scores each rank's contiguous row shard, rewards are all-gathered (gloo: RCCL refuses two ranks on one device, so the
+RCCL transport itself stays unexercised here -- DESIGN.md §6 says so), and every rank must end with the single-process result bit
+for bit.  Also the bench's own N>1 branch (barrier, max-over-ranks timing, gather inside the step) with 2 ranks on one device."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HELPER = os.path.join(ROOT, "tests", "helpers", "two_rank_score.py")
+
+
+def _env(rank, ws, port):
+    e = dict(os.environ)
+    e.update(RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return e
+
+
+def test_two_rank_processes_on_one_gpu_equal_single_process(tmp_path):
+    port = 29600 + os.getpid() % 300
+    single = str(tmp_path / "single.json")
+    subprocess.run([sys.executable, HELPER, single], env=_env(0, 1, port), check=True, timeout=600)
+    outs = [str(tmp_path / f"rank{r}.json") for r in range(2)]
+    ps = [subprocess.Popen([sys.executable, HELPER, outs[r]], env=_env(r, 2, port)) for r in range(2)]
+    for p in ps:
+        assert p.wait(timeout=600) == 0
+    ref = json.load(open(single))
+    assert len(ref["probs"]) == 9
+    for r in range(2):
+        got = json.load(open(outs[r]))
+        assert got["rank"] == r and got["probs"] == ref["probs"] and got["proportion"] == ref["proportion"]      # bit-identical on every rank
+
+
+def test_bench_two_ranks_on_one_device(tmp_path):
+    port = 29900 + os.getpid() % 90
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "2", "--backend", "gloo", "--all-ranks-on-device", "0",
+           "--quick"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 4 and res["scaling"] == "weak" and res["value"] > 0
+    assert res["config"]["collective"].startswith("all_gather")

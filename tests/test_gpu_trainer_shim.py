@@ -1,0 +1,114 @@
+"""Training-side reuse and the device-side batch builder (§8 row a17) on the GPU.
+
+* llava_reward_amd.trainer_shim.concatenated_forward / evaluate mirror GeneralPreferenceRewardTrainer.concatenated_forward
+  (rm_trainer_general_preference.py:447-460) and its evaluate loop (:381-445); the train-mode return conventions
+  (rw_model_general_preference.py:410-415, :429-434) are pinned by goldens the reference produced in model.train() mode
+  (tests/golden/ref_small_train_*.json, make_goldens.py `train`; run by test_gpu_forward.test_reference_goldens_small).
+* batch_inference_process_phi3v_device: ragged captions -> one left-padded [B, S] batch on the device
+  (reward_dataset.py:164-179 + datasets/utils.py:5-13)."""
+import numpy as np
+import pytest
+import torch
+
+from llava_reward_amd import preprocess as P
+from llava_reward_amd import synth, trainer_shim
+from llava_reward_amd.model import RewardModel
+from oracle import phi3v_hd_transform_oracle as HD
+from oracle import phi3v_reward_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _pairwise_loss(tau):
+    """PairWiseLoss.forward of the reference's trainer (llava_reward/models/loss.py:120-129), as a trainer would pass it in."""
+    def f(c, r, margin=None):
+        d = (c - r - margin) if margin is not None else (c - r)
+        return -torch.nn.functional.logsigmoid(d / tau).mean(), torch.sigmoid(d / tau).mean()
+    return f
+
+
+def test_concatenated_forward_and_evaluate_match_the_oracle():
+    cfg = synth.tiny_config()
+    seed = 61
+    m = RewardModel(cfg, synth_seed=seed, max_batch=4, max_seq=1024, max_crops=5, operand_dtype="f16x2").to("cuda")
+    W = orc.weights_to_torch(synth.make_weights(cfg, seed))
+    batches = []
+    for k in range(2):
+        bc = synth.synth_batch(cfg, seed + k, [5, 8, 3], (1, 1))
+        br = synth.synth_batch(cfg, seed + 10 + k, [4, 4, 9], (1, 1))
+        # the dataloader's layout: every tensor with the collate's singleton dim (rm_trainer...:394-402 squeezes it)
+        batches.append(tuple(torch.from_numpy(b[key])[:, None] for b in (bc, br) for key in ("input_ids", "attention_mask", "pixel_values", "image_sizes")))
+    # train mode: last position, BT -> [B]
+    m.train()
+    c_ids, c_mask, c_pix, c_sz, r_ids, r_mask, r_pix, r_sz = [t.squeeze(1) for t in batches[0]]
+    c, r, outs = trainer_shim.concatenated_forward(m, c_ids.cuda(), c_mask.cuda(), c_pix.cuda(), c_sz, r_ids.cuda(), r_mask.cuda(), r_pix.cuda(), r_sz,
+                                                   return_output=True)
+    assert c.shape == (3,) and r.shape == (3,) and len(outs) == 2
+    ref_c = orc.custom_forward(W, cfg, c_ids, c_mask, c_pix, c_sz, training=True).squeeze(-1)
+    ref_r = orc.custom_forward(W, cfg, r_ids, r_mask, r_pix, r_sz, training=True).squeeze(-1)
+    assert (c.cpu() - ref_c).abs().max().item() < 1e-4 and (r.cpu() - ref_r).abs().max().item() < 1e-4
+    # outputs["last_hidden_state"] (what evaluate reads, :414): final norm of every token, [B, S, D]
+    taps = {}
+    orc.custom_forward(W, cfg, r_ids, r_mask, r_pix, r_sz, training=True, taps=taps)
+    x = taps[f"layer{cfg.layers - 1}"]
+    want = orc.rms_norm(x, W["model.norm.weight"], cfg.rms_eps)
+    got = outs[1]["last_hidden_state"].cpu()
+    valid = r_mask.bool()
+    assert got.shape == want.shape and (got - want)[valid].abs().max().item() < 2e-4 * want[valid].abs().max().item() + 1e-5
+    # evaluate: eval-mode rewards (EOS gather, [B, 1]), the trainer's loss, means over the batches, model left in train mode
+    tau = cfg.general_preference_tau
+    stats = trainer_shim.evaluate(m, batches, _pairwise_loss(tau))
+    assert m.training is True
+    exp_loss, exp_prob = [], []
+    for b in batches:
+        ci, cm, cp, cs, ri, rm, rp, rs = [t.squeeze(1) for t in b]
+        ec = orc.custom_forward(W, cfg, ci, cm, cp, cs)
+        er = orc.custom_forward(W, cfg, ri, rm, rp, rs)
+        l, p = _pairwise_loss(tau)(ec, er)
+        exp_loss.append(float(l)); exp_prob.append(float(p))
+    assert abs(stats["eval_loss_mean"] - np.mean(exp_loss)) < 2e-3 and abs(stats["prob_mean"] - np.mean(exp_prob)) < 1e-3
+    # GPM head in train mode: [B, d]
+    cfg2 = synth.tiny_config(is_general_preference=True, value_head_dim=2)
+    m2 = RewardModel(cfg2, synth_seed=seed, max_batch=4, max_seq=1024, max_crops=5, operand_dtype="f16x2").to("cuda").train()
+    g, _ = m2.custom_forward(c_ids.cuda(), c_mask.cuda(), c_pix.cuda(), c_sz)
+    W2 = orc.weights_to_torch(synth.make_weights(cfg2, seed))
+    assert g.shape == (3, 2) and (g.cpu() - orc.custom_forward(W2, cfg2, c_ids, c_mask, c_pix, c_sz, training=True)).abs().max().item() < 1e-4
+
+
+def test_ragged_captions_collated_on_the_device(tmp_path):
+    """Three (image, caption) items with captions of different length -> ONE custom_forward over a left-padded [3, S] batch built
+    without leaving the GPU.  Checked against the oracle on the same collated batch (pixels from the HD-transform oracle), and the
+    layout against the reference's collate rules: ids padded on the left with the tokenizer's pad id, masks with 0."""
+    from PIL import Image
+    cfg = synth.tiny_config(is_general_preference=True, value_head_dim=2)
+    seed = 67
+    tok = synth.StandInTokenizer()
+    caps = ["a cat", "a considerably longer caption about a dog on a skateboard", "tree"]
+    items, imgs = [], []
+    for i, (hw, cap) in enumerate(zip([(200, 300), (336, 336), (300, 200)], caps)):
+        a = synth.synth_image(seed, f"collate.{i}", hw[0], hw[1], True)
+        p = str(tmp_path / f"im{i}.png")
+        Image.fromarray(a).save(p)
+        items.append((p, cap)); imgs.append(a)
+    batch = P.batch_inference_process_phi3v_device(None, tok, items, device="cuda", num_crops=4, pad_token_id=cfg.vocab_size - 1)
+    ids, mask = batch["input_ids"], batch["attention_mask"]
+    assert ids.is_cuda and ids.dim() == 2 and ids.shape == mask.shape and batch["pixel_values"].shape == (3, 5, 3, 336, 336)
+    lens = mask.sum(dim=1).tolist()
+    S = ids.shape[1]
+    assert max(lens) == S and len(set(lens)) > 1                      # ragged; the longest row un-padded
+    for b, n in enumerate(lens):
+        assert mask[b, : S - n].sum() == 0 and mask[b, S - n:].all() and (ids[b, : S - n] == cfg.vocab_size - 1).all()
+    m = RewardModel(cfg, synth_seed=seed, max_batch=4, max_seq=1024, max_crops=5, operand_dtype="f16x2").to("cuda").eval()
+    got, _ = m.custom_forward(**batch)
+    W = orc.weights_to_torch(synth.make_weights(cfg, seed))
+    pix = np.stack([HD.preprocess(a, 4)[0] for a in imgs])
+    ref = orc.custom_forward(W, cfg, ids.cpu(), mask.cpu(), pix, batch["image_sizes"])
+    err = (got.cpu() - ref).abs().max().item()
+    print(f"[device collate] max |reward err| = {err:.2e}")
+    assert err < 1e-4
+    # the rows, scored one by one from inference_process_phi3v_device (B = 1, no padding), agree with their batched rewards:
+    # all three images give the same V here (V_max does not change), only the padding and the position of the row differ
+    for b, (p, cap) in enumerate(items):
+        row = P.inference_process_phi3v_device(None, tok, [p], cap, num_crops=4)[0]
+        one, _ = m.custom_forward(**row)
+        assert (one[0] - got[b]).abs().max().item() < 2e-5

@@ -372,3 +372,23 @@ def test_shard_qwen_batch_rows_and_images():
     bad["image_grid_thw"] = tb["image_grid_thw"][:-1]
     with pytest.raises(ValueError, match="do not match"):
         shard_qwen_batch(bad, slice(0, 5), cfg.image_token_id, cfg.vision.merge_unit)
+
+
+def test_zero_pad_sequences_and_collate_rows_follow_the_reference_rules():
+    """datasets/utils.py:5-13 + reward_dataset.py:164-179: left padding with the pad id / 0, pixel tensors stacked; host tensors here,
+    the same code runs on device tensors (tests/test_gpu_trainer_shim.py)."""
+    import torch.nn.functional as F
+    from llava_reward_amd import collate_rows, zero_pad_sequences
+    seqs = [torch.arange(1, 4)[None], torch.arange(1, 7)[None], torch.arange(5, 6)[None]]
+    for side in ("left", "right"):
+        got = zero_pad_sequences(seqs, side, 9)
+        exp = torch.stack([F.pad(q, (6 - q.size(-1), 0) if side == "left" else (0, 6 - q.size(-1)), value=9) for q in seqs])
+        assert torch.equal(got, exp) and got.shape == (3, 1, 6)
+    rows = [{"input_ids": q, "attention_mask": torch.ones_like(q), "pixel_values": torch.full((1, 2, 3, 4, 4), float(i)),
+             "image_sizes": torch.tensor([[336, 336 * (i + 1)]])} for i, q in enumerate(seqs)]
+    b = collate_rows(rows, pad_token_id=7)
+    assert b["input_ids"].tolist() == [[7, 7, 7, 1, 2, 3], [1, 2, 3, 4, 5, 6], [7, 7, 7, 7, 7, 5]]
+    assert b["attention_mask"].tolist() == [[0, 0, 0, 1, 1, 1], [1] * 6, [0, 0, 0, 0, 0, 1]]
+    assert b["pixel_values"].shape == (3, 2, 3, 4, 4) and b["pixel_values"][2].eq(2.0).all() and b["image_sizes"].tolist() == [[336, 336], [336, 672], [336, 1008]]
+    raw = collate_rows(rows, pad_token_id=7, squeeze=False)          # the reference's own layout: singleton dim kept (:82-90 squeeze it)
+    assert raw["input_ids"].shape == (3, 1, 6) and raw["pixel_values"].shape == (3, 1, 2, 3, 4, 4)

@@ -31,10 +31,12 @@ def test_oracle_matches_reference(path):
     grids = g["grids"]
     grids = tuple(grids) if isinstance(grids[0], int) else [tuple(x) for x in grids]
     batch = synth.pad_left(synth.synth_batch(cfg, g["seed"], g["caption_lens"], grids, max_crops=g["max_crops"]), g.get("extra_left_pad", 0))
+    if g.get("right_padded"):
+        batch = synth.right_pad(batch)
     taps = {}
     r = orc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"],
                            batch["image_sizes"], taps=taps, layer_id=g.get("layer_id", 32),
-                           mean_hidden_state=g.get("mean_hidden_state", False))
+                           mean_hidden_state=g.get("mean_hidden_state", False), training=g.get("train", False))
     ref = np.array(g["reward"], dtype=np.float32).reshape(r.shape)
     assert np.abs(r.numpy() - ref).max() < TOL, (r, ref)
     # stage fingerprints localise any divergence; only valid (non-pad) rows are comparable
