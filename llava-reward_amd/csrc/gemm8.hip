@@ -890,7 +890,7 @@ void launch_gemm_bt8_fp8(GemmParams p, int operand_dtype, hipStream_t st) {
 
 // Split-operand mode with the e4m3 residual pass (kernel form F8 == 2, see there).  p as for the 16-bit split form but
 // K = kw + kw / 2 (2-byte units), Wlo = the rows that hold W8, aexp / wexp = the E8M0 scales.
-void launch_gemm_bt8_mixed(const GemmParams& p0, int operand_dtype, hipStream_t st) {
+void launch_gemm_bt8_mixed(const GemmParams& p0, int operand_dtype, hipStream_t st, int dbg) {
     if (p0.M <= 0) return;
     GemmParams p = p0;
     if (p.kw <= 0 || p.kw % 128 || !p.Wlo || !p.aexp || (p.aexp2 && p.Wlo16))
@@ -900,6 +900,11 @@ void launch_gemm_bt8_mixed(const GemmParams& p0, int operand_dtype, hipStream_t 
         throw std::runtime_error("gemm_bt8_mixed: N and ldc must be multiples of 8 and C/bias 16-byte aligned");
     if (p.epi == EPI_ROPE_OP && (!p.rope_cs || p.rope_hd % 16 || p.rope_cols % 256 || p.rope_cols % p.rope_hd || ((uintptr_t)p.rope_cs & 15)))
         throw std::runtime_error("gemm_bt8_mixed: bad RoPE epilogue parameters");
+    if (dbg == 2) {          // diagnostic (tools/gemm_epi_probe.py): the same K loop without the epilogue; results are not written
+        if (operand_dtype != DT_F16) throw std::runtime_error("gemm_bt8_mixed: the no-epilogue diagnostic is built for F16 only");
+        launch8<F16, 6, 2, EPI_OUT_F32, 2, 2>(p, true, st);
+        return;
+    }
     if (operand_dtype == DT_F16) launch8_epi<F16, 6, 0, 2, 2>(p, true, st);
     else launch8_epi<BF16, 6, 0, 2, 2>(p, true, st);
 }

@@ -13,7 +13,7 @@ bool gemm_bt_is_deep(const GemmParams& p, int tile);
 void launch_gemm_bt8(const GemmParams& p, int operand_dtype, int variant, hipStream_t st);
 // W8A8: e4m3 operands (K, lda, ldw in bytes), per-row / per-channel fp32 scales in p.ascale / p.wscale
 void launch_gemm_bt8_fp8(GemmParams p, int operand_dtype, hipStream_t st);
-void launch_gemm_bt8_mixed(const GemmParams& p, int operand_dtype, hipStream_t st);
+void launch_gemm_bt8_mixed(const GemmParams& p, int operand_dtype, hipStream_t st, int dbg = 0);
 void launch_quantize_lo_inplace(void* a, int ld, int K, int rows, int* aexp, int operand_dtype, hipStream_t st, int* aexp2 = nullptr);
 void prepare_weight_e4m3_pair(const void* w, void* twin, int ldw, int K, int N, void* tmp, int operand_dtype, unsigned* scratch_word,
                               hipStream_t st, int* wexp, int* wexp2);

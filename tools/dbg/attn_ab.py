@@ -1,0 +1,31 @@
+import ctypes as C, math, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "llava-reward_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch
+from llava_reward_amd import _lib as L
+libs = {"new": L.load(), "old": L.load(os.path.join(ROOT, "tools", "dbg", "lib_old_attn.so"))}
+def bench(lib, B, S, H, hd, causal, Hkv, reps=5):
+    W = (H + 2 * Hkv) * hd
+    torch.manual_seed(0)
+    qkv = torch.cat([torch.randn(B * S, W, device="cuda").half(), (torch.randn(B * S, W, device="cuda") * 2.0 ** -12).half()], dim=1).contiguous()
+    out = torch.zeros(B * S, 2 * H * hd, device="cuda", dtype=torch.float16)
+    mask = torch.ones(B, S, dtype=torch.int64, device="cuda") if causal else None
+    kmin = torch.zeros(B, dtype=torch.int32, device="cuda") if causal else None
+    st = torch.cuda.current_stream()
+    P = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
+    args = (P(qkv), P(qkv), P(qkv), P(out), P(mask), P(kmin), 2 * W, 2 * H * hd, 0, H * hd, (H + Hkv) * hd, W, H * hd, B, S, H, hd, int(causal), H // Hkv,
+            1.0 / math.sqrt(hd), L.LR_DT_F16, C.c_void_p(st.cuda_stream))
+    assert lib.lr_op_attention_split(*args) == 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(reps):
+        lib.lr_op_attention_split(*args)
+    e1.record(st); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps, out.clone()
+for name, cfgs in (("phi", (32, 2642, 32, 96, True, 32)), ("clip", (544, 577, 16, 64, False, 16)), ("llava", (64, 1313, 32, 128, True, 8))):
+    res = {}
+    for rnd in range(3):
+        for k, lib in libs.items():
+            ms, o = bench(lib, *cfgs)
+            res.setdefault(k, []).append(ms); res[k + "_o"] = o
+    print(name, {k: [round(x, 3) for x in v] for k, v in res.items() if not k.endswith("_o")}, "bit-identical:", torch.equal(res["new_o"], res["old_o"]))

@@ -19,6 +19,10 @@ __global__ __launch_bounds__(512) void rate(float* out, int iters, unsigned seed
         for (int j = 0; j < 8; ++j) {
             if (KIND == 0) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c[j], 0, 0, 0);
             else if (KIND == 1) c[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c[j], 0, 0, 0, 127, 0, 127);
+            else if (KIND == 2) c[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c[j], 2, 2, 0, 127, 0, 127);      // fp6 e2m3 x fp6 e2m3
+            else if (KIND == 3) c[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c[j], 4, 4, 0, 127, 0, 127);      // fp4 e2m1 x fp4 e2m1
+            else if (KIND == 4) c[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c[j], 2, 0, 0, 127, 0, 127);      // fp6 x e4m3
+            else if (KIND == 5) c[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c[j], 2, 4, 0, 127, 0, 127);      // fp6 x fp4
         }
     }
     float s = 0;
@@ -43,7 +47,11 @@ template <int KIND> static void run(const char* name, double flop_per_mfma) {
 int main() {
     run<0>("f16 16x16x32", 2.0 * 16 * 16 * 32);
     run<1>("e4m3 16x16x128 (scale 2^0)", 2.0 * 16 * 16 * 128);
-    run<0>("f16 16x16x32", 2.0 * 16 * 16 * 32);
+    run<2>("fp6 e2m3 16x16x128", 2.0 * 16 * 16 * 128);
+    run<3>("fp4 e2m1 16x16x128", 2.0 * 16 * 16 * 128);
+    run<4>("fp6 x e4m3 16x16x128", 2.0 * 16 * 16 * 128);
+    run<5>("fp6 x fp4 16x16x128", 2.0 * 16 * 16 * 128);
+    run<2>("fp6 e2m3 16x16x128", 2.0 * 16 * 16 * 128);
     run<1>("e4m3 16x16x128 (scale 2^0)", 2.0 * 16 * 16 * 128);
     return 0;
 }
