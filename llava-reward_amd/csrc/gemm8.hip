@@ -606,7 +606,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 #pragma unroll
                 for (int it = 0; it < 8; ++it) ca[it] = cload(it);
             }
-            // RoPE epilogue: the (cos, sin) rows are prefetched the same way (ca: iterations 0-3, cb: 4-7; 2 float4 each)
+            // RoPE epilogue: the (cos, sin) rows of iterations 0-3 are prefetched the same way (2 float4 each)
             const bool rot = E_ == EPI_ROPE_OP && n0 < p.rope_cols;         // rope_cols is a multiple of the tile width
             auto rload = [&](int it, int k) {
                 const int row = min(rowq + it * 16 + wave * 2 + (lane >> 5), p.M - 1);
@@ -634,12 +634,6 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
             if constexpr (E_ == EPI_RESADD_F32) {
 #pragma unroll
                 for (int it = 0; it < 8; ++it) cb[it] = cload(8 + it);
-            }
-            if constexpr (E_ == EPI_ROPE_OP) {
-                if (rot) {
-#pragma unroll
-                    for (int it = 0; it < 4; ++it) { cb[2 * it] = rload(4 + it, 0); cb[2 * it + 1] = rload(4 + it, 1); }
-                }
             }
             __syncthreads();
             if constexpr (E_ == EPI_SWIGLU_OP) {
@@ -705,11 +699,16 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                         if (p.split > 0) *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + p.split + col) = wl;
                     }
                 };
+                // the (cos, sin) rows of iterations 4-7 are requested as iterations 0-3 release their registers (one set of 8 float4
+                // instead of two: with both prefetched the epilogue spilled ~100 registers per lane around the staging pass)
 #pragma unroll
-                for (int it = 0; it < 4; ++it) body(it, ca[2 * it], ca[2 * it + 1]);
+                for (int it = 0; it < 4; ++it) {
+                    body(it, ca[2 * it], ca[2 * it + 1]);
+                    if (rot) { ca[2 * it] = rload(4 + it, 0); ca[2 * it + 1] = rload(4 + it, 1); }
+                }
                 __builtin_amdgcn_sched_barrier(0);          // keep the second half's LDS reads out of the first half's live range
 #pragma unroll
-                for (int it = 0; it < 4; ++it) body(4 + it, cb[2 * it], cb[2 * it + 1]);
+                for (int it = 0; it < 4; ++it) body(4 + it, ca[2 * it], ca[2 * it + 1]);
             } else if constexpr (E_ == EPI_OUT_OP) {
                 // 256 columns = 32 chunks of 8: 32 lanes per row, 2 rows per wave-iteration
                 const int c8 = lane & 31;

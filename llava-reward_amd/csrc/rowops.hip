@@ -126,6 +126,99 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
     }
 }
 
+// The same norm with 8 consecutive elements per lane and iteration (H % 8 == 0, group == 1: every norm of the three backbones at
+// their real widths): 32 contiguous bytes read, 16 bytes of hi and 16 (16-bit) or 8 (e4m3) bytes of residuals stored per lane,
+// instead of 8- and 4-byte stores (cdna_hip_programming.md Guideline 13).  HBM-bound: x fp32 in, [hi | lo] out.
+template <typename OT, bool LAYERNORM>
+__global__ __launch_bounds__(256) void norm_rows8_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ b, void* __restrict__ y, int rows,
+                                                         int H, float eps, int prec, int* __restrict__ lo8) {
+    constexpr int MAXI = NORM_MAXC / 2;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int n8 = H >> 3;
+    const float4* xr = (const float4*)(x + (size_t)row * H);
+    float v[MAXI][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = lane + 64 * i;
+        if (c < n8) {
+            const float4 a0 = xr[2 * c], a1 = xr[2 * c + 1];
+            v[i][0] = a0.x; v[i][1] = a0.y; v[i][2] = a0.z; v[i][3] = a0.w; v[i][4] = a1.x; v[i][5] = a1.y; v[i][6] = a1.z; v[i][7] = a1.w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += LAYERNORM ? v[i][j] : v[i][j] * v[i][j];
+        }
+    }
+    s = wave_sum(s);
+    float mean = 0.f, rstd;
+    if (LAYERNORM) {
+        mean = s / H;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i)
+            if (lane + 64 * i < n8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float a = v[i][j] - mean; q += a * a; }
+            }
+        q = wave_sum(q);
+        rstd = rsqrtf(q / H + eps);
+    } else {
+        rstd = rsqrtf(s / H + eps);
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = lane + 64 * i;
+        if (c < n8) {
+            const float4 w0 = ((const float4*)w)[2 * c], w1 = ((const float4*)w)[2 * c + 1];
+            const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = (v[i][j] - mean) * rstd * ww[j];
+            if (LAYERNORM) {
+                const float4 b0 = ((const float4*)b)[2 * c], b1 = ((const float4*)b)[2 * c + 1];
+                const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[i][j] += bb[j];
+            }
+            if (lo8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[i][j] - Op<OT>::to_f32(Op<OT>::from_f32(v[i][j]))));
+            }
+        }
+    }
+    int E = 127;
+    if (lo8) {
+        amax = wave_max(amax);
+        E = e8m0_of_amax(amax);
+        if (lane == 0) lo8[row] = E;
+    }
+    unsigned short* dst = (unsigned short*)y + (size_t)row * ((size_t)H << prec);
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = lane + 64 * i;
+        if (c < n8) {
+            unsigned short hb[8];
+            float r[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { hb[j] = Op<OT>::from_f32(v[i][j]); r[j] = v[i][j] - Op<OT>::to_f32(hb[j]); }
+            *(uint4*)(dst + 8 * c) = make_uint4(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16),
+                                                hb[4] | ((unsigned)hb[5] << 16), hb[6] | ((unsigned)hb[7] << 16));
+            if (lo8) {          // residual half as e4m3 scaled by the row's power of two (what quantize_lo_inplace_kernel would write)
+                int p0 = 0, p1 = 0;
+                p0 = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(r[0], 127 - E), ldexpf(r[1], 127 - E), p0, false);
+                p0 = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(r[2], 127 - E), ldexpf(r[3], 127 - E), p0, true);
+                p1 = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(r[4], 127 - E), ldexpf(r[5], 127 - E), p1, false);
+                p1 = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(r[6], 127 - E), ldexpf(r[7], 127 - E), p1, true);
+                *(uint2*)((unsigned char*)(dst + H) + 8 * c) = make_uint2((unsigned)p0, (unsigned)p1);
+            } else if (prec) {
+                *(uint4*)(dst + H + 8 * c) = make_uint4(pack2<OT>(r[0], r[1]), pack2<OT>(r[2], r[3]), pack2<OT>(r[4], r[5]), pack2<OT>(r[6], r[7]));
+            }
+        }
+    }
+}
+
 void launch_norm_rows(const float* x, const float* w, const float* b, void* y, int rows, int H, float eps,
                       int operand_dtype, hipStream_t st, int prec, int group, int* lo8) {
     if (rows <= 0) return;
@@ -134,6 +227,16 @@ void launch_norm_rows(const float* x, const float* w, const float* b, void* y, i
     if (H % 4 || H > NORM_MAXC * 256) throw std::runtime_error("norm_rows: H must be a multiple of 4 and <= 4096");
     dim3 g(cdiv(rows, 4)), t(256);
     const bool f16 = operand_dtype == DT_F16;
+    if (group == 1 && H % 8 == 0 && (((uintptr_t)y) & 15) == 0 && (((uintptr_t)w) & 15) == 0 && (!b || (((uintptr_t)b) & 15) == 0)) {
+        if (b) {
+            if (f16) hipLaunchKernelGGL((norm_rows8_kernel<F16, true>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, lo8);
+            else hipLaunchKernelGGL((norm_rows8_kernel<BF16, true>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, lo8);
+        } else {
+            if (f16) hipLaunchKernelGGL((norm_rows8_kernel<F16, false>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, lo8);
+            else hipLaunchKernelGGL((norm_rows8_kernel<BF16, false>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, lo8);
+        }
+        return;
+    }
     if (b) {
         if (f16) hipLaunchKernelGGL((norm_rows_kernel<F16, true>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group, lo8);
         else hipLaunchKernelGGL((norm_rows_kernel<BF16, true>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group, lo8);
