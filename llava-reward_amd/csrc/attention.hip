@@ -234,17 +234,35 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
                 for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks) {
+#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 2)      // diagnostic build: no LDS fragment reads
+                    const uint4 kf = qf[(ks + 1) % KSTEPS];
+#else
                     const uint4 kf = *(const uint4*)(sK + koff[kt][ks]);
+#endif
                     s[kt] = Op<OT>::mfma32(kf, qf[ks], s[kt]);
                     if constexpr (PREC) {
                         s[kt] = Op<OT>::mfma32(kf, qfl[ks], s[kt]);
+#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 2)
+                        const uint4 kl = qfl[(ks + 1) % KSTEPS];
+#else
                         const uint4 kl = *(const uint4*)(sK + 2 * TILE + koff[kt][ks]);
+#endif
                         s[kt] = Op<OT>::mfma32(kl, qf[ks], s[kt]);
                     }
                 }
             }
         };
         auto soft = [&](int t) {
+#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 1)      // diagnostic build (tools/dbg): no softmax arithmetic, results invalid
+            for (int kt = 0; kt < 2; ++kt)
+                for (int st = 0; st < 2; ++st) {
+                    uint4& f = pf[2 * kt + st];
+                    f.x = pack2_fast<OT>(s[kt][8 * st + 0], s[kt][8 * st + 1]); f.y = pack2_fast<OT>(s[kt][8 * st + 2], s[kt][8 * st + 3]);
+                    f.z = pack2_fast<OT>(s[kt][8 * st + 4], s[kt][8 * st + 5]); f.w = pack2_fast<OT>(s[kt][8 * st + 6], s[kt][8 * st + 7]);
+                    if constexpr (PREC) pl[2 * kt + st] = f;
+                }
+            return;
+#endif
             const int k0 = kbeg + t * KT;
             const unsigned blo = __builtin_amdgcn_readfirstlane(sBits[2 * (k0 / KT)]);
             const unsigned bhi = __builtin_amdgcn_readfirstlane(sBits[2 * (k0 / KT) + 1]);
@@ -316,19 +334,28 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
 #pragma unroll
                     for (int d = 0; d < DT; ++d) {
                         const char* vb = sV + (kt * 32 + 16 * st) * ROW + voff[d];
+#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 2)
+                        (void)vb;
+                        const uint4 vf = qf[d], vl_diag = qfl[d];
+#else
                         const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb));
                         const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * ROW));
                         uint4 vf;
                         const uint2 a = __builtin_bit_cast(uint2, v0), c = __builtin_bit_cast(uint2, v1);
                         vf.x = a.x; vf.y = a.y; vf.z = c.x; vf.w = c.y;
+#endif
                         o[d] = Op<OT>::mfma32(vf, pf[2 * kt + st], o[d]);
                         if constexpr (PREC) {
                             o[d] = Op<OT>::mfma32(vf, pl[2 * kt + st], o[d]);
+#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 2)
+                            const uint4 vl = vl_diag;
+#else
                             const s16x4 w0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 2 * TILE));
                             const s16x4 w1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 2 * TILE + 8 * ROW));
                             uint4 vl;
                             const uint2 a2 = __builtin_bit_cast(uint2, w0), c2 = __builtin_bit_cast(uint2, w1);
                             vl.x = a2.x; vl.y = a2.y; vl.z = c2.x; vl.w = c2.y;
+#endif
                             o[d] = Op<OT>::mfma32(vl, pf[2 * kt + st], o[d]);
                         }
                     }
