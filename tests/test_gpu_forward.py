@@ -131,8 +131,9 @@ def test_training_flag_and_errors():
     tr = _fwd(m, batch)
     m.eval()
     # row 1 is un-padded: last position == last valid token; row 0 is left-padded and its last position is
-    # also its last valid token (left padding), so both modes agree (rw_model:410-421)
-    assert torch.equal(ev, tr)
+    # also its last valid token (left padding), so both modes agree (rw_model:410-421) -- in value; the BT head returns
+    # [B] in train mode (values.squeeze(-1)[:, -1], :413-415) and [B, 1] in eval mode (:420-421)
+    assert ev.shape == (2, 1) and tr.shape == (2,) and torch.equal(ev.squeeze(-1), tr)
     bad = dict(batch)
     bad["input_ids"] = batch["input_ids"].copy()
     bad["input_ids"][0, -1] = -1          # one image slot too many

@@ -153,7 +153,8 @@ def test_qwen_training_flag_and_errors():
     m.train()
     tr = _fwd(m, batch)
     m.eval()
-    assert torch.equal(ev, tr)                       # left padding: last position == last valid token (rw_model:410-421)
+    # left padding: last position == last valid token (rw_model:410-421); BT head: [B] in train mode, [B, 1] in eval mode
+    assert ev.shape == (2, 1) and tr.shape == (2,) and torch.equal(ev.squeeze(-1), tr)
     bad = dict(batch)
     bad["input_ids"] = batch["input_ids"].copy()
     bad["input_ids"][0, -2] = cfg.image_token_id     # one image slot too many
