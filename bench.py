@@ -369,6 +369,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": f"{a.dtype} MFMA operands (bf16-valued weights), f32 accumulate/residual/softmax",
             "data": "synthetic (seeded weights and inputs; no checkpoint offline)",
+            "hbm_bytes": {"workspace": model.engine.workspace_bytes(), "note": "activation workspace sized for (rows_per_gpu, seq_len) at lr_finalize; weights "
+                          "(operand copies + residual / e4m3 twins in the split-operand modes) are extra"},
             "config": {"workload": w["name"] + ", S=%d" % S + (", un-merged LoRA adapter r=%d on the decoder linears" % a.lora_rank if a.lora_rank else ""),
                        "rows_per_gpu": B, "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
                        "collective": "all_gather rewards [B,%d] fp32" % cfg.value_head_dim if world > 1 else "none"},
@@ -428,6 +430,7 @@ def main():
                 m = build_model(wl, dtype, fp32_valued)
                 ms = timed_steps(lambda: forward(m, wl), 1, steps)
                 out = {"dtype": dtype, "value": wl["B"] / (ms * 1e-3), "unit": "reward-pairs/sec", "ms_per_step": ms, "rows_per_step": wl["B"],
+                       "workspace_bytes": m.engine.workspace_bytes(),
                        "roofline_frac_whole_pass": wl["B"] / (ms * 1e-3) * wl["flop"] / 1e12 / PEAK_TFLOPS}
                 if golden:
                     out["parity_check"] = golden_check(m, wl["model"], golden if isinstance(golden, str) else None)
@@ -452,6 +455,7 @@ def main():
                 ga = type("A", (), dict(is_general_preference=True, value_head_dim=2, general_preference_tau=wg["cfg"].general_preference_tau))
                 msg = timed_steps(lambda: preference_compute(ga, forward(mg, wg), forward(mg, wg, pg)), 1, 2)
                 res["gpm_pairwise"] = {"workload": wg["name"] + ", B=64 rows per forward", "dtype": a.dtype, "value": 128 / (msg * 1e-3), "unit": "reward-pairs/sec",
+                                       "workspace_bytes": mg.engine.workspace_bytes(),
                                        "preference_pairs_per_sec": 64 / (msg * 1e-3), "ms_per_step": msg,
                                        "step": "chosen forward + rejected forward + preference_compute", "parity_check": golden_check(mg, "phi3v", "ref_full_gpm2_ca")}
                 release(mg)

@@ -200,6 +200,8 @@ void run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_ma
             if (tiles_ok && (L.lqkv.k2 > 0 || w8a8_eligible(h, probe) || lo8_eligible(h, probe) || gemm_bt_is_deep(probe, h->gemm_tile))) {
                 gemm_p(h, st, gp, &L.lqkv);
             } else {
+                // (pre-RoPE fp32 projections: only this fallback needs them, so the 3.1 GB at B=32 are allocated on its first use)
+                if (!h->qkv32) h->qkv32 = (float*)h->dalloc(((size_t)d.max_batch * d.max_seq + 256) * Nqkv * 4, false);
                 gemm(h, st, h->h, L.qkv_w, h->qkv32, L.qkv_b, Rl, Nqkv, D, D, D, Nqkv, EPI_OUT_F32, ACT_NONE, &L.lqkv);
                 launch_rope_split(h->qkv32, h->cs, h->qkv, Rl, Hq + Hkv, Hkv, h->hd, h->op_dt, st, h->prec);
             }
@@ -430,7 +432,7 @@ int lr_finalize(lr_handle h) {
             h->hdA = W(SV * 4 * Hc * ob); h->proj1 = W(SV * D * ob);
         }
         h->ev = (float*)W(SV * D * 4);
-        h->x = (float*)W(Rl * D * 4); h->h = W(Rl * D * ob); h->qkv32 = (float*)W(Rl * h->Nqkv * 4); h->qkv = W(Rl * h->Nqkv * ob);
+        h->x = (float*)W(Rl * D * 4); h->h = W(Rl * D * ob); h->qkv = W(Rl * h->Nqkv * ob);
         h->att = W(Rl * h->Hq * ob); h->ff = W(Rl * I * ob); h->cs = (float*)W(Rl * h->hd * 4);
         if (h->lora_k2max > 0) h->lt = W(Rl * (size_t)h->lora_k2max * ob);
         h->pos_ids = (int*)W(Rl * 4); h->img_row = (int*)W(Rl * 4); h->tstat = (int*)W(B * 16);

@@ -181,10 +181,10 @@ void finalize_qwen(lr_engine* h) {
     auto W = [&](size_t bytes) { return h->dalloc(bytes, false); };
     const size_t ob = 2 * (size_t)(1 + h->prec);      // bytes per operand element (hi [+ lo])
     h->vA = W(Rv * h->vKpad * ob); h->vx = (float*)W(Rv * h->vH * 4); h->vhn = W(Rv * h->vH * ob);
-    h->vqkv = W(Rv * 3 * h->vHp * ob); h->vqkv32 = (float*)W(Rv * 3 * h->vHp * 4); h->vatt = W(Rv * h->vHp * ob);
+    h->vqkv = W(Rv * 3 * h->vHp * ob); h->vatt = W(Rv * h->vHp * ob);
     h->vff = W(Rv * h->vIp * ob); h->vcs = (float*)W(Rv * h->vhdp * 4); h->vm1 = W(Rm * h->vHm * ob);
     h->ev = (float*)W(Rm * D * 4);
-    h->x = (float*)W(Rl * D * 4); h->h = W(Rl * D * ob); h->qkv32 = (float*)W(Rl * h->Nqkv * 4); h->qkv = W(Rl * h->Nqkv * ob);
+    h->x = (float*)W(Rl * D * 4); h->h = W(Rl * D * ob); h->qkv = W(Rl * h->Nqkv * ob);
     h->att = W(Rl * h->Hq * ob); h->ff = W(Rl * I * ob); h->cs = (float*)W(Rl * h->hd * 4);
     if (h->lora_k2max > 0) h->lt = W(Rl * (size_t)h->lora_k2max * ob);
     h->pos_ids = (int*)W(Rl * 4); h->img_row = (int*)W(Rl * 4); h->pos3 = (int*)W(3 * Rl * 4);
@@ -339,6 +339,7 @@ extern "C" int lr_forward_qwen(lr_handle h, const int64_t* input_ids, const int6
                     upgrade_lo8(h, gp, st);
                     launch_gemm_bt(gp, h->op_dt, h->gemm_tile, st);
                 } else {
+                    if (!h->vqkv32) h->vqkv32 = (float*)h->dalloc(((size_t)d.max_patches + 256) * 3 * vHp * 4, false);      // fallback only
                     gemm(h, st, h->vhn, L.qkv_w, h->vqkv32, L.qkv_b, N, 3 * vHp, vH, vH, vH, 3 * vHp, EPI_OUT_F32, ACT_NONE);
                     launch_rope_split(h->vqkv32, h->vcs, h->vqkv, N, 2 * vHp, vHp, vhdp, h->op_dt, st, h->prec);
                 }

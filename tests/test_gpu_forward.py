@@ -143,6 +143,29 @@ def test_training_flag_and_errors():
         m.custom_forward(torch.from_numpy(batch["input_ids"]).cuda(), torch.from_numpy(batch["attention_mask"]).cuda())
 
 
+def test_c_abi_caller_with_wrong_slot_count_gets_nan_not_garbage():
+    """lr_forward cannot compare a row's image-slot count with the image tokens its image_sizes produce without a device sync (the
+    Python wrapper does, and raises as the reference would: test_training_flag_and_errors).  A direct C-ABI caller gets NaN for
+    such a row -- surplus slots never index another row's features or run past the buffer -- and correct rewards for the others."""
+    cfg = synth.tiny_config()
+    batch = synth.synth_batch(cfg, 5, [3, 6, 4], (1, 1))
+    m = _model(cfg, 5, "f16x2", upload=False)
+    good = _fwd(m, batch)
+    for delta in (+1, -1):
+        ids = batch["input_ids"].copy()
+        row = 1
+        if delta > 0:
+            ids[row, -2] = -1                                   # one slot too many (a caption token turned into an image slot)
+        else:
+            first = int(np.argmax(ids[row] < 0))
+            ids[row, first] = 7                                 # one slot too few
+        tb = {k: torch.from_numpy(v) for k, v in dict(batch, input_ids=ids).items()}
+        r = m.engine.forward(tb["input_ids"].cuda(), tb["attention_mask"].cuda(), tb["pixel_values"].cuda(), tb["image_sizes"])    # no wrapper check
+        torch.cuda.synchronize()
+        r = r.cpu()
+        assert torch.isnan(r[row]).all() and torch.equal(r[0], good[0]) and torch.equal(r[2], good[2])
+
+
 CASES = sorted(glob.glob(os.path.join(GOLD, "ref_small_*.json")))
 
 
