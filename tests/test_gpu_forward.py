@@ -143,6 +143,31 @@ def test_training_flag_and_errors():
         m.custom_forward(torch.from_numpy(batch["input_ids"]).cuda(), torch.from_numpy(batch["attention_mask"]).cuda())
 
 
+def test_sequence_longer_than_original_max_position_embeddings():
+    """S = 4231 > original_max_position_embeddings = 4096 with the stock config: the su-RoPE long factors apply to the whole batch
+    (the switch is on the padded length, modeling_phi3_v.py:673), position ids run past 4096 on the long row, and the attention
+    kernels walk 67 key tiles; a short left-padded row rides along.  Against the oracle, strict and default parity modes."""
+    cfg = synth.tiny_config()
+    assert cfg.orig_max_pos == 4096
+    seed = 83
+    batch = synth.synth_batch(cfg, seed, [1717, 40], [(4, 4), (1, 2)], max_crops=16)
+    S = batch["input_ids"].shape[1]
+    assert S > cfg.orig_max_pos
+    W = orc.weights_to_torch(synth.make_weights(cfg, seed))
+    ref = orc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"])
+    for dtype, tol in (("f16x2", TOL_X2), ("f16x2f8", TOL_X8)):
+        m = _model(cfg, seed, dtype, upload=False, max_batch=2, max_seq=S, max_crops=17)
+        got = _fwd(m, batch)
+        err = (got - ref).abs().max().item()
+        print(f"[S={S} > 4096, {dtype}] max |reward err| = {err:.2e}")
+        assert err < tol
+    # the long factors really are in effect: with the short factors the long row's reward is elsewhere
+    import dataclasses
+    ref_short = orc.custom_forward(W, dataclasses.replace(cfg, long_factor=cfg.short_factor), batch["input_ids"], batch["attention_mask"],
+                                   batch["pixel_values"], batch["image_sizes"])
+    assert (ref_short - ref).abs().max().item() > 10 * TOL_X8
+
+
 def test_c_abi_caller_with_wrong_slot_count_gets_nan_not_garbage():
     """lr_forward cannot compare a row's image-slot count with the image tokens its image_sizes produce without a device sync (the
     Python wrapper does, and raises as the reference would: test_training_flag_and_errors).  A direct C-ABI caller gets NaN for
