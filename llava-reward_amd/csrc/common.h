@@ -141,6 +141,9 @@ struct GemmParams {
     enum : int { SRC_A2 = 1, SRC_W2 = 2, SRC_LO = 4, SRC_LO16 = 8, MAX_SEG = 8 };
     int nseg, nk_f16, nk_e1, nk;
     KSeg seg[MAX_SEG];
+    // persistent launches: tile scheduler words (launch8), 8 per-XCD claim counters + 1 count of finished workgroups, all zero
+    // between launches; null = every workgroup walks a fixed list of tiles
+    int* sched;
 };
 
 struct AttnParams {

@@ -727,7 +727,7 @@ int lr_op_gemm_bt_mixed(void* A, const void* W, void* W8, int* aexp, void* C, co
         GemmParams p{A, W, C, bias, M, N, inexact ? 2 * K : K + K / 2, 2 * K, K, op_out ? 2 * nout : nout, epi, act, nullptr, 0, 0, K, op_out ? nout : 0, W8};
         p.aexp = aexp; p.wexp = wexp[0];
         if (inexact) { p.aexp2 = aexp + M; p.wexp2 = wexp[1]; }
-        launch_gemm_bt8_mixed(p, dt, st, (flags & 16) ? 2 : 0);          // flags & 16: no-epilogue diagnostic (tools/gemm_epi_probe.py)
+        launch_gemm_bt8_mixed(p, dt, st, (flags & 16) ? 2 : (flags >> 8));          // flags & 16: no-epilogue diagnostic (tools/gemm_epi_probe.py)
     });
 }
 

@@ -26,7 +26,9 @@
 //
 // Column mapping inside a block tile: wave wc owns columns wc*64 + qb*32 + [0,32) for qb = 0,1, so the
 // SwiGLU pair (gate block, up block: weight rows interleaved in 32s) stays in one lane/register.
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 
 #include "common.h"
 #include "kernels.h"
@@ -126,13 +128,28 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
     };
 
     // ---- persistent walk over tiles: virtual block id vb keeps the XCD-aware order of gemm.hip ----
-    for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
-        int L;
-        {
-            const int xcd = vb & 7, idx = vb >> 3;
-            const int q = nwg >> 3, r = nwg & 7;
-            L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    int tile_it = 0;           // DBG == 9: timeline stamps (100 MHz clock) per workgroup and tile -> p.ascale: tile start, K loop start, epilogue start, end
+    auto tstamp = [&](int k) {
+        if constexpr (DBG == 9) {
+            if (tid == 0 && tile_it < 128) ((unsigned long long*)p.ascale)[((size_t)blockIdx.x * 128 + tile_it) * 16 + k] = __builtin_amdgcn_s_memrealtime();
         }
+    };
+    // Tile order L: XCD x owns the contiguous chunk [chunk0(x), chunk0(x) + chunk_n(x)) and walks it in order, so that the 32
+    // tiles its CUs hold at any time form an 8 x 4 patch of the band order below (A / W slices shared in that XCD's L2).
+    // Static walk: workgroup slot i of the XCD takes i, i + 32, ...  Dynamic (p.sched, launch8): the first tile is the static one,
+    // every further tile is claimed from the XCD's counter while the previous tile's epilogue runs; an XCD that runs ahead of the
+    // others -- they differ by several per cent in sustained speed -- then takes tiles from the chunk with the most left.
+    const int chq = nwg >> 3, chr = nwg & 7;
+    auto chunk0 = [&](int x) { return x < chr ? x * (chq + 1) : chr * (chq + 1) + (x - chr) * chq; };
+    auto chunk_n = [&](int x) { return chq + (x < chr ? 1 : 0); };
+    const int my_xcd = (int)blockIdx.x & 7, per_xcd = (int)gridDim.x >> 3;
+    const bool dyn = PB == 2 && p.sched != nullptr;
+    int Ldyn = -1;
+    for (int vb = blockIdx.x; vb < nwg;) {
+        tstamp(0);
+        int L;
+        if (Ldyn >= 0) L = Ldyn;
+        else L = chunk0(vb & 7) + (vb >> 3);
         constexpr int GM = 8;
         const int band = L / (GM * Nt);
         const int within = L - band * (GM * Nt);
@@ -299,6 +316,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         LR_BARRIER();
         if (wr == 1) LR_BARRIER();                      // stagger the second wave group by one barrier
+        tstamp(1);
         uint4 af[8], bf[4], bg[4];
         if constexpr (DBG != 4) {
 #pragma unroll
@@ -546,14 +564,18 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 dbg2[0] = lsegs[0]; dbg2[1] = lsegs[1]; dbg2[2] = lsegs[2];
             }
         }
-        if constexpr (DBG >= 2) {   // diagnostics 2-5: no epilogue (keep the accumulators live)
+        if constexpr (DBG >= 2 && DBG <= 5) {   // diagnostics 2-5: no epilogue (keep the accumulators live); 6-8: epilogue without its C loads / stores / both
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(acc[q][i][0]), "v"(acc[q][i][1])); }
+            vb += gridDim.x;
             continue;
         }
 
+        tstamp(2);
+        int claim = 0;              // requested here, looked at behind the epilogue: the round trip hides behind it
+        if (dyn && tid == 0) claim = __hip_atomic_fetch_add(&p.sched[my_xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if constexpr (F8 == 1) {    // dequantise: C[m][n] *= ascale[m] * wscale[n]
             // (the pointers are laundered so that these ordinary loads cannot be hoisted above the K loop, where their vmcnt
             //  waits would drain the DMA ring in front of every ds_read)
@@ -604,7 +626,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
             };
             if constexpr (E_ == EPI_RESADD_F32) {
 #pragma unroll
-                for (int it = 0; it < 8; ++it) ca[it] = cload(it);
+                for (int it = 0; it < 8; ++it) ca[it] = (DBG == 6 || DBG == 8) ? make_float4(0.f, 0.f, 0.f, 0.f) : cload(it);
             }
             // RoPE epilogue: the (cos, sin) rows of iterations 0-3 are prefetched the same way (2 float4 each)
             const bool rot = E_ == EPI_ROPE_OP && n0 < p.rope_cols;         // rope_cols is a multiple of the tile width
@@ -620,6 +642,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 }
             }
             __syncthreads();
+            tstamp(4 + 3 * qa);
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 const int q = qa == 0 ? qb : 3 - qb;
@@ -633,9 +656,10 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
             }
             if constexpr (E_ == EPI_RESADD_F32) {
 #pragma unroll
-                for (int it = 0; it < 8; ++it) cb[it] = cload(8 + it);
+                for (int it = 0; it < 8; ++it) cb[it] = (DBG == 6 || DBG == 8) ? make_float4(0.f, 0.f, 0.f, 0.f) : cload(8 + it);
             }
             __syncthreads();
+            tstamp(5 + 3 * qa);
             if constexpr (E_ == EPI_SWIGLU_OP) {
                 // 128 output columns per row = 16 chunks of 8: 16 lanes per row, 4 rows per wave-iteration
                 const int c8 = lane & 15, wcc = c8 >> 2, cc = c8 & 3;
@@ -747,12 +771,48 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                     if (row < p.M && fcol < p.N) {
                         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                         if constexpr (E_ == EPI_RESADD_F32) { const float4 c = it < 8 ? ca[it & 7] : cb[it & 7]; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
-                        *(float4*)((float*)p.C + (size_t)row * p.ldc + fcol) = v;
+                        if constexpr (DBG == 7 || DBG == 8) { if (v.x == 1.2345e30f) *(float4*)((float*)p.C + (size_t)row * p.ldc + fcol) = v; }
+                        else *(float4*)((float*)p.C + (size_t)row * p.ldc + fcol) = v;
                     }
                 }
             }
+            tstamp(6 + 3 * qa);
         }
-        __syncthreads();      // staging reads done before the next tile's DMA reuses the ring
+        tstamp(3);
+        ++tile_it;
+        if (dyn) {
+            volatile int* next_l = (volatile int*)(smem + 9 * HT);          // behind the staging area
+            if (tid == 0) {
+                int Ln = -1;
+                const int i = per_xcd + claim;
+                if (i < chunk_n(my_xcd)) Ln = chunk0(my_xcd) + i;
+                else {
+                    for (int tries = 0; tries < 16 && Ln < 0; ++tries) {      // own chunk exhausted: help the XCD with the most tiles left
+                        int v = -1, best = 0;
+                        for (int y = 0; y < 8; ++y) {
+                            const int rem = chunk_n(y) - per_xcd - __hip_atomic_load(&p.sched[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (rem > best) { best = rem; v = y; }
+                        }
+                        if (v < 0) break;
+                        const int j = per_xcd + __hip_atomic_fetch_add(&p.sched[v], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (j < chunk_n(v)) Ln = chunk0(v) + j;
+                    }
+                }
+                if (Ln < 0) {          // this workgroup is done; the last one to get here leaves the words zero for the next launch
+                    if (__hip_atomic_fetch_add(&p.sched[8], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+                        for (int y = 0; y < 9; ++y) __hip_atomic_store(&p.sched[y], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                *next_l = Ln;
+            }
+            __syncthreads();      // staging reads done, the claim visible
+            Ldyn = *next_l;
+            __syncthreads();      // ... and read by every wave before the next tile's DMA reuses the ring
+            if (Ldyn < 0) break;
+        } else {
+            __syncthreads();      // staging reads done before the next tile's DMA reuses the ring
+            vb += gridDim.x;
+        }
     }
 }
 
@@ -768,6 +828,21 @@ static int num_cus() {
     return n;
 }
 
+// The tile scheduler's words of a stream (GemmParams::sched): launches of one stream run one after the other and each leaves its
+// words zero, so one set per stream is enough.  Allocated (and zeroed) on the stream's first persistent launch, never freed.
+static int* sched_words(hipStream_t st) {
+    static std::mutex mu;
+    static std::unordered_map<hipStream_t, int*> words;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = words.find(st);
+    if (it != words.end()) return it->second;
+    int* w = nullptr;
+    LR_HIP_CHECK(hipMalloc((void**)&w, 64));
+    LR_HIP_CHECK(hipMemset(w, 0, 64));
+    words[st] = w;
+    return w;
+}
+
 template <typename OT, int PF, int DBG, int EPI, int PB = 0, int F8 = 0>
 static void launch8(const GemmParams& p, bool persistent, hipStream_t st) {
     constexpr int NS = 10;
@@ -781,7 +856,10 @@ static void launch8(const GemmParams& p, bool persistent, hipStream_t st) {
     const int Mt = (p.M + 255) / 256, Nt = (p.N + 255) / 256;
     // persistent: one resident workgroup per CU (160 KB LDS each) walking its tiles; else one workgroup per tile
     const int grid = persistent ? std::min(Mt * Nt, num_cus()) : Mt * Nt;
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), smem, st, p);
+    GemmParams q = p;
+    static const bool dynamic = [] { const char* e = getenv("LR_GEMM_DYNAMIC"); return !e || atoi(e) != 0; }();
+    q.sched = (persistent && PB == 2 && DBG != 2 && dynamic && grid % 8 == 0 && Mt * Nt >= 4 * grid) ? sched_words(st) : nullptr;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), smem, st, q);
 }
 
 template <typename OT, int PF, int DBG, int PB = 0, int F8 = 0>
@@ -902,6 +980,19 @@ void launch_gemm_bt8_mixed(const GemmParams& p0, int operand_dtype, hipStream_t 
     if (dbg == 2) {          // diagnostic (tools/gemm_epi_probe.py): the same K loop without the epilogue; results are not written
         if (operand_dtype != DT_F16) throw std::runtime_error("gemm_bt8_mixed: the no-epilogue diagnostic is built for F16 only");
         launch8<F16, 6, 2, EPI_OUT_F32, 2, 2>(p, true, st);
+        return;
+    }
+    if (dbg == 9) {          // diagnostic (tools/gemm_timeline.py): per-tile time stamps into the buffer passed as `bias`
+        p.ascale = p.bias; p.bias = nullptr;
+        if (p.epi == EPI_RESADD_F32) launch8<F16, 6, 9, EPI_RESADD_F32, 2, 2>(p, true, st);
+        else if (p.epi == EPI_OUT_OP) launch8<F16, 6, 9, EPI_OUT_OP, 2, 2>(p, true, st);
+        else throw std::runtime_error("gemm_bt8_mixed: timeline diagnostic built for the residual-add and operand-out epilogues");
+        return;
+    }
+    if (dbg >= 6 && dbg <= 8) {
+        if (dbg == 6) launch8<F16, 6, 6, EPI_RESADD_F32, 2, 2>(p, true, st);
+        else if (dbg == 7) launch8<F16, 6, 7, EPI_RESADD_F32, 2, 2>(p, true, st);
+        else launch8<F16, 6, 8, EPI_RESADD_F32, 2, 2>(p, true, st);
         return;
     }
     if (operand_dtype == DT_F16) launch8_epi<F16, 6, 0, 2, 2>(p, true, st);

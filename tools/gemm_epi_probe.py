@@ -18,6 +18,7 @@ SHAPES = [("clip.qkv", 313888, 3072, 1024, L.EPI_OUT_OP, 23), ("clip.out", 31388
 lib = L.load()
 st = torch.cuda.current_stream()
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+FLAGS = (0, 16) + tuple(int(x) << 8 for x in sys.argv[2].split(',')) if len(sys.argv) > 2 else (0, 16)
 tot = [0.0, 0.0]
 for name, M, N, K, epi, cnt in SHAPES:
     A = torch.cat([torch.randn(M, K, device="cuda").half(), (torch.randn(M, K, device="cuda") * 2.0 ** -12).half()], dim=1).contiguous()
@@ -33,7 +34,7 @@ for name, M, N, K, epi, cnt in SHAPES:
     assert lib.lr_op_gemm_bt_mixed(*base, 7, C.byref(we), C.c_void_p(st.cuda_stream)) == 0
     res = {}
     for rnd in range(2):
-        for flags in (0, 16):
+        for flags in (FLAGS if epi == L.EPI_RESADD_F32 else (0, 16)):
             args = base + (flags, C.byref(we), C.c_void_p(st.cuda_stream))
             assert lib.lr_op_gemm_bt_mixed(*args) == 0
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -47,7 +48,7 @@ for name, M, N, K, epi, cnt in SHAPES:
     per_cu = tiles / 256.0
     print(f"{name:12s} M={M:6d} N={N:5d} K={K:4d} | product {res[0]:7.3f} ms | no epilogue {res[16]:7.3f} ms | epilogue {res[0] - res[16]:6.3f} ms "
           f"= {100 * (res[0] - res[16]) / res[0]:4.1f} % = {1e3 * (res[0] - res[16]) / per_cu:5.1f} us per tile; K loop + prologue {1e3 * res[16] / per_cu:6.1f} us per tile "
-          f"({K // 64 + K // 128} K-tile units)", flush=True)
+          f"({K // 64 + K // 128} K-tile units)" + "".join(f" | dbg{f >> 8}: {res[f]:7.3f}" for f in FLAGS if f > 16 and f in res), flush=True)
     tot[0] += res[0] * cnt
     tot[1] += res[16] * cnt
     del A, W, W8, out
