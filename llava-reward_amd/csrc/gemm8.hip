@@ -806,7 +806,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 *next_l = Ln;
             }
             __syncthreads();      // staging reads done, the claim visible
-            Ldyn = *next_l;
+            Ldyn = __builtin_amdgcn_readfirstlane(*next_l);        // uniform again: the tile coordinates stay in scalar registers
             __syncthreads();      // ... and read by every wave before the next tile's DMA reuses the ring
             if (Ldyn < 0) break;
         } else {
