@@ -448,6 +448,9 @@ def main():
                 # not bf16-valued any more, every GEMM carries a third K segment
                 res["merged_lora_weights"] = dict(leg(w, a.dtype, steps=2, fp32_valued=True),
                                                   note="fallback: merged (fp32-valued) weights, third K segment per GEMM")
+                # the other reading of "336 px" (SURVEY.md §8d): num_crops = 4 -> 5 crops, V = 757, 8.48 TFLOP per pair
+                w4 = workload("phi3v", B, 4)
+                res["num_crops4"] = dict(leg(w4, a.dtype), workload=w4["name"] + ", S=%d" % w4["S"])
                 # BASELINE configs[2]: GPM d=2 + SkipCA, pairwise, B=64 rows per forward
                 wg = workload("phi3v", 64, 16, gpm=True)
                 mg = build_model(wg, a.dtype)

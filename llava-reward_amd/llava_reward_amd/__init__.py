@@ -10,7 +10,8 @@ from .reward_adaptor_loader import inference_process_phi3v, load_reward_adaptor,
 from .preprocess import (batch_inference_process_phi3v_device, collate_rows, hd_transform_batch,  # noqa: F401
                          inference_process_phi3v_device, zero_pad_sequences)
 from . import trainer_shim  # noqa: F401
+from .scoring import score_candidates  # noqa: F401
 
 __all__ = ["synth", "RewardModel", "load_reward_adaptor", "inference_process_phi3v", "preference_compute",
            "hd_transform_batch", "inference_process_phi3v_device", "batch_inference_process_phi3v_device", "collate_rows",
-           "zero_pad_sequences", "trainer_shim"]
+           "zero_pad_sequences", "trainer_shim", "score_candidates"]

@@ -198,13 +198,24 @@ def collate_rows(rows, pad_token_id: int, squeeze: bool = True):
     return out
 
 
+def _load_rgb(image):
+    """An image of a scoring request: a path (opened as the reference does, reward_adaptor_loader.py:161), a PIL image, or RGB uint8
+    [h, w, 3] pixels already in memory -- a numpy array or a tensor on any device (a sampler's decoded candidates stay on the GPU)."""
+    if isinstance(image, (str, bytes)) or hasattr(image, "__fspath__"):
+        from PIL import Image
+        return np.asarray(Image.open(image).convert("RGB"))
+    if hasattr(image, "convert") and not torch.is_tensor(image):          # PIL.Image
+        return np.asarray(image.convert("RGB"))
+    return image
+
+
 def batch_inference_process_phi3v_device(args, tokenizer, items, device="cuda", num_crops: int = 16, pad_token_id: int = None):
-    """Rows for ONE batched custom_forward from (image path, caption) pairs with captions of any length: every image goes through
-    lr_hd_transform into one [B, num_crops+1, 3, 336, 336] tensor, every prompt is built and merged with its image slots as
-    inference_process_phi3v does (eval/reward_adaptor_loader.py:163-167), and the rows are left-padded into [B, S]
-    (collate_rows).  Returns the dict custom_forward(**batch) takes."""
-    from PIL import Image
-    imgs = [np.asarray(Image.open(path).convert("RGB")) for path, _ in items]
+    """Rows for ONE batched custom_forward from (image, caption) pairs with captions of any length -- image: a path, a PIL image or
+    RGB uint8 pixels in memory (_load_rgb): every image goes through lr_hd_transform into one [B, num_crops+1, 3, 336, 336]
+    tensor, every prompt is built and merged with its image slots as inference_process_phi3v does
+    (eval/reward_adaptor_loader.py:163-167), and the rows are left-padded into [B, S] (collate_rows).  Returns the dict
+    custom_forward(**batch) takes."""
+    imgs = [_load_rgb(image) for image, _ in items]
     pix, sizes, ntok = hd_transform_batch(imgs, num_crops, device)
     rows = []
     for b, (_, caption) in enumerate(items):

@@ -141,6 +141,42 @@ def _forward_rows(model, b, rows: slice, device):
 
 
 @torch.no_grad()
+def score_candidates(model, tokenizer, captions, images, num_crops: int = 16, batch_size: int = 32, pad_token_id: Optional[int] = None,
+                     device=None) -> torch.Tensor:
+    """Rewards of N (caption, image) candidates, [N, value_head_dim] fp32 on the model's device, in input order: the reward function
+    of reward-guided sampling (the Fk-steering use of the reference's README: a population of candidate images per prompt, scored at
+    every resampling step).  captions: one string for all candidates or one per candidate; images: paths, PIL images or RGB uint8
+    [h, w, 3] arrays / tensors (device tensors never leave the GPU: HD transform, left-pad collate and forward all run there).
+    Phi-3.5-V backbone.  With torch.distributed initialised the candidates are sharded by rows (contiguous, before any
+    preprocessing) and the rewards all-gathered, bit-identical to the single-process result."""
+    from .preprocess import batch_inference_process_phi3v_device
+    if getattr(model, "model_type", "phi3v") != "phi3v":
+        raise NotImplementedError("score_candidates builds Phi-3.5-V inputs; use the model's own processor + custom_forward(inputs_batch=...)")
+    n = len(images)
+    caps = [captions] * n if isinstance(captions, str) else list(captions)
+    if len(caps) != n:
+        raise ValueError(f"{len(caps)} captions for {n} images")
+    rank, ws = world()
+    device = device or model.device
+    rows = shard_rows(n, rank, ws)
+    d = int(getattr(model, "value_head_dim", 1))
+    was_training = bool(getattr(model, "training", False))
+    if was_training:
+        model.eval()                     # the EOS-position convention of inference (rw_model:416-425)
+    out = [torch.empty((0, d), dtype=torch.float32, device=device)]
+    try:
+        for lo in range(rows.start, rows.stop, batch_size):
+            hi = min(lo + batch_size, rows.stop)
+            batch = batch_inference_process_phi3v_device(None, tokenizer, list(zip(images[lo:hi], caps[lo:hi])), device=device,
+                                                         num_crops=num_crops, pad_token_id=pad_token_id)
+            out.append(model.custom_forward(**batch)[0].float().reshape(hi - lo, d))
+    finally:
+        if was_training:
+            model.train()
+    return gather_rewards(torch.cat(out, dim=0), n)
+
+
+@torch.no_grad()
 def score_pairwise(model, args, batches: Iterable, device=None) -> Dict[str, object]:
     """batches yields (inputs_c, inputs_r, c_rates, r_rates) as the reference's DataLoader does.
     Returns the quantities the reference prints: prob_mean, proportion (prob > 0.5), proportion w/o ties."""

@@ -16,7 +16,7 @@ import torch.distributed as dist  # noqa: E402
 
 from llava_reward_amd import synth  # noqa: E402
 from llava_reward_amd.model import RewardModel  # noqa: E402
-from llava_reward_amd.scoring import score_pairwise  # noqa: E402
+from llava_reward_amd.scoring import score_candidates, score_pairwise  # noqa: E402
 
 
 def batches(cfg, seed):
@@ -42,7 +42,10 @@ def main():
     model = RewardModel(cfg, synth_seed=seed, max_batch=8, max_seq=512, max_crops=3).to("cuda:0").eval()
     args = types.SimpleNamespace(is_general_preference=True, value_head_dim=2, general_preference_tau=0.1)
     res = score_pairwise(model, args, batches(cfg, seed))
-    json.dump({"rank": rank, "probs": res["probs"], "proportion": res["proportion"]}, open(out_path, "w"))
+    # a population of 5 candidate images for one prompt (reward-guided sampling): in memory, on the GPU, sharded 3 + 2 over two ranks
+    cands = [torch.from_numpy(synth.synth_image(seed, f"cand.{i}", 336, 336)).cuda() for i in range(5)]
+    cr = score_candidates(model, synth.StandInTokenizer(), "a photo of a cat", cands, num_crops=1, batch_size=2, pad_token_id=cfg.vocab_size - 1)
+    json.dump({"rank": rank, "probs": res["probs"], "proportion": res["proportion"], "candidates": cr.cpu().tolist()}, open(out_path, "w"))
     if ws > 1:
         dist.barrier()
         dist.destroy_process_group()

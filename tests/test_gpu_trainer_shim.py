@@ -112,3 +112,44 @@ def test_ragged_captions_collated_on_the_device(tmp_path):
         row = P.inference_process_phi3v_device(None, tok, [p], cap, num_crops=4)[0]
         one, _ = m.custom_forward(**row)
         assert (one[0] - got[b]).abs().max().item() < 2e-5
+
+
+def test_score_candidates_in_memory_images():
+    """Reward-guided sampling (the Fk-steering use of the reference's README): a population of candidate images for
+    one prompt, decoded pixels already on the GPU -> rewards [N, d] in input order.  Equal, bit for bit, to scoring the same images
+    from files through batch_inference_process_phi3v_device + custom_forward, whatever the chunking (same-sized candidates share
+    V_max, so the reference's un-masked SkipCA padding does not come into it), and to the oracle within the f16x2 bound."""
+    import tempfile
+    from PIL import Image
+    from llava_reward_amd.scoring import score_candidates
+    cfg = synth.tiny_config(is_general_preference=True, value_head_dim=2)
+    seed = 73
+    tok = synth.StandInTokenizer()
+    pad = cfg.vocab_size - 1
+    m = RewardModel(cfg, synth_seed=seed, max_batch=8, max_seq=1024, max_crops=5, operand_dtype="f16x2").to("cuda").eval()
+    arrs = [synth.synth_image(seed, f"cand.{i}", 300, 200, True) for i in range(5)]
+    cands = [torch.from_numpy(a).cuda() for a in arrs]
+    prompt = "an astronaut riding a horse"
+    got = score_candidates(m, tok, prompt, cands, num_crops=4, batch_size=32, pad_token_id=pad)
+    assert got.shape == (5, 2) and got.is_cuda and got.dtype == torch.float32
+    for bs in (2, 1):
+        assert torch.equal(score_candidates(m, tok, prompt, cands, num_crops=4, batch_size=bs, pad_token_id=pad), got)
+    # numpy arrays, PIL images and files are the same request
+    assert torch.equal(score_candidates(m, tok, [prompt] * 5, [Image.fromarray(a) for a in arrs[:3]] + arrs[3:], num_crops=4, pad_token_id=pad), got)
+    with tempfile.TemporaryDirectory() as d:
+        paths = []
+        for i, a in enumerate(arrs):
+            paths.append(f"{d}/c{i}.png")
+            Image.fromarray(a).save(paths[-1])
+        batch = P.batch_inference_process_phi3v_device(None, tok, [(p, prompt) for p in paths], device="cuda", num_crops=4, pad_token_id=pad)
+    direct, _ = m.custom_forward(**batch)
+    assert torch.equal(direct, got)
+    W = orc.weights_to_torch(synth.make_weights(cfg, seed))
+    pix = np.stack([HD.preprocess(a, 4)[0] for a in arrs])
+    ref = orc.custom_forward(W, cfg, batch["input_ids"].cpu(), batch["attention_mask"].cpu(), pix, batch["image_sizes"])
+    assert (got.cpu() - ref).abs().max().item() < 1e-4
+    # train mode is left as it was found, and the rewards are the inference (EOS position) ones either way
+    m.train()
+    assert torch.equal(score_candidates(m, tok, prompt, cands, num_crops=4, pad_token_id=pad), got) and m.training
+    with pytest.raises(ValueError):
+        score_candidates(m, tok, [prompt] * 4, cands, num_crops=4, pad_token_id=pad)
