@@ -136,7 +136,7 @@ def dominant_kernel_probe(dtype_code, tile, steps=5, split=False, lo8=False):
     st = torch.cuda.current_stream()
     if lo8:      # split-operand form with the e4m3 residual pass: W8 twin prepared and the residual half encoded once, then timed
         W8 = torch.zeros_like(W)
-        ae = torch.zeros(M, dtype=torch.int32, device="cuda")
+        ae = torch.full((lib.lr_op_lo8_scratch_bytes(M, K),), 127, dtype=torch.uint8, device="cuda")
         we = C.c_int(0)
         base = (C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(W8.data_ptr()), C.c_void_p(ae.data_ptr()), C.c_void_p(out.data_ptr()),
                 C.c_void_p(0), M, N, K, L.EPI_SWIGLU_OP, 0, dtype_code)

@@ -207,12 +207,19 @@ int lr_op_quantize_rows_fp8(const void* x, int rows, int K, int ldx, void* q, fl
 int lr_op_gemm_fp8(const void* A8, const float* ascale, const void* W8, const float* wscale, void* C, const float* bias, int M, int N,
                    int K, int ldc, int epi, int act, int operand_dtype, void* hip_stream);
 /* Split-operand GEMM with the e4m3 residual pass (lr_model_desc.precise == 2): A = [A_hi | A_lo] (2-byte elements, 2K per row),
- * W [N, K], W8 = DEVICE scratch of the size of W (the e4m3 twin), aexp = DEVICE int32 [M] scratch, wexp = HOST int (in/out).
+ * W [N, K], W8 = DEVICE scratch of the size of W (the e4m3 twin), scratch = DEVICE bytes, lr_op_lo8_scratch_bytes(M, K) of them
+ * (block scales of A's residuals: one E8M0 byte per row and 128 columns, K / 128 planes of 256 * ceil(M / 256) bytes in the
+ * consuming kernel's lane order; then one int32 per row for flag 8), wexp = HOST int (in/out).
  * flags: 1 = prepare W8 from W and store its exponent in *wexp (synchronous), 2 = re-encode the residual half of A in place
- * (e4m3 bytes + one E8M0 exponent per row), 4 = stop there (no GEMM), 8 = W is NOT exact in the operand type: on entry W8 holds
- * its 16-bit residuals (W's layout); a third segment A_hi(e4m3) x e4m3(W_lo)^T is added (aexp: int32 [2 M], wexp: int [2]).
+ * (e4m3 bytes + the block scales), 4 = stop there (no GEMM), 8 = W is NOT exact in the operand type: on entry W8 holds
+ * its 16-bit residuals (W's layout); a third segment A_hi(e4m3) x e4m3(W_lo)^T is added (one exponent per row; wexp: int [2]),
+ * 16 = diagnostic, 32 = operand-typed output (EPI_OUT_OP / EPI_SWIGLU_OP, columns % 128 == 0) with ITS residual half in the one-byte
+ * form as well, written by the epilogue: e4m3 bytes in C + the block scales of C at scratch + lr_op_lo8_scratch_bytes(M, K)
+ * (lr_op_lo8_scratch_bytes(M, columns) more bytes) -- the next lr_op_gemm_bt_mixed takes C as its A with that pointer as its scratch
+ * and without flag 2.
  * Output as lr_op_gemm_bt_split.  K multiple of 128. */
-int lr_op_gemm_bt_mixed(void* A, const void* W, void* W8, int* aexp, void* C, const float* bias, int M, int N, int K, int epi, int act,
+size_t lr_op_lo8_scratch_bytes(int M, int K);
+int lr_op_gemm_bt_mixed(void* A, const void* W, void* W8, void* scratch, void* C, const float* bias, int M, int N, int K, int epi, int act,
                         int operand_dtype, int flags, int* wexp, void* hip_stream);
 int lr_op_norm_rows(const float* x, const float* w, const float* b, void* y, int rows, int H, float eps,
                     int operand_dtype, void* hip_stream);

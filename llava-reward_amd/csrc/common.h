@@ -50,6 +50,33 @@ template <> struct Op<F16> {
     }
 };
 
+// One-byte residuals of split operands (default parity mode): the residual half of an operand row is stored as e4m3
+// with one power-of-two scale (E8M0 byte) per (row, 128-column block) -- the block-scaled form the CDNA4 scaled matrix instruction
+// takes natively.  A block is row-local and at most one producer tile wide, so every producer (norms, GEMM epilogues) can encode
+// in its own epilogue, and a row's bytes never depend on the other rows of the batch.
+// Scale array of an operand with M rows and K columns, laid out for the consuming GEMM: per group of 4 K-tiles (128 columns each) and
+// 256-row tile one KB = 4 slices of 256 bytes (what one LDS-DMA instruction moves); inside a slice the byte of row r sits at
+// lo8_sidx(r): 8 bytes per lane of the consumer = its 4 row tiles of A half 0, then of A half 1.
+__host__ __device__ inline size_t lo8_scale_bytes(int M, int K) { return (size_t)((M + 255) / 256) * 1024 * (size_t)((K / 128 + 3) / 4); }
+__host__ __device__ inline int lo8_sidx(int r) { return ((((r >> 6) & 1) * 16 + (r & 15)) * 2 + (r >> 7)) * 4 + ((r >> 4) & 3); }     // r = row % 256
+__host__ __device__ inline size_t lo8_scale_at(int row, int kblock, int M) {
+    return ((size_t)(kblock >> 2) * ((M + 255) / 256) + (row >> 8)) * 1024 + (kblock & 3) * 256 + lo8_sidx(row & 255);
+}
+#if defined(__HIPCC__)
+// maximum over the 16 lanes of a DPP row (lanes 16g .. 16g + 15); m >= 0.  Call in uniform control flow.
+__device__ __forceinline__ float row16_max(float m) {
+    int v = __builtin_bit_cast(int, m);                 // non-negative floats order like their bit patterns
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));    // row_half_mirror
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));    // row_mirror
+    return __builtin_bit_cast(float, v);
+}
+// 2^(E-127) puts amax into [128, 256) <= 448 (e4m3's largest finite value); E = 127 for an all-zero block
+__device__ __forceinline__ int e8m0_of_amax(float amax) { return amax > 0.f ? min(max(127 + (ilogbf(amax) - 7), 1), 253) : 127; }
+__device__ __forceinline__ float e8m0_inv_scale(int E) { return __builtin_bit_cast(float, (unsigned)(254 - E) << 23); }   // 2^(127 - E)
+#endif
+
 template <typename OT> __device__ __forceinline__ unsigned pack2(float lo, float hi) {
     return (unsigned)Op<OT>::from_f32(lo) | ((unsigned)Op<OT>::from_f32(hi) << 16);
 }
@@ -116,9 +143,13 @@ struct GemmParams {
     // W8A8 mode (launch_gemm_bt8_fp8): dequantisation scales, one per row of A and one per row of W
     const float* ascale;
     const float* wscale;
-    // split-operand mode with an e4m3 residual pass (launch_gemm_bt8_mixed): E8M0 scale of every residual row, and of W8
-    const int* aexp;
+    // split-operand mode with an e4m3 residual pass (launch_gemm_bt8_mixed): block scales of A's residual half (lo8_scale_bytes(M, kw)
+    // bytes, see lo8_scale_at) and the tensor scale of W8
+    const unsigned char* aexp;
     int wexp;
+    // EPI_OUT_OP / EPI_SWIGLU_OP in split-operand mode: write the residual half of C in that one-byte form too (the GEMM that reads C
+    // takes the e4m3 residual pass): oexp = C's scale array (lo8_scale_at over M rows), null = 16-bit residuals.  Output columns % 128 == 0.
+    unsigned char* oexp;
     // ... with weights that are not exact in the operand type: a third segment, A_hi as e4m3 (row exponents aexp2, bytes behind the
     // residual bytes) against e4m3(W_lo) (tensor exponent wexp2, bytes behind W8 in the same rows); K = 2 kw
     const int* aexp2;

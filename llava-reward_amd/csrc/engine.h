@@ -94,7 +94,11 @@ struct lr_engine {
     int op_dt = DT_BF16;
     int prec = 0;              // split-operand mode: operand buffers are [hi | lo], twice as wide
     int lo8 = 0;               // ... with the residual pass of the big GEMMs in e4m3 (desc.precise == 2)
-    int* aexp = nullptr; size_t aexp_cap = 0;        // E8M0 exponent of every residual row of the GEMM being launched
+    // block scales of one-byte residuals (common.h lo8_scale_at): two arrays used in turn -- a GEMM reads its operand's scales from
+    // one while its epilogue writes its output's into the other -- and the row exponents of the e4m3 copy of a hi half
+    unsigned char* sc[2] = {nullptr, nullptr}; size_t sc_cap = 0; int sc_i = 0;
+    const unsigned char* pre_enc_sc = nullptr;       // the scale array that belongs to pre_enc
+    int* aexp2 = nullptr; size_t aexp2_cap = 0;
     unsigned* amax_word = nullptr;
     std::unordered_map<const void*, int> w8exp;      // weight base pointer -> E8M0 exponent of its prepared e4m3 twin
     std::unordered_map<const void*, int> w8exp2;     // ... and of e4m3(W_lo) for weights that are inexact in the operand type
@@ -317,12 +321,22 @@ inline void ensure_lo8_twin(lr_engine* e, const void* W, int N, int K, int ldw, 
     e->w8exp[W] = E;
     e->w8exp2[W] = E2;
 }
-inline void ensure_aexp(lr_engine* e, size_t rows) {
-    if (rows > e->aexp_cap) {
-        e->aexp_cap = (rows + 4095) & ~(size_t)4095;
-        e->aexp = (int*)e->dalloc(e->aexp_cap * 2 * 4, false);          // [residual rows | hi rows]
+inline void ensure_aexp(lr_engine* e, size_t rows, size_t K) {
+    const size_t need = lo8_scale_bytes((int)rows, (int)K);
+    if (need > e->sc_cap) {
+        e->sc_cap = (need + 65535) & ~(size_t)65535;
+        for (int i = 0; i < 2; ++i) {
+            e->sc[i] = (unsigned char*)e->dalloc(e->sc_cap, false);
+            LR_HIP_CHECK(hipMemset(e->sc[i], 127, e->sc_cap));           // rows beyond M of a last tile read these: any finite scale
+        }
+    }
+    if (rows > e->aexp2_cap) {
+        e->aexp2_cap = (rows + 4095) & ~(size_t)4095;
+        e->aexp2 = (int*)e->dalloc(e->aexp2_cap * 4, false);
     }
 }
+// the array the next producer of one-byte residuals writes its scales to
+inline unsigned char* next_scales(lr_engine* e) { e->sc_i ^= 1; return e->sc[e->sc_i]; }
 
 // keep_enc: another GEMM reads the same operand buffer next (the main GEMM behind an adapter's t GEMM): leave the "already encoded"
 // mark on it.  force_hi8: that next GEMM needs the e4m3 copy of the hi half as well, so the one in-place encoding pass writes it now.
@@ -340,17 +354,19 @@ inline void upgrade_lo8(lr_engine* e, GemmParams& p, hipStream_t st, bool keep_e
         char* lo_rows = e->wbufs[it->second].lo;
         ensure_lo8_twin(e, p.W, p.N, p.kw, p.ldw, st);
         auto w8 = e->w8exp.find(p.W);
-        ensure_aexp(e, (size_t)p.M);
-        int* aexp2 = e->aexp + e->aexp_cap;
+        ensure_aexp(e, (size_t)p.M, (size_t)p.kw);
+        int* aexp2 = e->aexp2;
         if (!(e->pre_enc == p.A && (!hi8 || e->pre_enc_hi8))) {
             if (e->pre_enc == p.A) throw std::logic_error("operand buffer already carries e4m3 residuals without the e4m3 copy of its hi half");
-            launch_quantize_lo_inplace(const_cast<void*>(p.A), p.lda, p.kw, p.M, e->aexp, e->op_dt, st, hi8 ? aexp2 : nullptr);
+            unsigned char* sc = next_scales(e);
+            launch_quantize_lo_inplace(const_cast<void*>(p.A), p.lda, p.kw, p.M, sc, e->op_dt, st, hi8 ? aexp2 : nullptr);
             e->pre_enc_hi8 = hi8;
+            e->pre_enc_sc = sc;
         }
-        e->pre_enc = keep_enc ? p.A : nullptr;      // (a norm kernel may have written [hi | e4m3(lo)] and e->aexp itself: lo8_norm_target)
+        p.aexp = e->pre_enc_sc;
+        e->pre_enc = keep_enc ? p.A : nullptr;      // (a norm kernel may have written [hi | e4m3(lo)] and the scales itself: lo8_norm_target)
         if (own != e->own8.end()) { p.Wlo16 = inexact ? lo_rows : nullptr; p.Wlo = own->second; }
         else p.Wlo = lo_rows;
-        p.aexp = e->aexp;
         p.wexp = w8->second;
         p.aexp2 = third8 ? aexp2 : nullptr;
         p.wexp2 = e->w8exp2[p.W];
@@ -364,15 +380,17 @@ inline void apply_prec(lr_engine* e, GemmParams& p, hipStream_t st) {
 }
 // For a norm kernel that feeds the GEMM described by `probe` (logical shapes, as passed to gemm()): where to put the row exponents if
 // that GEMM will take the e4m3 residual form with exact weights, else null (the norm then writes 16-bit residuals as usual).
-inline int* lo8_norm_target(lr_engine* e, GemmParams probe) {
+inline unsigned char* lo8_norm_target(lr_engine* e, GemmParams probe) {
     e->pre_enc = nullptr;
     if (!e->lo8) return nullptr;
     apply_prec_base(e, probe);
     if (!lo8_eligible(e, probe) || probe.Wlo) return nullptr;
-    ensure_aexp(e, (size_t)probe.M);
+    ensure_aexp(e, (size_t)probe.M, (size_t)probe.kw);
     e->pre_enc = probe.A;
     e->pre_enc_hi8 = false;
-    return e->aexp;
+    unsigned char* sc = next_scales(e);
+    e->pre_enc_sc = sc;
+    return sc;
 }
 inline void apply_prec(const lr_engine* e, AttnParams& p) {
     if (!e->prec) return;
@@ -404,7 +422,7 @@ inline void prepare_twins(lr_engine* e, const std::vector<GemmWeight>& ws) {
     if (!e->lo8 && !e->w8a8) return;
     for (const GemmWeight& g : ws) {
         if (!g.W || g.K % 128) continue;
-        if (e->lo8) { ensure_lo8_twin(e, g.W, g.N, g.K, g.K, 0); ensure_aexp(e, g.rows); }
+        if (e->lo8) { ensure_lo8_twin(e, g.W, g.N, g.K, g.K, 0); ensure_aexp(e, g.rows, (size_t)g.K); }
         else { ensure_w8a8_twin(e, g.W, g.N, g.K, g.K, 0); ensure_q8(e, g.rows, (size_t)g.K); }
     }
     LR_HIP_CHECK(hipStreamSynchronize(0));
@@ -422,9 +440,30 @@ inline bool launch_w8a8(lr_engine* e, GemmParams p, hipStream_t st) {
     return true;
 }
 
+// For a GEMM whose operand-typed output C [M, Kout] is read next by the GEMM with weight next_W [next_N, Kout]: where the producer's
+// epilogue should put C's block scales if that consumer will take the e4m3 residual form with exact weights (it then finds its
+// operand encoded: no in-place pass), else null.  p: the producer after apply_prec (its kernel must be the deep-pipelined one).
+inline unsigned char* lo8_out_target(lr_engine* e, const GemmParams& p, const void* next_W, int next_N) {
+    if (!e->lo8 || !next_W || p.split <= 0 || !(p.epi == EPI_OUT_OP || p.epi == EPI_SWIGLU_OP)) return nullptr;
+    if (!(p.A2 || gemm_bt_is_deep(p, e->gemm_tile)) || (e->gemm_tile >= 0 && e->gemm_tile != 6)) return nullptr;
+    const int Kout = p.split;                                  // logical output columns = the consumer's K
+    GemmParams probe{p.C, next_W, nullptr, nullptr, p.M, next_N, Kout, Kout, Kout, next_N, EPI_OUT_F32, ACT_NONE, nullptr, 0, 0};
+    apply_prec_base(e, probe);
+    if (!lo8_eligible(e, probe) || probe.Wlo) return nullptr;
+    ensure_aexp(e, (size_t)p.M, (size_t)Kout);
+    return next_scales(e);
+}
+inline void mark_lo8_out(lr_engine* e, const GemmParams& p) {
+    if (!p.oexp) return;
+    e->pre_enc = p.C;
+    e->pre_enc_hi8 = false;
+    e->pre_enc_sc = p.oexp;
+}
+
 // One linear layer, p in LOGICAL shapes (as gemm() takes them).  With an adapter L: t = x A^T first (always on the deep-pipelined
 // kernel, in the same operand form as the main GEMM -- they read the same rows of x), then the main GEMM with the K-extension.
-inline void gemm_p(lr_engine* e, hipStream_t st, GemmParams p, const Lora* L = nullptr) {
+// next_W / next_N: the weight of the GEMM that reads this one's output as its operand (lo8_out_target), or null.
+inline void gemm_p(lr_engine* e, hipStream_t st, GemmParams p, const Lora* L = nullptr, const void* next_W = nullptr, int next_N = 0) {
     if (L && L->k2 > 0) {
         if (e->w8a8) throw std::logic_error("W8A8 mode runs merged weights only (no un-merged adapters)");
         GemmParams probe = p;
@@ -440,16 +479,20 @@ inline void gemm_p(lr_engine* e, hipStream_t st, GemmParams p, const Lora* L = n
         if (it != e->wbuf_of.end() && !e->inexact.empty() && e->inexact[it->second]) p.W2lo = e->wbufs[it->second].lo;
         apply_prec_base(e, p);
         if (both8) upgrade_lo8(e, p, st);
+        p.oexp = lo8_out_target(e, p, next_W, next_N);
         launch_gemm_bt(p, e->op_dt, e->gemm_tile, st);
+        mark_lo8_out(e, p);
         return;
     }
     if (launch_w8a8(e, p, st)) return;
     apply_prec(e, p, st);
+    p.oexp = lo8_out_target(e, p, next_W, next_N);
     launch_gemm_bt(p, e->op_dt, e->gemm_tile, st);
+    mark_lo8_out(e, p);
 }
 inline void gemm(lr_engine* e, hipStream_t st, const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int lda,
-          int ldw, int ldc, int epi, int act, const Lora* L = nullptr) {
-    gemm_p(e, st, GemmParams{A, W, C, bias, M, N, K, lda, ldw, ldc, epi, act, nullptr, 0, 0}, L);
+          int ldw, int ldc, int epi, int act, const Lora* L = nullptr, const void* next_W = nullptr, int next_N = 0) {
+    gemm_p(e, st, GemmParams{A, W, C, bias, M, N, K, lda, ldw, ldc, epi, act, nullptr, 0, 0}, L, next_W, next_N);
 }
 
 // Adapter slots of one linear `mod` (checkpoint names mod.lora_A.weight [r, K], mod.lora_B.weight [n_rows, r]); part / parts: this

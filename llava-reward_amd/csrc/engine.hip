@@ -213,7 +213,7 @@ void run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_ma
         gemm(h, st, h->att, L.o_w, h->x, nullptr, Rl, D, Hq, Hq, Hq, D, EPI_RESADD_F32, ACT_NONE, &L.lo);
         launch_norm_rows(h->x, L.ln2, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st, h->prec, 1,
                          lo8_norm_target(h, GemmParams{h->h, L.gu_w, h->ff, nullptr, Rl, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE, nullptr, 0, 0}));
-        gemm(h, st, h->h, L.gu_w, h->ff, nullptr, Rl, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE, &L.lgu);
+        gemm(h, st, h->h, L.gu_w, h->ff, nullptr, Rl, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE, &L.lgu, L.down_w, D);      // ff is down's operand
         gemm(h, st, h->ff, L.down_w, h->x, nullptr, Rl, D, I, I, I, D, EPI_RESADD_F32, ACT_NONE, &L.ldown);
     }
 }
@@ -575,19 +575,19 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
             gemm(h, st, h->clip_att, c.out_w, h->clip_x, c.out_b, Rc, Hc, Hc, Hc, Hc, Hc, EPI_RESADD_F32, ACT_NONE);
             launch_norm_rows(h->clip_x, c.ln2_w, c.ln2_b, h->clip_h, Rc, Hc, d.clip_ln_eps, h->op_dt, st, h->prec, 1,
                              lo8_norm_target(h, GemmParams{h->clip_h, c.fc1_w, h->clip_ff, c.fc1_b, Rc, Mc, Hc, Hc, Hc, Mc, EPI_OUT_OP, ACT_QUICK_GELU, nullptr, 0, 0}));
-            gemm(h, st, h->clip_h, c.fc1_w, h->clip_ff, c.fc1_b, Rc, Mc, Hc, Hc, Hc, Mc, EPI_OUT_OP, ACT_QUICK_GELU);
+            gemm(h, st, h->clip_h, c.fc1_w, h->clip_ff, c.fc1_b, Rc, Mc, Hc, Hc, Hc, Mc, EPI_OUT_OP, ACT_QUICK_GELU, nullptr, c.fc2_w, Hc);
             gemm(h, st, h->clip_ff, c.fc2_w, h->clip_x, c.fc2_b, Rc, Hc, Mc, Mc, Mc, Hc, EPI_RESADD_F32, ACT_NONE);
         }
         if (h->llava) {
             // ---- per-token projector, then anyres packing (modeling_llava_next.py get_image_features/pack_image_features) ----
             launch_clip_tokens(h->clip_x, h->hdA, NC, T, Hc, h->op_dt, st, h->prec);
-            gemm(h, st, h->hdA, h->p0_w, h->proj1, h->p0_b, Rp, D, Hc, Hc, Hc, D, EPI_OUT_OP, ACT_GELU_ERF);
+            gemm(h, st, h->hdA, h->p0_w, h->proj1, h->p0_b, Rp, D, Hc, Hc, Hc, D, EPI_OUT_OP, ACT_GELU_ERF, nullptr, h->p2_w, D);
             gemm(h, st, h->proj1, h->p2_w, h->pf32, h->p2_b, Rp, D, D, D, D, D, EPI_OUT_F32, ACT_NONE);
             launch_llava_pack(h->pf32, d_lsmp, B, SV, h->G, D, h->newline, h->ev, st);
         } else {
             // ---- HD transform + projector (modeling_phi3_v.py:254-303) ----
             launch_hd_gather(h->clip_x, d_smp, B, SV, T, Hc, h->sub_gn, h->glb_gn, h->hdA, h->op_dt, st, h->prec);
-            gemm(h, st, h->hdA, h->p0_w, h->proj1, h->p0_b, SV, D, 4 * Hc, 4 * Hc, 4 * Hc, D, EPI_OUT_OP, ACT_GELU_ERF);
+            gemm(h, st, h->hdA, h->p0_w, h->proj1, h->p0_b, SV, D, 4 * Hc, 4 * Hc, 4 * Hc, D, EPI_OUT_OP, ACT_GELU_ERF, nullptr, h->p2_w, D);
             gemm(h, st, h->proj1, h->p2_w, h->ev, h->p2_b, SV, D, D, D, D, D, EPI_OUT_F32, ACT_NONE);
         }
         // ---- embeddings, positions (modeling_phi3_v.py:228-249, rw_model:344-345 | llava: masked_scatter, arange positions) ----
@@ -700,12 +700,16 @@ int lr_op_gemm_bt_ext(const void* A, const void* W, const void* T, const void* B
     });
 }
 
-int lr_op_gemm_bt_mixed(void* A, const void* W, void* W8, int* aexp, void* C, const float* bias, int M, int N, int K, int epi, int act,
+size_t lr_op_lo8_scratch_bytes(int M, int K) { return ((lo8_scale_bytes(M, K) + 255) & ~(size_t)255) + (((size_t)M * 4 + 255) & ~(size_t)255); }
+
+int lr_op_gemm_bt_mixed(void* A, const void* W, void* W8, void* scratch, void* C, const float* bias, int M, int N, int K, int epi, int act,
                         int operand_dtype, int flags, int* wexp, void* hip_stream) {
     return op_guard([&] {
         const int dt = operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16;
         hipStream_t st = (hipStream_t)hip_stream;
-        if (!wexp) throw std::runtime_error("lr_op_gemm_bt_mixed: wexp is required");
+        if (!wexp || !scratch || K % 128) throw std::runtime_error("lr_op_gemm_bt_mixed: wexp and scratch are required, K % 128 == 0");
+        unsigned char* scales = (unsigned char*)scratch;                                                    // lr_op_lo8_scratch_bytes(M, K)
+        int* aexp2 = (int*)(scales + ((lo8_scale_bytes(M, K) + 255) & ~(size_t)255));
         const bool inexact = (flags & 8) != 0;
         if (flags & 1) {                                   // prepare the e4m3 twin(s) of W (synchronous)
             unsigned* word = nullptr;
@@ -720,13 +724,17 @@ int lr_op_gemm_bt_mixed(void* A, const void* W, void* W8, int* aexp, void* C, co
             }
             LR_HIP_CHECK(hipFree(word));
         }
-        if (flags & 2) launch_quantize_lo_inplace(A, 2 * K, K, M, aexp, dt, st, inexact ? aexp + M : nullptr);       // re-encode A's residual half
+        if (flags & 2) launch_quantize_lo_inplace(A, 2 * K, K, M, scales, dt, st, inexact ? aexp2 : nullptr);       // re-encode A's residual half
         if (flags & 4) return;
         const int nout = epi == EPI_SWIGLU_OP ? N / 2 : N;
         const bool op_out = epi == EPI_OUT_OP || epi == EPI_SWIGLU_OP;
         GemmParams p{A, W, C, bias, M, N, inexact ? 2 * K : K + K / 2, 2 * K, K, op_out ? 2 * nout : nout, epi, act, nullptr, 0, 0, K, op_out ? nout : 0, W8};
-        p.aexp = aexp; p.wexp = wexp[0];
-        if (inexact) { p.aexp2 = aexp + M; p.wexp2 = wexp[1]; }
+        p.aexp = scales; p.wexp = wexp[0];
+        if (inexact) { p.aexp2 = aexp2; p.wexp2 = wexp[1]; }
+        if (flags & 32) {          // operand-typed output with one-byte residuals: C's block scales behind this call's own scratch
+            if (!op_out || nout % 128) throw std::runtime_error("lr_op_gemm_bt_mixed: flag 32 needs an operand-typed output with columns % 128 == 0");
+            p.oexp = scales + lr_op_lo8_scratch_bytes(M, K);
+        }
         launch_gemm_bt8_mixed(p, dt, st, (flags & 16) ? 2 : (flags >> 8));          // flags & 16: no-epilogue diagnostic (tools/gemm_epi_probe.py)
     });
 }

@@ -253,8 +253,11 @@ void launch_gemm_bt(const GemmParams& p, int operand_dtype, int tile, hipStream_
     if (p.split < 0 || p.split % 8) throw std::runtime_error("gemm_bt: split must be a non-negative multiple of 8");
     if (p.epi == EPI_SWIGLU_OP && (p.N % 64) != 0) throw std::runtime_error("gemm_bt: SwiGLU needs N % 64 == 0");
     tile = p.A2 ? 6 : pick_tile(p, tile);          // a K-extension (un-merged adapter) exists in the deep-pipelined kernel only
+    if (p.oexp && (tile != 6 || p.split <= 0 || p.split % 128 || !(p.epi == EPI_OUT_OP || p.epi == EPI_SWIGLU_OP)))
+        throw std::runtime_error("gemm_bt: one-byte residual output needs the product kernel, a split operand output and columns % 128 == 0");
     if (tile >= 3) { launch_gemm_bt8(p, operand_dtype, tile, st); return; }
     if (p.epi == EPI_ROPE_OP) throw std::runtime_error("gemm_bt: the fused RoPE epilogue exists only in the deep-pipelined kernel");
+    if (p.oexp) throw std::runtime_error("gemm_bt: one-byte residual output exists only in the deep-pipelined kernel");
     if (operand_dtype == DT_F16) launch_dt<F16>(p, tile, st);
     else launch_dt<BF16>(p, tile, st);
 }

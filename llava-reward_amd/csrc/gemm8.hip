@@ -14,7 +14,9 @@
 //                           barrier; COMPUTE(P): MFMAs; barrier.
 // Hazards: half-tile g is first read at phase >= g-2, i.e. one phase after the wait that retires it
 // (RAW); its slot is restaged by half-tile g+NS, issued at phase g+NS-PF, while its last read is at
-// phase <= g+2 of the lagging wave group (WAR) => NS - PF >= 4.  NS = 10 slots = all 160 KB of LDS.
+// phase <= g+2 of the lagging wave group (WAR) => NS - PF >= 4.  NS = 10 slots = all 160 KB of LDS (4-phase A/B forms).
+// The product schedule (PB = 2, below) issues 6 half-tiles ahead on 8 slots -- it measures the same as 8 on 10 -- and keeps the
+// other 32 KB for the residual K-tiles' scale bytes.
 // Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA segment while
 // its partner issues LDS reads / DMA.
 // PB = 1 (product): the LOAD segments are the critical path (~300-350 cycles against 256 of MFMA), so the B fragments are
@@ -35,6 +37,9 @@
 
 namespace lr {
 
+#ifndef LR_PF2
+#define LR_PF2 6          // half-tiles issued ahead in the product schedule: 6 and 8 measure the same; 6 leaves 32 KB of LDS
+#endif
 #define LR_BARRIER() do { asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 // DBG: 0 = product; 1 = every K-tile re-reads K-tile 0 (cache-resident operands; results invalid);
@@ -67,8 +72,8 @@ template <typename F> __device__ __forceinline__ void for4(F&& f) { f(IC<0>{}); 
 
 // F8 == 2: split-operand mode with an e4m3 residual pass: A rows are [hi f16 x kw | lo e4m3 x kw bytes], the K loop
 // runs kw / 64 f16 K-tiles against W and then kw / 128 e4m3 K-tiles against W8 (the e4m3 twin of W, in the rows of p.Wlo), with
-// the power-of-two scales of the residual rows (p.aexp, E8M0 per row) and of W8 (p.wexp, one per tensor) applied by the matrix
-// instruction itself, so both passes meet in the same accumulators and every epilogue is the one of the 16-bit form.
+// the power-of-two scales of the residuals (p.aexp, one E8M0 byte per row and K-tile) and of W8 (p.wexp, one per tensor) applied by
+// the matrix instruction itself, so both passes meet in the same accumulators and every epilogue is the one of the 16-bit form.
 template <typename OT, int PF, int NS, int DBG, int EPI, int PB, int F8 = 0>
 __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
     static_assert(!F8 || PB == 2, "the fp8 operand path exists in the super-phase schedule only");
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 
     constexpr int BM = 256, BN = 256, BK = 64;
     constexpr int HT = 16384;                      // bytes per half-tile slot
-    static_assert(NS - PF >= 4 && PF >= 3, "ring hazard distances");
+    static_assert(PB == 2 || (NS - PF >= 4 && PF >= 3), "ring hazard distances");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -258,20 +263,15 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[q][i][j][r] = 0.f;
 
-        // F8 == 2: E8M0 exponents of this tile's residual rows (one per A row a lane feeds: [A half][row tile]) and of W8.  Ordinary
-        // loads: retired here, in front of the DMA stream, so that no compiler-placed vmcnt wait can appear inside the K loop.
-        int ea[2] = {0x7F7F7F7F, 0x7F7F7F7F};        // [A half]: byte i = exponent of row tile i
-        int ea2[2] = {0x7F7F7F7F, 0x7F7F7F7F};       // the same for the third segment (A_hi as e4m3)
+        // F8 == 2: E8M0 scales.  Residual segment: one byte per (row, K-tile) (common.h lo8_scale_at), i.e. per K-tile one dword per
+        // lane and A half -- byte i = row tile i of the lane's rows -- see issue_slice below.  Third segment
+        // (weights inexact in the operand type: A_hi as e4m3, one exponent per row): ordinary loads, retired here, in front of the DMA
+        // stream, so that no compiler-placed vmcnt wait can appear inside the K loop.
+        int ea[2] = {0x7F7F7F7F, 0x7F7F7F7F};        // [A half]: byte i = exponent of row tile i, of the K-tile being multiplied
+        int ea2[2] = {0x7F7F7F7F, 0x7F7F7F7F};       // the same for the third segment
         const int eb2 = p.wexp2;
         const int eb = p.wexp;
         if constexpr (F8 == 2) {
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int e1 = p.aexp[min(m0 + h2 * 128 + wr * 64 + i * 16 + l15, p.M - 1)] & 255;
-                    ea[h2] = i == 0 ? e1 : (ea[h2] | (e1 << (8 * i)));
-                }
             if (nk > nk_lo) {                    // weights inexact in the operand type: third segment, A_hi as e4m3 against e4m3(W_lo)
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2)
@@ -280,10 +280,26 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                         const int e1 = p.aexp2[min(m0 + h2 * 128 + wr * 64 + i * 16 + l15, p.M - 1)] & 255;
                         ea2[h2] = i == 0 ? e1 : (ea2[h2] | (e1 << (8 * i)));
                     }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("" : "+v"(ea[0]), "+v"(ea[1]), "+v"(ea2[0]), "+v"(ea2[1]));
+            asm volatile("" : "+v"(ea2[0]), "+v"(ea2[1]));
         }
+        // The scale bytes of the residual K-tiles travel through LDS: group g (the 4 x 256 bytes of this row tile for residual K-tiles
+        // 4g .. 4g+3, common.h lo8_scale_at) is ONE LDS-DMA instruction of one wave, issued during the 16-bit K-tiles -- whose LOAD
+        // segments have slack -- into the 32 KB behind the ring (32 groups; beyond that a group follows the one it replaces), so
+        // that the residual K-tiles, which are LOAD-bound, only pay one 8-byte LDS read per lane and K-tile.
+        constexpr int SC_GROUPS = 32;
+        const unsigned sc_voff = (unsigned)((wr * 16 + l15) * 8);
+        const unsigned char* sc_tile = p.aexp + (size_t)mi * 1024;
+        const size_t sc_plane = (size_t)Mt * 1024;
+        const int nsl = nk_lo - nk_hi, nsg = (nsl + 3) >> 2;
+        auto issue_scales = [&](int g) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + NS * HT + (g & (SC_GROUPS - 1)) * 1024);
+            const unsigned char* src = sc_tile + (size_t)g * sc_plane + lane * 16;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        };
 
         if constexpr (PB == 2) {
         // ================= super-phase schedule (product) =================
@@ -300,7 +316,9 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         // 2Q+5: B1(kt) = 4kt+2 <= 2(2kt-1)+5, A1 = 4kt+3 and B0(kt+1) = 4kt+5 <= 2(2kt)+5, A0(kt+1) = 4kt+4 <= 2(2kt+1)+5.
         // WAR: half-tile g+NS is issued at LOAD(floor((g+NS-8)/2)); the lagging group is then in COMPUTE of the interval before
         // and its reads of g (A0: LOAD(g/2); B1: COMPUTE(g/2-1); A1: LOAD((g-1)/2); B0: COMPUTE((g-5)/2)) are behind it iff NS-8 >= 2.
-        constexpr int PF2 = 8, WAIT2 = 2 * (PF2 - 4);
+        constexpr int PF2 = LR_PF2, WAIT2 = 2 * (PF2 - 4);
+        static_assert(PF2 == 8 || PF2 == 6, "the issue pattern below knows these two depths");
+        static_assert(F8 != 2 || (NS + 2) * HT <= 160 * 1024, "the scale slices live behind the ring");
         static_assert(NS - PF2 >= 2, "ring hazard distances (super-phase schedule)");
         int islot = 0;
 #pragma unroll
@@ -323,6 +341,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
             for (int f = 0; f < 4; ++f) bf[f] = *(const uint4*)(smem + 1 * HT + boff[f]);      // B0 of K-tile 0 (slot 1)
         }
         int rslot = 0, gi = PF2;
+        bool scl = false;          // this wave issued a scale slice in this LOAD segment: one more entry in its vmcnt queue
         // One K-tile.  A generic lambda so that the mixed form (F8 == 2) can run two loops, 16-bit tiles then e4m3 tiles, each
         // with its own straight-line body: a run-time branch around the two MFMA kinds merges 64 accumulator registers behind it
         // and spills inside the K loop.
@@ -346,19 +365,44 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 #pragma unroll
                     for (int f = 0; f < 8; ++f) af[f] = *(const uint4*)(sa + aoff[f]);
                 }
+                // scale groups of the residual K-tiles: one per phase of the first 16-bit K-tiles, the waves taking turns; the scales
+                // of this K-tile's rows (both A halves) from LDS
+                if constexpr (F8 == 2 && LO == 0) {
+                    const int g = 2 * kt + sp;
+                    if (g < min(nsg, SC_GROUPS) && wave == (g & 7)) { issue_scales(g); scl = true; }
+                } else if constexpr (F8 == 2 && LO == 1) {
+                    const int j = kt - nk_hi;
+                    if (sp == 0) {
+                        typedef int v2i_t __attribute__((ext_vector_type(2)));
+                        typedef __attribute__((address_space(3))) const volatile v2i_t lds_scale_t;       // an LDS read, never a flat one
+                        const v2i_t e2 = *(lds_scale_t*)(lds_base + NS * HT + (((j >> 2) & (SC_GROUPS - 1)) << 10) + ((j & 3) << 8) + sc_voff);
+                        ea[0] = e2.x; ea[1] = e2.y;
+                        const int g = (j >> 2) - 1 + SC_GROUPS;        // its slot was last read in the K-tile before this one
+                        if ((j & 3) == 0 && j >= 4 && g < nsg && wave == (g & 7)) { issue_scales(g); scl = true; }
+                    }
+                }
                 if (more) {
-                    if constexpr (DBG != 5) {
+                    if constexpr (DBG != 5 && PF2 == 8) {
                         if (sp == 0) ktile_begin();
                         issue(2 * sp, kt + 2, islot);
                         islot = (islot + 1 == NS) ? 0 : islot + 1;
                         issue(2 * sp + 1, kt + 2, islot);
                         islot = (islot + 1 == NS) ? 0 : islot + 1;
                         if (sp == 1) ktile_end();
+                    } else if constexpr (DBG != 5) {          // 6 ahead: second half of K-tile kt+1, then first half of kt+2
+                        if (sp == 1) ktile_begin();
+                        issue(sp == 0 ? 2 : 0, kt + 2, islot);
+                        islot = (islot + 1 == NS) ? 0 : islot + 1;
+                        issue(sp == 0 ? 3 : 1, kt + 2, islot);
+                        islot = (islot + 1 == NS) ? 0 : islot + 1;
+                        if (sp == 0) ktile_end();
                     }
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT2) : "memory");
+                    if (scl) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT2 + 1) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT2) : "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
+                scl = false;
                 gi += 2;
                 if constexpr (DBG == 3) t1 = stamp();
                 LR_BARRIER();
@@ -605,6 +649,27 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                     }
         }
 
+        // operand out with one-byte residuals (GemmParams::oexp): 8 consecutive columns of a row per lane, 16 lanes (one DPP row) = one
+        // 128-column block.  hi as 16 bytes, residuals as 8 e4m3 bytes scaled by the block's power of two, one scale byte per block.
+        // Lanes past the matrix edge do not get here; their DPP contribution reads as zero.
+        auto store_hi_lo8 = [&](const float (&v)[8], unsigned short* crow, int split, int col, unsigned char* scale_byte, bool writes_scale) {
+            unsigned short hb[8];
+            float r[8];
+            float m = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { hb[e] = Op<OT>::from_f32(v[e]); r[e] = v[e] - Op<OT>::to_f32(hb[e]); m = fmaxf(m, fabsf(r[e])); }
+            *(uint4*)(crow + col) = make_uint4(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16), hb[4] | ((unsigned)hb[5] << 16), hb[6] | ((unsigned)hb[7] << 16));
+            const int E = e8m0_of_amax(row16_max(m));
+            const float sc = e8m0_inv_scale(E);
+            int p0 = 0, p1 = 0;
+            p0 = __builtin_amdgcn_cvt_pk_fp8_f32(r[0] * sc, r[1] * sc, p0, false);
+            p0 = __builtin_amdgcn_cvt_pk_fp8_f32(r[2] * sc, r[3] * sc, p0, true);
+            p1 = __builtin_amdgcn_cvt_pk_fp8_f32(r[4] * sc, r[5] * sc, p1, false);
+            p1 = __builtin_amdgcn_cvt_pk_fp8_f32(r[6] * sc, r[7] * sc, p1, true);
+            *(uint2*)((unsigned char*)(crow + split) + col) = make_uint2((unsigned)p0, (unsigned)p1);
+            if (writes_scale) *scale_byte = (unsigned char)E;
+        };
+
         // ---- epilogue ----  quadrant index q -> (qa, qb): 0:(0,0) 1:(0,1) 2:(1,1) 3:(1,0)
         // The ring is idle (every DMA was retired by the vmcnt(0) of the tail phases), so the tile is staged
         // through LDS, 128 rows at a time, and leaves the CU as whole rows with 16 bytes per lane.
@@ -685,13 +750,16 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                     }
                     if (row < p.M && n0 + wcc * 64 + 64 <= p.N) {
                         auto sw = [](float gg, float uu) { return uu * x_sigmoid_fast(gg, 1.f); };
-                        uint4 w, wl;
-                        split2<OT>(sw(g0.x, u0.x), sw(g0.y, u0.y), w.x, wl.x);
-                        split2<OT>(sw(g0.z, u0.z), sw(g0.w, u0.w), w.y, wl.y);
-                        split2<OT>(sw(g1.x, u1.x), sw(g1.y, u1.y), w.z, wl.z);
-                        split2<OT>(sw(g1.z, u1.z), sw(g1.w, u1.w), w.w, wl.w);
-                        *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + ocol) = w;
-                        if (p.split > 0) *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + p.split + ocol) = wl;
+                        const float v[8] = {sw(g0.x, u0.x), sw(g0.y, u0.y), sw(g0.z, u0.z), sw(g0.w, u0.w), sw(g1.x, u1.x), sw(g1.y, u1.y), sw(g1.z, u1.z), sw(g1.w, u1.w)};
+                        if (p.oexp) {        // the 16 lanes of this row hold one 128-column block of the output
+                            store_hi_lo8(v, (unsigned short*)p.C + (size_t)row * p.ldc, p.split, ocol, p.oexp + lo8_scale_at(row, ocol >> 7, p.M), (lane & 15) == 0);
+                        } else {
+                            uint4 w, wl;
+                            split2<OT>(v[0], v[1], w.x, wl.x); split2<OT>(v[2], v[3], w.y, wl.y);
+                            split2<OT>(v[4], v[5], w.z, wl.z); split2<OT>(v[6], v[7], w.w, wl.w);
+                            *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + ocol) = w;
+                            if (p.split > 0) *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + p.split + ocol) = wl;
+                        }
                     }
                 }
             } else if constexpr (E_ == EPI_ROPE_OP) {
@@ -752,11 +820,15 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                             if (p.act == ACT_QUICK_GELU) v[e] = x_sigmoid_fast(v[e], 1.702f);
                             else if (p.act == ACT_GELU_ERF) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752440f));
                         }
-                        uint4 w, wl;
-                        split2<OT>(v[0], v[1], w.x, wl.x); split2<OT>(v[2], v[3], w.y, wl.y);
-                        split2<OT>(v[4], v[5], w.z, wl.z); split2<OT>(v[6], v[7], w.w, wl.w);
-                        *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + col) = w;
-                        if (p.split > 0) *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + p.split + col) = wl;
+                        if (p.oexp) {        // each half-wave row holds two 128-column blocks: lanes 0-15 and 16-31 of it
+                            store_hi_lo8(v, (unsigned short*)p.C + (size_t)row * p.ldc, p.split, col, p.oexp + lo8_scale_at(row, col >> 7, p.M), (lane & 15) == 0);
+                        } else {
+                            uint4 w, wl;
+                            split2<OT>(v[0], v[1], w.x, wl.x); split2<OT>(v[2], v[3], w.y, wl.y);
+                            split2<OT>(v[4], v[5], w.z, wl.z); split2<OT>(v[6], v[7], w.w, wl.w);
+                            *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + col) = w;
+                            if (p.split > 0) *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + p.split + col) = wl;
+                        }
                     }
                 }
             } else {
@@ -781,7 +853,8 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         tstamp(3);
         ++tile_it;
         if (dyn) {
-            volatile int* next_l = (volatile int*)(smem + 9 * HT);          // behind the staging area
+            typedef __attribute__((address_space(3))) volatile int lds_int_t;                    // LDS accesses, not flat ones
+            lds_int_t* next_l = (lds_int_t*)(lds_base + 9 * HT);                                 // behind the staging area
             if (tid == 0) {
                 int Ln = -1;
                 const int i = per_xcd + claim;
@@ -845,8 +918,8 @@ static int* sched_words(hipStream_t st) {
 
 template <typename OT, int PF, int DBG, int EPI, int PB = 0, int F8 = 0>
 static void launch8(const GemmParams& p, bool persistent, hipStream_t st) {
-    constexpr int NS = 10;
-    constexpr int smem = NS * 16384;
+    constexpr int NS = PB == 2 ? LR_PF2 + 2 : 10;      // ring slots; the product schedule keeps the rest of the 160 KB for scale slices
+    constexpr int smem = 10 * 16384;
     static bool attr_set = false;
     auto kfn = gemm_bt8_kernel<OT, PF, NS, DBG, EPI, PB, F8>;
     if (!attr_set) {
@@ -970,8 +1043,10 @@ void launch_gemm_bt8_fp8(GemmParams p, int operand_dtype, hipStream_t st) {
 void launch_gemm_bt8_mixed(const GemmParams& p0, int operand_dtype, hipStream_t st, int dbg) {
     if (p0.M <= 0) return;
     GemmParams p = p0;
-    if (p.kw <= 0 || p.kw % 128 || !p.Wlo || !p.aexp || (p.aexp2 && p.Wlo16))
-        throw std::runtime_error("gemm_bt8_mixed: needs kw % 128 == 0, W8 rows and row exponents (third segment: e4m3 OR 16-bit, not both)");
+    if (p.kw <= 0 || p.kw % 128 || !p.Wlo || !p.aexp || (p.aexp2 && p.Wlo16) || (((uintptr_t)p.aexp) & 15))
+        throw std::runtime_error("gemm_bt8_mixed: needs kw % 128 == 0, W8 rows and block scales (third segment: e4m3 OR 16-bit, not both)");
+    if (p.oexp && (p.split <= 0 || p.split % 128 || !(p.epi == EPI_OUT_OP || p.epi == EPI_SWIGLU_OP)))
+        throw std::runtime_error("gemm_bt8_mixed: one-byte residual output needs a split operand output with columns % 128 == 0");
     build_segments(p, 2);
     if (p.N % 8 || p.ldc % 8 || ((uintptr_t)p.C & 15) || (p.bias && ((uintptr_t)p.bias & 15)))
         throw std::runtime_error("gemm_bt8_mixed: N and ldc must be multiples of 8 and C/bias 16-byte aligned");

@@ -350,12 +350,12 @@ extern "C" int lr_forward_qwen(lr_handle h, const int64_t* input_ids, const int6
             launch_attention(ap, 1, vhdp, false, h->op_dt, st);
             gemm(h, st, h->vatt, L.proj_w, h->vx, L.proj_b, N, vH, vHp, vHp, vHp, vH, EPI_RESADD_F32, ACT_NONE);
             launch_norm_rows(h->vx, L.n2, nullptr, h->vhn, N, vH, d.vit_eps, h->op_dt, st, h->prec);
-            gemm(h, st, h->vhn, L.gu_w, h->vff, L.gu_b, N, 2 * vIp, vH, vH, vH, vIp, EPI_SWIGLU_OP, ACT_NONE);
+            gemm(h, st, h->vhn, L.gu_w, h->vff, L.gu_b, N, 2 * vIp, vH, vH, vH, vIp, EPI_SWIGLU_OP, ACT_NONE, nullptr, L.down_w, vH);
             gemm(h, st, h->vff, L.down_w, h->vx, L.down_b, N, vH, vIp, vIp, vIp, vH, EPI_RESADD_F32, ACT_NONE);
         }
         // ---- merger (Qwen2_5_VLPatchMerger): RMSNorm, 4 consecutive rows = one LLM token, Linear-GELU-Linear ----
         launch_norm_rows(h->vx, h->vlnq, nullptr, h->vhn, N, vH, 1e-6f, h->op_dt, st, h->prec, unit);     // rows of one merged token side by side
-        gemm(h, st, h->vhn, h->m0_w, h->vm1, h->m0_b, M, vHm, vHm, vHm, vHm, vHm, EPI_OUT_OP, ACT_GELU_ERF);
+        gemm(h, st, h->vhn, h->m0_w, h->vm1, h->m0_b, M, vHm, vHm, vHm, vHm, vHm, EPI_OUT_OP, ACT_GELU_ERF, nullptr, h->m2_w, D);
         gemm(h, st, h->vm1, h->m2_w, h->ev, h->m2_b, M, D, vHm, vHm, vHm, D, EPI_OUT_F32, ACT_NONE);
 
         // ---- embeddings + 3-D positions (Qwen2_5_VLModel.forward: masked_scatter, get_rope_index) ----

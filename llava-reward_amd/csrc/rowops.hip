@@ -29,9 +29,6 @@ template <typename OT> __device__ __forceinline__ void store4s(void* base, size_
     if (prec) *(uint2*)(dst + W) = l;
 }
 
-__device__ __forceinline__ int e8m0_of_amax(float amax) {      // 2^(E-127) puts amax into [128, 256) <= 448; E = 127 for a zero row
-    return amax > 0.f ? 127 + (ilogbf(amax) - 7) : 127;
-}
 
 // ------------------------------------------------------------------------------------------ norms
 // modeling_phi3_v.py:377-391 (RMSNorm: w * (x * rsqrt(mean(x^2) + eps))) and CLIP LayerNorm.
@@ -40,7 +37,7 @@ constexpr int NORM_MAXC = 16;   // H <= 4096
 template <typename OT, bool LAYERNORM>
 __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, void* __restrict__ y, int rows,
-                                                        int H, float eps, int prec, int group, int* __restrict__ lo8) {
+                                                        int H, float eps, int prec, int group) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -86,42 +83,7 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
                 const float4 bb = ((const float4*)b)[c];
                 o0 += bb.x; o1 += bb.y; o2 += bb.z; o3 += bb.w;
             }
-            if (lo8) v[i] = make_float4(o0, o1, o2, o3);
-            else store4s<OT>(y, row / group, H * group, prec, (row % group) * H + 4 * c, o0, o1, o2, o3);
-        }
-    }
-    if (lo8) {
-        // default parity mode, the consumer is a GEMM with the e4m3 residual pass: write [hi | e4m3(lo)] and the row's E8M0 exponent
-        // directly (what quantize_lo_inplace_kernel would make of the [hi | lo] row, minus its extra pass over HBM; group == 1)
-        float amax = 0.f;
-#pragma unroll
-        for (int i = 0; i < NORM_MAXC; ++i) {
-            if (lane + 64 * i < nch) {
-                const float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(o[j] - Op<OT>::to_f32(Op<OT>::from_f32(o[j]))));
-            }
-        }
-        amax = wave_max(amax);
-        const int E = e8m0_of_amax(amax);
-        if (lane == 0) lo8[row] = E;
-        unsigned short* dst = (unsigned short*)y + (size_t)row * (2 * H);
-        unsigned char* q = (unsigned char*)(dst + H);
-#pragma unroll
-        for (int i = 0; i < NORM_MAXC; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nch) {
-                const float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-                unsigned short hb[4];
-                float r[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { hb[j] = Op<OT>::from_f32(o[j]); r[j] = ldexpf(o[j] - Op<OT>::to_f32(hb[j]), 127 - E); }
-                *(uint2*)(dst + 4 * c) = make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
-                int pk = 0;
-                pk = __builtin_amdgcn_cvt_pk_fp8_f32(r[0], r[1], pk, false);
-                pk = __builtin_amdgcn_cvt_pk_fp8_f32(r[2], r[3], pk, true);
-                *(unsigned*)(q + 4 * c) = (unsigned)pk;
-            }
+            store4s<OT>(y, row / group, H * group, prec, (row % group) * H + 4 * c, o0, o1, o2, o3);
         }
     }
 }
@@ -132,7 +94,7 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
 template <typename OT, bool LAYERNORM>
 __global__ __launch_bounds__(256) void norm_rows8_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ b, void* __restrict__ y, int rows,
-                                                         int H, float eps, int prec, int* __restrict__ lo8) {
+                                                         int H, float eps, int prec, unsigned char* __restrict__ lo8) {
     constexpr int MAXI = NORM_MAXC / 2;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -167,7 +129,6 @@ __global__ __launch_bounds__(256) void norm_rows8_kernel(const float* __restrict
     } else {
         rstd = rsqrtf(s / H + eps);
     }
-    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
         const int c = lane + 64 * i;
@@ -182,48 +143,45 @@ __global__ __launch_bounds__(256) void norm_rows8_kernel(const float* __restrict
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[i][j] += bb[j];
             }
-            if (lo8) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[i][j] - Op<OT>::to_f32(Op<OT>::from_f32(v[i][j]))));
-            }
         }
-    }
-    int E = 127;
-    if (lo8) {
-        amax = wave_max(amax);
-        E = e8m0_of_amax(amax);
-        if (lane == 0) lo8[row] = E;
     }
     unsigned short* dst = (unsigned short*)y + (size_t)row * ((size_t)H << prec);
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
         const int c = lane + 64 * i;
+        unsigned short hb[8];
+        float r[8];
+        float m = 0.f;
         if (c < n8) {
-            unsigned short hb[8];
-            float r[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { hb[j] = Op<OT>::from_f32(v[i][j]); r[j] = v[i][j] - Op<OT>::to_f32(hb[j]); }
+            for (int j = 0; j < 8; ++j) { hb[j] = Op<OT>::from_f32(v[i][j]); r[j] = v[i][j] - Op<OT>::to_f32(hb[j]); m = fmaxf(m, fabsf(r[j])); }
             *(uint4*)(dst + 8 * c) = make_uint4(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16),
                                                 hb[4] | ((unsigned)hb[5] << 16), hb[6] | ((unsigned)hb[7] << 16));
-            if (lo8) {          // residual half as e4m3 scaled by the row's power of two (what quantize_lo_inplace_kernel would write)
+        }
+        if (lo8) {              // residual half as block-scaled e4m3 (common.h): 16 lanes = one 128-column block (H % 128 == 0)
+            const int E = e8m0_of_amax(row16_max(m));
+            if (c < n8) {
+                const float sc = e8m0_inv_scale(E);
                 int p0 = 0, p1 = 0;
-                p0 = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(r[0], 127 - E), ldexpf(r[1], 127 - E), p0, false);
-                p0 = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(r[2], 127 - E), ldexpf(r[3], 127 - E), p0, true);
-                p1 = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(r[4], 127 - E), ldexpf(r[5], 127 - E), p1, false);
-                p1 = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(r[6], 127 - E), ldexpf(r[7], 127 - E), p1, true);
+                p0 = __builtin_amdgcn_cvt_pk_fp8_f32(r[0] * sc, r[1] * sc, p0, false);
+                p0 = __builtin_amdgcn_cvt_pk_fp8_f32(r[2] * sc, r[3] * sc, p0, true);
+                p1 = __builtin_amdgcn_cvt_pk_fp8_f32(r[4] * sc, r[5] * sc, p1, false);
+                p1 = __builtin_amdgcn_cvt_pk_fp8_f32(r[6] * sc, r[7] * sc, p1, true);
                 *(uint2*)((unsigned char*)(dst + H) + 8 * c) = make_uint2((unsigned)p0, (unsigned)p1);
-            } else if (prec) {
-                *(uint4*)(dst + H + 8 * c) = make_uint4(pack2<OT>(r[0], r[1]), pack2<OT>(r[2], r[3]), pack2<OT>(r[4], r[5]), pack2<OT>(r[6], r[7]));
+                if ((lane & 15) == 0) lo8[lo8_scale_at(row, c >> 4, rows)] = (unsigned char)E;
             }
+        } else if (prec && c < n8) {
+            *(uint4*)(dst + H + 8 * c) = make_uint4(pack2<OT>(r[0], r[1]), pack2<OT>(r[2], r[3]), pack2<OT>(r[4], r[5]), pack2<OT>(r[6], r[7]));
         }
     }
 }
 
 void launch_norm_rows(const float* x, const float* w, const float* b, void* y, int rows, int H, float eps,
-                      int operand_dtype, hipStream_t st, int prec, int group, int* lo8) {
+                      int operand_dtype, hipStream_t st, int prec, int group, unsigned char* lo8) {
     if (rows <= 0) return;
     if (group < 1 || rows % group) throw std::runtime_error("norm_rows: rows must be a multiple of group");
-    if (lo8 && (!prec || group != 1)) throw std::runtime_error("norm_rows: the e4m3 residual form needs split-operand rows, group 1");
+    if (lo8 && (!prec || group != 1 || H % 128 || (((uintptr_t)y) & 15) || (((uintptr_t)w) & 15) || (b && (((uintptr_t)b) & 15))))
+        throw std::runtime_error("norm_rows: the e4m3 residual form needs split-operand rows, group 1, H % 128 == 0 and 16-byte aligned pointers");
     if (H % 4 || H > NORM_MAXC * 256) throw std::runtime_error("norm_rows: H must be a multiple of 4 and <= 4096");
     dim3 g(cdiv(rows, 4)), t(256);
     const bool f16 = operand_dtype == DT_F16;
@@ -238,11 +196,11 @@ void launch_norm_rows(const float* x, const float* w, const float* b, void* y, i
         return;
     }
     if (b) {
-        if (f16) hipLaunchKernelGGL((norm_rows_kernel<F16, true>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group, lo8);
-        else hipLaunchKernelGGL((norm_rows_kernel<BF16, true>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group, lo8);
+        if (f16) hipLaunchKernelGGL((norm_rows_kernel<F16, true>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group);
+        else hipLaunchKernelGGL((norm_rows_kernel<BF16, true>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group);
     } else {
-        if (f16) hipLaunchKernelGGL((norm_rows_kernel<F16, false>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group, lo8);
-        else hipLaunchKernelGGL((norm_rows_kernel<BF16, false>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group, lo8);
+        if (f16) hipLaunchKernelGGL((norm_rows_kernel<F16, false>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group);
+        else hipLaunchKernelGGL((norm_rows_kernel<BF16, false>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, group);
     }
 }
 
@@ -1031,51 +989,44 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const unsigned s
     }
 }
 
-// ---- split-operand mode, e4m3 residual pass: power-of-two scaled e4m3 with the scale in E8M0 form ----
+// ---- split-operand mode, e4m3 residual pass: block-scaled e4m3 (common.h lo8_scale_at) ----
 // Rows [hi x K | lo x K] of 2-byte elements: the residual half is rewritten IN PLACE as K e4m3 bytes (the first half of its own
-// space) + one E8M0 exponent per row.  One wave per row, two sweeps (row maximum, then convert); a sweep step reads bytes
-// [1024 t, 1024 t + 1024) of the residual half and writes [512 t, 512 t + 512): only bytes that were already consumed.
-// aexp2 != null (weights inexact in the operand type): the hi half is ALSO encoded, K more e4m3 bytes + exponent, into the second half
-// of the residual space (behind the residual bytes), after the residual sweep has consumed it.
+// space) + one E8M0 byte per 128-column block.  For producers that do not write that form themselves.  One wave per row, ONE sweep:
+// 16 lanes hold a block, so its maximum is a DPP reduction; a sweep step reads bytes [1024 t, 1024 t + 1024) of the residual half
+// and writes [512 t, 512 t + 512): only bytes that were already consumed.  K % 128 == 0.
+// aexp2 != null (weights inexact in the operand type): the hi half is ALSO encoded, K more e4m3 bytes with ONE exponent per row, into
+// the second half of the residual space (behind the residual bytes), after the residual sweep has consumed it.
 template <typename OT>
-__global__ __launch_bounds__(256) void quantize_lo_inplace_kernel(unsigned short* __restrict__ a, int ld, int K, int rows, int* __restrict__ aexp,
+__global__ __launch_bounds__(256) void quantize_lo_inplace_kernel(unsigned short* __restrict__ a, int ld, int K, int rows, unsigned char* __restrict__ scales,
                                                                   int* __restrict__ aexp2) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     unsigned short* lo = a + (size_t)row * ld + K;
-    float amax = 0.f;
-    for (int k = lane * 8; k < K; k += 512) {
-        const uint4 v = *(const uint4*)(lo + k);
-        const unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            amax = fmaxf(amax, fabsf(Op<OT>::to_f32((unsigned short)(w[i] & 0xFFFF))));
-            amax = fmaxf(amax, fabsf(Op<OT>::to_f32((unsigned short)(w[i] >> 16))));
-        }
-    }
-    amax = wave_max(amax);
-    const int E = e8m0_of_amax(amax);
-    if (lane == 0) aexp[row] = E;
     unsigned char* q = (unsigned char*)lo;
     for (int k0 = 0; k0 < K; k0 += 512) {
         const int k = k0 + lane * 8;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (k < K) v = *(const uint4*)(lo + k);
         __builtin_amdgcn_s_waitcnt(0);                       // the whole wave has its 16 bytes before anyone overwrites them
-        if (k < K) {
-            const unsigned w[4] = {v.x, v.y, v.z, v.w};
-            float f[8];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        float f[8];
+        float m = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f[2 * i] = ldexpf(Op<OT>::to_f32((unsigned short)(w[i] & 0xFFFF)), 127 - E);
-                f[2 * i + 1] = ldexpf(Op<OT>::to_f32((unsigned short)(w[i] >> 16)), 127 - E);
-            }
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = Op<OT>::to_f32((unsigned short)(w[i] & 0xFFFF));
+            f[2 * i + 1] = Op<OT>::to_f32((unsigned short)(w[i] >> 16));
+            m = fmaxf(m, fmaxf(fabsf(f[2 * i]), fabsf(f[2 * i + 1])));
+        }
+        const int E = e8m0_of_amax(row16_max(m));
+        if (k < K) {
+            const float sc = e8m0_inv_scale(E);
             int l2 = 0, h2 = 0;
-            l2 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], l2, false);
-            l2 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], l2, true);
-            h2 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], h2, false);
-            h2 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], h2, true);
+            l2 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * sc, f[1] * sc, l2, false);
+            l2 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * sc, f[3] * sc, l2, true);
+            h2 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * sc, f[5] * sc, h2, false);
+            h2 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * sc, f[7] * sc, h2, true);
             *(uint2*)(q + k) = make_uint2((unsigned)l2, (unsigned)h2);
+            if ((lane & 15) == 0) scales[lo8_scale_at(row, k >> 7, rows)] = (unsigned char)E;
         }
     }
     if (aexp2) {
@@ -1113,12 +1064,12 @@ __global__ __launch_bounds__(256) void quantize_lo_inplace_kernel(unsigned short
     }
 }
 
-void launch_quantize_lo_inplace(void* a, int ld, int K, int rows, int* aexp, int operand_dtype, hipStream_t st, int* aexp2) {
+void launch_quantize_lo_inplace(void* a, int ld, int K, int rows, unsigned char* scales, int operand_dtype, hipStream_t st, int* aexp2) {
     if (rows <= 0) return;
-    if (K % 8 || ld % 8) throw std::runtime_error("quantize_lo_inplace: K and the row stride must be multiples of 8");
+    if (K % 128 || ld % 8) throw std::runtime_error("quantize_lo_inplace: K must be a multiple of 128 and the row stride of 8");
     const dim3 grid((rows + 3) / 4), block(256);
-    if (operand_dtype == DT_F16) hipLaunchKernelGGL(quantize_lo_inplace_kernel<F16>, grid, block, 0, st, (unsigned short*)a, ld, K, rows, aexp, aexp2);
-    else hipLaunchKernelGGL(quantize_lo_inplace_kernel<BF16>, grid, block, 0, st, (unsigned short*)a, ld, K, rows, aexp, aexp2);
+    if (operand_dtype == DT_F16) hipLaunchKernelGGL(quantize_lo_inplace_kernel<F16>, grid, block, 0, st, (unsigned short*)a, ld, K, rows, scales, aexp2);
+    else hipLaunchKernelGGL(quantize_lo_inplace_kernel<BF16>, grid, block, 0, st, (unsigned short*)a, ld, K, rows, scales, aexp2);
 }
 
 // W8 twin of a weight matrix [N, K] (2-byte elements, row stride ldw): e4m3(W * 2^(127 - E)) into the first K bytes of the rows of

@@ -83,6 +83,7 @@ _SIGS = {
     "lr_op_quantize_rows_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "lr_op_gemm_fp8": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_void_p]),
     "lr_op_gemm_bt_mixed": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7 + [C.POINTER(C.c_int), C.c_void_p]),
+    "lr_op_lo8_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "lr_op_norm_rows": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "lr_op_synth_fill": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_char_p, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "lr_hd_transform_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

@@ -428,7 +428,7 @@ def test_gemm_e4m3_residual_pass_matches_fp64(lib):
         A2 = torch.cat([hi, lo], dim=1).contiguous()
         ref = (A32.double() @ W.double().t() + bias.double()).float()
         W8 = torch.zeros(N, K, device="cuda", dtype=tdt)
-        aexp = torch.zeros(M, dtype=torch.int32, device="cuda")
+        aexp = torch.full((lib.lr_op_lo8_scratch_bytes(M, K),), 127, dtype=torch.uint8, device="cuda")
         wexp = C.c_int(0)
         out = torch.empty(M, N, device="cuda", dtype=torch.float32)
         A_work = A2.clone()
@@ -441,11 +441,20 @@ def test_gemm_e4m3_residual_pass_matches_fp64(lib):
         torch.cuda.synchronize()
         e1 = (single - ref).abs().max().item()
         assert err < 3e-5 * scale and err < e1 / 8, (M, N, K, err / scale, e1 / scale)
-        # the residual half now holds e4m3 bytes with one power-of-two scale per row: decode and compare with the f16 residuals
+        # the residual half now holds e4m3 bytes with one power-of-two scale per (row, 128-column block), the scales grouped by
+        # 4 K-tiles and 256-row tile in the consuming kernel's lane order (csrc/common.h lo8_scale_at): decode, compare with the f16
+        # residuals -- every element within 2^-4 of its BLOCK's maximum
         lo8 = A_work[:, K:].contiguous().view(torch.uint8)[:, :K].contiguous().view(torch.float8_e4m3fn).float()
-        dec = lo8 * torch.exp2((aexp - 127).float())[:, None]
+        Mb, nkb = (M + 255) // 256, K // 128
+        planes = aexp[: Mb * 1024 * ((nkb + 3) // 4)].view((nkb + 3) // 4, Mb, 4, 256).permute(0, 2, 1, 3).reshape(-1, Mb, 256)[:nkb]   # [kblock, Mb, 256]
+        r = torch.arange(256, device="cuda")
+        sidx = ((((r >> 6) & 1) * 16 + (r & 15)) * 2 + (r >> 7)) * 4 + ((r >> 4) & 3)
+        E = planes[:, :, sidx].reshape(nkb, Mb * 256)[:, :M].t().float()                  # [M, K / 128]
+        dec = (lo8.view(M, K // 128, 128) * torch.exp2(E - 127)[:, :, None]).view(M, K)
         ref_lo = lo.float()
-        assert (dec - ref_lo).abs().max().item() <= 2.0 ** -4 * ref_lo.abs().amax(dim=1).max().item()
+        bmax = ref_lo.view(M, K // 128, 128).abs().amax(dim=2, keepdim=True).expand(M, K // 128, 128).reshape(M, K)
+        assert ((dec - ref_lo).abs() <= 2.0 ** -4 * bmax + 1e-30).all()
+        print(f"[e4m3 residual pass, block scales] M={M} N={N} K={K}: err {err / scale:.2e} of the output scale (single pass {e1 / scale:.2e})")
         assert torch.equal(A_work[:, :K], hi)                                  # the hi half is untouched
         # operand-typed output with GELU: [hi | lo]
         o2 = torch.zeros(M, 2 * N, device="cuda", dtype=tdt)
@@ -454,6 +463,85 @@ def test_gemm_e4m3_residual_pass_matches_fp64(lib):
         g = torch.nn.functional.gelu(ref)
         got = o2[:, :N].float() + o2[:, N:].float()
         assert (got - g).abs().max().item() < 4e-5 * g.abs().max().item()
+
+
+def test_gemm_e4m3_residual_pass_more_scale_groups_than_lds_slots(lib):
+    """K = 16640: 130 residual K-tiles = 33 scale groups, one more than the 32 slots the kernel keeps behind its LDS ring, so the last
+    group is fetched late into the slot of the first (the Qwen2.5-VL down projection, K = 18944, is the path's only such GEMM)."""
+    code, tdt = L.LR_DT_F16, torch.float16
+    M, N, K = 300, 256, 16640
+    A32 = rnd((M, K), 201, 0.7)
+    W = rnd((N, K), 202, 0.02).to(torch.bfloat16).to(tdt)
+    hi, lo = _split(A32, tdt)
+    A2 = torch.cat([hi, lo], dim=1).contiguous()
+    ref = (A32.double() @ W.double().t()).float()
+    scr = torch.full((lib.lr_op_lo8_scratch_bytes(M, K),), 127, dtype=torch.uint8, device="cuda")
+    W8 = torch.zeros_like(W)
+    we = C.c_int(0)
+    out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    assert lib.lr_op_gemm_bt_mixed(P(A2), P(W), P(W8), P(scr), P(out), None, M, N, K, L.EPI_OUT_F32, 0, code, 3, C.byref(we), stream()) == 0
+    single = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    assert lib.lr_op_gemm_bt(P(hi), P(W), P(single), None, M, N, K, K, K, N, L.EPI_OUT_F32, 0, code, 6, stream()) == 0
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    err, e1 = (out - ref).abs().max().item(), (single - ref).abs().max().item()
+    print(f"[33 scale groups] err {err / scale:.2e} (single pass {e1 / scale:.2e})")
+    assert err < 3e-5 * scale and err < e1 / 6
+
+
+def test_gemm_e4m3_residuals_written_by_the_producing_epilogue(lib):
+    """Two chained default-mode GEMMs, h = gelu(x W1^T + b) (or silu(gate) * up) then y = h W2^T: the first one's epilogue writes h's
+    residual half in the one-byte block-scaled form itself (flag 32), the second reads it as it is (no in-place pass).  The chain
+    against fp64 on un-rounded operands, as close as with the in-place encoder in between; h's bytes decode to within 2^-4 of their
+    block maximum of the exact residuals; ragged M (rows beyond the last full 256-row tile)."""
+    code, tdt = L.LR_DT_F16, torch.float16
+    for (M, K, N1, N2, epi) in [(700, 384, 512, 256, L.EPI_OUT_OP), (4100, 1024, 2048, 768, L.EPI_SWIGLU_OP), (8190, 512, 4096, 512, L.EPI_OUT_OP)]:
+        x32 = rnd((M, K), 191, 0.7) * torch.exp2(torch.randint(-4, 5, (M, 1), generator=torch.Generator().manual_seed(7)).float()).cuda()
+        W1 = rnd((N1, K), 192, 0.05).to(torch.bfloat16).to(tdt)
+        b1 = rnd((N1,), 193) if epi == L.EPI_OUT_OP else None
+        Kh = N1 if epi == L.EPI_OUT_OP else N1 // 2
+        W2 = rnd((N2, Kh), 194, 0.05).to(torch.bfloat16).to(tdt)
+        hi, lo = _split(x32, tdt)
+        pre = x32.double() @ W1.double().t()
+        if epi == L.EPI_OUT_OP:
+            h_ref = torch.nn.functional.gelu(pre + b1.double())
+        else:      # weight rows interleaved in blocks of 32: [gate 0..31 | up 0..31 | gate 32..63 | ...]
+            pr = pre.view(M, N1 // 64, 2, 32)
+            h_ref = (torch.nn.functional.silu(pr[:, :, 0]) * pr[:, :, 1]).reshape(M, Kh)
+        ref = (h_ref @ W2.double().t()).float()
+        scale = ref.abs().max().item()
+        outs = {}
+        for fused in (True, False):
+            A = torch.cat([hi, lo], dim=1).contiguous()
+            s1 = torch.full((lib.lr_op_lo8_scratch_bytes(M, K) + lib.lr_op_lo8_scratch_bytes(M, Kh),), 127, dtype=torch.uint8, device="cuda")
+            W81, W82 = torch.zeros_like(W1), torch.zeros_like(W2)
+            we1, we2 = C.c_int(0), C.c_int(0)
+            h = torch.zeros(M, 2 * Kh, device="cuda", dtype=tdt)
+            y = torch.empty(M, N2, device="cuda", dtype=torch.float32)
+            act = L.ACT_GELU_ERF if epi == L.EPI_OUT_OP else 0
+            assert lib.lr_op_gemm_bt_mixed(P(A), P(W1), P(W81), P(s1), P(h), P(b1), M, N1, K, epi, act, code, 3 | (32 if fused else 0), C.byref(we1), stream()) == 0
+            s2 = s1[lib.lr_op_lo8_scratch_bytes(M, K):]
+            if fused:
+                torch.cuda.synchronize()
+                h_bytes, h_scales = h.clone(), s2.clone()
+            assert lib.lr_op_gemm_bt_mixed(P(h), P(W2), P(W82), P(s2), P(y), None, M, N2, Kh, L.EPI_OUT_F32, 0, code, 1 if fused else 3, C.byref(we2), stream()) == 0
+            torch.cuda.synchronize()
+            outs[fused] = (y - ref).abs().max().item() / scale
+        print(f"[fused residual encode] M={M} K={K} N1={N1} N2={N2} epi={epi}: chain err fused {outs[True]:.2e}, in-place {outs[False]:.2e}")
+        assert outs[True] < 4e-5 and outs[True] < 1.5 * outs[False] + 2e-6
+        # decode h's residual half
+        hh = h_bytes[:, :Kh].float()
+        lo8 = h_bytes[:, Kh:].contiguous().view(torch.uint8)[:, :Kh].contiguous().view(torch.float8_e4m3fn).float()
+        Mb, nkb = (M + 255) // 256, Kh // 128
+        planes = h_scales[: Mb * 1024 * ((nkb + 3) // 4)].view((nkb + 3) // 4, Mb, 4, 256).permute(0, 2, 1, 3).reshape(-1, Mb, 256)[:nkb]
+        r = torch.arange(256, device="cuda")
+        sidx = ((((r >> 6) & 1) * 16 + (r & 15)) * 2 + (r >> 7)) * 4 + ((r >> 4) & 3)
+        E = planes[:, :, sidx].reshape(nkb, Mb * 256)[:, :M].t().float()
+        dec = (lo8.view(M, nkb, 128) * torch.exp2(E - 127)[:, :, None]).view(M, Kh)
+        # the epilogue's own fp32 h is not visible; hi + decoded lo must sit closer to the fp64 h than hi alone by ~2^-4 of the f16 step
+        e_hi = (hh.double() - h_ref).abs()
+        e_full = (hh.double() + dec.double() - h_ref).abs()
+        assert e_full.max().item() < 2e-5 * h_ref.abs().max().item() and e_full.mean().item() < e_hi.mean().item() / 6
 
 
 def test_gemm_w8a8_e4m3(lib):
@@ -499,7 +587,7 @@ def test_gemm_e4m3_residual_pass_with_inexact_weights(lib):
         ref = (A32.double() @ W32.double().t()).float()
         scale = ref.abs().max().item()
         twin = Wlo.clone().contiguous()
-        aexp = torch.zeros(2 * M, dtype=torch.int32, device="cuda")
+        aexp = torch.full((lib.lr_op_lo8_scratch_bytes(M, K),), 127, dtype=torch.uint8, device="cuda")
         wexp = (C.c_int * 2)(0, 0)
         out = torch.empty(M, N, device="cuda", dtype=torch.float32)
         assert lib.lr_op_gemm_bt_mixed(P(A2), P(Whi), P(twin), P(aexp), P(out), None, M, N, K, L.EPI_OUT_F32, 0, code, 11, wexp, stream()) == 0

@@ -24,7 +24,7 @@ for name, M, N, K, epi, cnt in SHAPES:
     A = torch.cat([torch.randn(M, K, device="cuda").half(), (torch.randn(M, K, device="cuda") * 2.0 ** -12).half()], dim=1).contiguous()
     W = (torch.randn(N, K, device="cuda") * 0.02).half()
     W8 = torch.zeros_like(W)
-    ae = torch.zeros(M, dtype=torch.int32, device="cuda")
+    ae = torch.full((lib.lr_op_lo8_scratch_bytes(M, K),), 127, dtype=torch.uint8, device="cuda")
     we = C.c_int(0)
     op = epi in (L.EPI_OUT_OP, L.EPI_SWIGLU_OP)
     nout = N // 2 if epi == L.EPI_SWIGLU_OP else N

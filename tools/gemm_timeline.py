@@ -22,7 +22,7 @@ for name in (sys.argv[1:] or list(SHAPES)):
     A = torch.cat([torch.randn(M, K, device="cuda").half(), (torch.randn(M, K, device="cuda") * 2.0 ** -12).half()], dim=1).contiguous()
     W = (torch.randn(N, K, device="cuda") * 0.02).half()
     W8 = torch.zeros_like(W)
-    ae = torch.zeros(M, dtype=torch.int32, device="cuda")
+    ae = torch.full((lib.lr_op_lo8_scratch_bytes(M, K),), 127, dtype=torch.uint8, device="cuda")
     we = C.c_int(0)
     op = epi == L.EPI_OUT_OP
     out = torch.zeros(M, 2 * N if op else N, device="cuda", dtype=torch.float16 if op else torch.float32)
