@@ -136,12 +136,14 @@ def dominant_kernel_probe(dtype_code, tile, steps=5, split=False, lo8=False):
     st = torch.cuda.current_stream()
     if lo8:      # split-operand form with the e4m3 residual pass: W8 twin prepared and the residual half encoded once, then timed
         W8 = torch.zeros_like(W)
-        ae = torch.full((lib.lr_op_lo8_scratch_bytes(M, K),), 127, dtype=torch.uint8, device="cuda")
+        # (as the engine launches it: the epilogue writes the output's residual half as block-scaled e4m3 too -- flag 32 -- because
+        #  the down projection that reads it takes the same form)
+        ae = torch.full((lib.lr_op_lo8_scratch_bytes(M, K) + lib.lr_op_lo8_scratch_bytes(M, N // 2),), 127, dtype=torch.uint8, device="cuda")
         we = C.c_int(0)
         base = (C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(W8.data_ptr()), C.c_void_p(ae.data_ptr()), C.c_void_p(out.data_ptr()),
                 C.c_void_p(0), M, N, K, L.EPI_SWIGLU_OP, 0, dtype_code)
         assert lib.lr_op_gemm_bt_mixed(*base, 7, C.byref(we), C.c_void_p(st.cuda_stream)) == 0
-        fn, args = lib.lr_op_gemm_bt_mixed, base + (0, C.byref(we), C.c_void_p(st.cuda_stream))
+        fn, args = lib.lr_op_gemm_bt_mixed, base + (32, C.byref(we), C.c_void_p(st.cuda_stream))
     elif split:
         fn, args = lib.lr_op_gemm_bt_split, (C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(0),
                                              M, N, K, L.EPI_SWIGLU_OP, 0, dtype_code, tile, C.c_void_p(st.cuda_stream))
@@ -161,7 +163,7 @@ def dominant_kernel_probe(dtype_code, tile, steps=5, split=False, lo8=False):
     label = ", split-operand form, e4m3 residual pass" if lo8 else ", split-operand form" if split else ""
     return dict({"kernel": "gemm_bt8_kernel<SwiGLU> decoder gate_up" + label, "shape": [M, N, K],
                  "avg_ms": ms, "tflops": 2.0 * M * N * K / (ms * 1e-3) / 1e12, "mfma_work_factor": 1.5 if lo8 else w,
-                 "algorithmic_bytes": 2.0 * ((1.5 if lo8 else w) * M * K + (1.5 if lo8 else 1) * N * K + w * M * N // 2)}, **pmc)
+                 "algorithmic_bytes": 2.0 * ((1.5 if lo8 else w) * M * K + (1.5 if lo8 else 1) * N * K + (1.5 if lo8 else w) * M * N // 2)}, **pmc)
 
 
 def golden_check(model, model_name, name=None):

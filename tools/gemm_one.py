@@ -20,13 +20,13 @@ W = (torch.randn(N, K, device="cuda") * 0.02).to(torch.float16)
 out = torch.zeros(M, w * N // 2, device="cuda", dtype=torch.float16)
 st = torch.cuda.current_stream()
 if mixed:
-    W8 = torch.zeros(N, K, device="cuda", dtype=torch.float16); ae = torch.full((lib.lr_op_lo8_scratch_bytes(M, K),), 127, dtype=torch.uint8, device="cuda"); we = C.c_int(0)
+    W8 = torch.zeros(N, K, device="cuda", dtype=torch.float16); ae = torch.full((lib.lr_op_lo8_scratch_bytes(M, K) + lib.lr_op_lo8_scratch_bytes(M, N // 2),), 127, dtype=torch.uint8, device="cuda"); we = C.c_int(0)
     assert lib.lr_op_gemm_bt_mixed(C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(W8.data_ptr()), C.c_void_p(ae.data_ptr()),
                                    C.c_void_p(out.data_ptr()), C.c_void_p(0), M, N, K, L.EPI_SWIGLU_OP, 0, L.LR_DT_F16, 7, C.byref(we), C.c_void_p(st.cuda_stream)) == 0
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
     if mixed:
         lib.lr_op_gemm_bt_mixed(C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(W8.data_ptr()), C.c_void_p(ae.data_ptr()),
-                                C.c_void_p(out.data_ptr()), C.c_void_p(0), M, N, K, L.EPI_SWIGLU_OP, 0, L.LR_DT_F16, 0, C.byref(we), C.c_void_p(st.cuda_stream))
+                                C.c_void_p(out.data_ptr()), C.c_void_p(0), M, N, K, L.EPI_SWIGLU_OP, 0, L.LR_DT_F16, 32, C.byref(we), C.c_void_p(st.cuda_stream))      # 32: as the engine launches it
     elif split:
         lib.lr_op_gemm_bt_split(C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(0), M, N, K,
                                 L.EPI_SWIGLU_OP, 0, L.LR_DT_F16, 6, C.c_void_p(st.cuda_stream))
@@ -34,4 +34,4 @@ for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
         lib.lr_op_gemm_bt(C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(0), M, N, K, K, K, N // 2,
                           L.EPI_SWIGLU_OP, 0, L.LR_DT_F16, 6, C.c_void_p(st.cuda_stream))
 torch.cuda.synchronize()
-print("algorithmic bytes per launch (A + W + out): %.3f GB" % (((1.5 if mixed else w) * M * K + (1.5 if mixed else 1) * N * K + w * M * N // 2) * 2 / 1e9))
+print("algorithmic bytes per launch (A + W + out): %.3f GB" % (((1.5 if mixed else w) * M * K + (1.5 if mixed else 1) * N * K + (1.5 if mixed else w) * M * N // 2) * 2 / 1e9))
