@@ -37,9 +37,6 @@
 
 namespace lr {
 
-#ifndef LR_PF2
-#define LR_PF2 6          // half-tiles issued ahead in the product schedule: 6 and 8 measure the same; 6 leaves 32 KB of LDS
-#endif
 #define LR_BARRIER() do { asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 // DBG: 0 = product; 1 = every K-tile re-reads K-tile 0 (cache-resident operands; results invalid);
@@ -307,17 +304,17 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         // COMPUTE = 32 MFMAs (an A half against B0 and B1) with the 4 B reads of the next use riding inside it.  Half the
         // barriers and priority flips per K-tile, and the LOAD segment (the critical path of the 4-phase form) is shorter than
         // its partner's COMPUTE.  Super-phase Q = 2 kt + s:
-        //   LOAD(2kt)    af <- A0(kt)                 issue half-tiles 4kt+8, 4kt+9     wait: all but the newest 4 half-tiles landed
+        //   LOAD(2kt)    af <- A0(kt)                 issue half-tiles 4kt+6, 4kt+7     wait: all but the newest 2 half-tiles landed
         //   COMPUTE(2kt)   bg <- B1(kt);  (0,0) = af x bf;  (0,1) = af x bg
-        //   LOAD(2kt+1)  af <- A1(kt)                 issue half-tiles 4kt+10, 4kt+11
+        //   LOAD(2kt+1)  af <- A1(kt)                 issue half-tiles 4kt+8, 4kt+9
         //   COMPUTE(2kt+1) (1,0) = af x bf;  bf <- B0(kt+1);  (1,1) = af x bg
         // RAW: a read inside COMPUTE(Q) of the leading group needs the LAGGING group's LOAD(Q-1) wait (it is still inside its own
-        // LOAD(Q)), a read in LOAD(Q+1) its LOAD(Q) wait; with 8 half-tiles issued ahead and 4 allowed in flight LOAD(Q) retires
-        // 2Q+5: B1(kt) = 4kt+2 <= 2(2kt-1)+5, A1 = 4kt+3 and B0(kt+1) = 4kt+5 <= 2(2kt)+5, A0(kt+1) = 4kt+4 <= 2(2kt+1)+5.
-        // WAR: half-tile g+NS is issued at LOAD(floor((g+NS-8)/2)); the lagging group is then in COMPUTE of the interval before
-        // and its reads of g (A0: LOAD(g/2); B1: COMPUTE(g/2-1); A1: LOAD((g-1)/2); B0: COMPUTE((g-5)/2)) are behind it iff NS-8 >= 2.
-        constexpr int PF2 = LR_PF2, WAIT2 = 2 * (PF2 - 4);
-        static_assert(PF2 == 8 || PF2 == 6, "the issue pattern below knows these two depths");
+        // LOAD(Q)), a read in LOAD(Q+1) its LOAD(Q) wait; with PF2 half-tiles issued ahead and PF2 - 4 allowed in flight LOAD(Q)
+        // retires 2Q+5: B1(kt) = 4kt+2 <= 2(2kt-1)+5, A1 = 4kt+3 and B0(kt+1) = 4kt+5 <= 2(2kt)+5, A0(kt+1) = 4kt+4 <= 2(2kt+1)+5.
+        // WAR: half-tile g+NS is issued at LOAD(floor((g+NS-PF2)/2)); the lagging group is then in COMPUTE of the interval before
+        // and its reads of g (A0: LOAD(g/2); B1: COMPUTE(g/2-1); A1: LOAD((g-1)/2); B0: COMPUTE((g-5)/2)) are behind it iff
+        // NS - PF2 >= 2.  A half-tile has one phase and a half between its issue and the wait that retires it.
+        constexpr int PF2 = 6, WAIT2 = 2 * (PF2 - 4);       // 6 half-tiles ahead measure the same as 8 and leave 32 KB of LDS
         static_assert(F8 != 2 || (NS + 2) * HT <= 160 * 1024, "the scale slices live behind the ring");
         static_assert(NS - PF2 >= 2, "ring hazard distances (super-phase schedule)");
         int islot = 0;
@@ -382,14 +379,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                     }
                 }
                 if (more) {
-                    if constexpr (DBG != 5 && PF2 == 8) {
-                        if (sp == 0) ktile_begin();
-                        issue(2 * sp, kt + 2, islot);
-                        islot = (islot + 1 == NS) ? 0 : islot + 1;
-                        issue(2 * sp + 1, kt + 2, islot);
-                        islot = (islot + 1 == NS) ? 0 : islot + 1;
-                        if (sp == 1) ktile_end();
-                    } else if constexpr (DBG != 5) {          // 6 ahead: second half of K-tile kt+1, then first half of kt+2
+                    if constexpr (DBG != 5) {                 // second half of K-tile kt+1, then first half of kt+2
                         if (sp == 1) ktile_begin();
                         issue(sp == 0 ? 2 : 0, kt + 2, islot);
                         islot = (islot + 1 == NS) ? 0 : islot + 1;
@@ -918,7 +908,7 @@ static int* sched_words(hipStream_t st) {
 
 template <typename OT, int PF, int DBG, int EPI, int PB = 0, int F8 = 0>
 static void launch8(const GemmParams& p, bool persistent, hipStream_t st) {
-    constexpr int NS = PB == 2 ? LR_PF2 + 2 : 10;      // ring slots; the product schedule keeps the rest of the 160 KB for scale slices
+    constexpr int NS = PB == 2 ? 8 : 10;      // ring slots; the product schedule keeps the rest of the 160 KB for scale slices
     constexpr int smem = 10 * 16384;
     static bool attr_set = false;
     auto kfn = gemm_bt8_kernel<OT, PF, NS, DBG, EPI, PB, F8>;
