@@ -277,8 +277,9 @@ template <typename F> int guarded(lr_engine* e, F&& f) {
 // Split-operand mode: callers pass LOGICAL shapes; here A becomes [A_hi | A_lo] (K doubled, W re-read from column 0) and an
 // operand-typed output becomes [C_hi | C_lo].
 // With desc.precise == 2 the residual pass of a GEMM that runs on the deep-pipelined kernel is made in e4m3: the residual half of
-// A is re-encoded in place (stream-ordered, right here: every operand buffer feeds exactly one GEMM after it is produced) and W's
-// e4m3 twin is prepared on first use in the rows of its residual buffer (exact weights only; one synchronisation per weight).
+// A arrives as block-scaled e4m3 from its producer (norms, SwiGLU / operand-out epilogues: pre_enc) or is re-encoded in place
+// (stream-ordered, right here: every operand buffer feeds exactly one GEMM after it is produced), and W's e4m3 twin is prepared on
+// first use in the rows of its residual buffer (exact weights only; one synchronisation per weight).
 // apply_prec_base only rewrites the parameters (no side effects); upgrade_lo8 commits the e4m3 form right before the launch.
 inline void apply_prec_base(const lr_engine* e, GemmParams& p) {
     if (!e->prec) return;
@@ -321,6 +322,7 @@ inline void ensure_lo8_twin(lr_engine* e, const void* W, int N, int K, int ldw, 
     e->w8exp[W] = E;
     e->w8exp2[W] = E2;
 }
+// scale arrays (and the hi-half row exponents) large enough for an operand of `rows` x K; presized at lr_finalize (prepare_twins)
 inline void ensure_aexp(lr_engine* e, size_t rows, size_t K) {
     const size_t need = lo8_scale_bytes((int)rows, (int)K);
     if (need > e->sc_cap) {
@@ -378,7 +380,7 @@ inline void apply_prec(lr_engine* e, GemmParams& p, hipStream_t st) {
     apply_prec_base(e, p);
     upgrade_lo8(e, p, st);
 }
-// For a norm kernel that feeds the GEMM described by `probe` (logical shapes, as passed to gemm()): where to put the row exponents if
+// For a norm kernel that feeds the GEMM described by `probe` (logical shapes, as passed to gemm()): where to put the block scales if
 // that GEMM will take the e4m3 residual form with exact weights, else null (the norm then writes 16-bit residuals as usual).
 inline unsigned char* lo8_norm_target(lr_engine* e, GemmParams probe) {
     e->pre_enc = nullptr;
