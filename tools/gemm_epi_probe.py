@@ -24,7 +24,7 @@ for name, M, N, K, epi, cnt in SHAPES:
     A = torch.cat([torch.randn(M, K, device="cuda").half(), (torch.randn(M, K, device="cuda") * 2.0 ** -12).half()], dim=1).contiguous()
     W = (torch.randn(N, K, device="cuda") * 0.02).half()
     W8 = torch.zeros_like(W)
-    ae = torch.full((lib.lr_op_lo8_scratch_bytes(M, K),), 127, dtype=torch.uint8, device="cuda")
+    ae = torch.full((lib.lr_op_lo8_scratch_bytes(M, K) + lib.lr_op_lo8_scratch_bytes(M, N),), 127, dtype=torch.uint8, device="cuda")
     we = C.c_int(0)
     op = epi in (L.EPI_OUT_OP, L.EPI_SWIGLU_OP)
     nout = N // 2 if epi == L.EPI_SWIGLU_OP else N
@@ -34,7 +34,8 @@ for name, M, N, K, epi, cnt in SHAPES:
     assert lib.lr_op_gemm_bt_mixed(*base, 7, C.byref(we), C.c_void_p(st.cuda_stream)) == 0
     res = {}
     for rnd in range(2):
-        for flags in (FLAGS if epi == L.EPI_RESADD_F32 else (0, 16)):
+        fused = 32 if (op and os.environ.get("LR_PROBE_FUSED", "1") != "0") else 0      # operand outputs as the engine writes them: one-byte residuals
+        for flags in (FLAGS if epi == L.EPI_RESADD_F32 else (fused, 16)):
             args = base + (flags, C.byref(we), C.c_void_p(st.cuda_stream))
             assert lib.lr_op_gemm_bt_mixed(*args) == 0
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -43,7 +44,7 @@ for name, M, N, K, epi, cnt in SHAPES:
                 lib.lr_op_gemm_bt_mixed(*args)
             e1.record(st)
             torch.cuda.synchronize()
-            res[flags] = min(res.get(flags, 1e9), e0.elapsed_time(e1) / reps)
+            res[0 if flags == 32 else flags] = min(res.get(0 if flags == 32 else flags, 1e9), e0.elapsed_time(e1) / reps)
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
     per_cu = tiles / 256.0
     print(f"{name:12s} M={M:6d} N={N:5d} K={K:4d} | product {res[0]:7.3f} ms | no epilogue {res[16]:7.3f} ms | epilogue {res[0] - res[16]:6.3f} ms "
