@@ -282,9 +282,10 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
             asm volatile("" : "+v"(ea2[0]), "+v"(ea2[1]));
         }
         // The scale bytes of the residual K-tiles travel through LDS: group g (the 4 x 256 bytes of this row tile for residual K-tiles
-        // 4g .. 4g+3, common.h lo8_scale_at) is ONE LDS-DMA instruction of one wave, issued during the 16-bit K-tiles -- whose LOAD
-        // segments have slack -- into the 32 KB behind the ring (32 groups; beyond that a group follows the one it replaces), so
-        // that the residual K-tiles, which are LOAD-bound, only pay one 8-byte LDS read per lane and K-tile.
+        // 4g .. 4g+3, common.h lo8_scale_at) is ONE LDS-DMA instruction of one wave, issued in the tile's prologue -- in front of the
+        // first half-tiles, whose latency is exposed there anyway -- into the 32 KB behind the ring (32 groups; beyond that a group
+        // follows the one it replaces), so that the residual K-tiles, which are LOAD-bound, only pay one 8-byte LDS read per lane
+        // and K-tile.  (Issued inside the K loop, a scale group is a cold line at the head of the in-order queue: ~0.6 us per group.)
         constexpr int SC_GROUPS = 32;
         const unsigned sc_voff = (unsigned)((wr * 16 + l15) * 8);
         const unsigned char* sc_tile = p.aexp + (size_t)mi * 1024;
@@ -318,6 +319,9 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         static_assert(F8 != 2 || (NS + 2) * HT <= 160 * 1024, "the scale slices live behind the ring");
         static_assert(NS - PF2 >= 2, "ring hazard distances (super-phase schedule)");
         int islot = 0;
+        if constexpr (F8 == 2) {         // this tile's scale groups first: the oldest entries of the queue, retired by the prologue's wait
+            for (int g = wave; g < min(nsg, SC_GROUPS); g += 8) issue_scales(g);
+        }
 #pragma unroll
         for (int g = 0; g < PF2; ++g) {
             if (g < Gtot) {
@@ -362,12 +366,9 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 #pragma unroll
                     for (int f = 0; f < 8; ++f) af[f] = *(const uint4*)(sa + aoff[f]);
                 }
-                // scale groups of the residual K-tiles: one per phase of the first 16-bit K-tiles, the waves taking turns; the scales
-                // of this K-tile's rows (both A halves) from LDS
-                if constexpr (F8 == 2 && LO == 0) {
-                    const int g = 2 * kt + sp;
-                    if (g < min(nsg, SC_GROUPS) && wave == (g & 7)) { issue_scales(g); scl = true; }
-                } else if constexpr (F8 == 2 && LO == 1) {
+                // the scales of this residual K-tile's rows (both A halves) from LDS; a late scale group (K > 16384) into the slot of
+                // the one it replaces
+                if constexpr (F8 == 2 && LO == 1) {
                     const int j = kt - nk_hi;
                     if (sp == 0) {
                         typedef int v2i_t __attribute__((ext_vector_type(2)));
