@@ -293,7 +293,9 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         const int nsl = nk_lo - nk_hi, nsg = (nsl + 3) >> 2;
         auto issue_scales = [&](int g) {
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + NS * HT + (g & (SC_GROUPS - 1)) * 1024);
-            const unsigned char* src = sc_tile + (size_t)g * sc_plane + lane * 16;
+            int l16 = lane * 16;
+            asm volatile("" : "+v"(l16));          // rebuilt at each call: hoisted, the address is one more 64-bit value spilled across the K loop
+            const unsigned char* src = sc_tile + (size_t)g * sc_plane + l16;
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
@@ -611,6 +613,14 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         tstamp(2);
         int claim = 0;              // requested here, looked at behind the epilogue: the round trip hides behind it
         if (dyn && tid == 0) claim = __hip_atomic_fetch_add(&p.sched[my_xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // The epilogue's per-lane index arithmetic starts HERE: the lane id is laundered so that nothing derived from it can be
+        // hoisted above the K loop (a persistent kernel's tile loop makes all of it loop-invariant).  Hoisted, it lived in registers
+        // the accumulators need, was spilled across the K loop, and the reloads' vmcnt waits -- placed by the compiler at the first
+        // use, inside the residual K-tile loop -- drained the DMA ring every K-tile of the RoPE kernel.
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        {
+        const int lane = lane_e, l15 = lane_e & 15, l4 = lane_e >> 4;
         if constexpr (F8 == 1) {    // dequantise: C[m][n] *= ascale[m] * wscale[n]
             // (the pointers are laundered so that these ordinary loads cannot be hoisted above the K loop, where their vmcnt
             //  waits would drain the DMA ring in front of every ds_read)
@@ -841,6 +851,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
             }
             tstamp(6 + 3 * qa);
         }
+        }       // (epilogue scope: laundered lane id)
         tstamp(3);
         ++tile_it;
         if (dyn) {
