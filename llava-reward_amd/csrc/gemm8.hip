@@ -654,12 +654,17 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         // 128-column block.  hi as 16 bytes, residuals as 8 e4m3 bytes scaled by the block's power of two, one scale byte per block.
         // Lanes past the matrix edge do not get here; their DPP contribution reads as zero.
         auto store_hi_lo8 = [&](const float (&v)[8], unsigned short* crow, int split, int col, unsigned char* scale_byte, bool writes_scale) {
-            unsigned short hb[8];
+            unsigned hp[4];
             float r[8];
             float m = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { hb[e] = Op<OT>::from_f32(v[e]); r[e] = v[e] - Op<OT>::to_f32(hb[e]); m = fmaxf(m, fabsf(r[e])); }
-            *(uint4*)(crow + col) = make_uint4(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16), hb[4] | ((unsigned)hb[5] << 16), hb[6] | ((unsigned)hb[7] << 16));
+            for (int e = 0; e < 4; ++e) {
+                hp[e] = round_pair<OT>(v[2 * e], v[2 * e + 1]);
+                r[2 * e] = v[2 * e] - Op<OT>::to_f32((unsigned short)(hp[e] & 0xFFFFu));
+                r[2 * e + 1] = v[2 * e + 1] - Op<OT>::to_f32((unsigned short)(hp[e] >> 16));
+                m = fmaxf(m, fmaxf(fabsf(r[2 * e]), fabsf(r[2 * e + 1])));
+            }
+            *(uint4*)(crow + col) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
             const int E = e8m0_of_amax(row16_max(m));
             const float sc = e8m0_inv_scale(E);
             int p0 = 0, p1 = 0;
@@ -756,8 +761,8 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                             store_hi_lo8(v, (unsigned short*)p.C + (size_t)row * p.ldc, p.split, ocol, p.oexp + lo8_scale_at(row, ocol >> 7, p.M), (lane & 15) == 0);
                         } else {
                             uint4 w, wl;
-                            split2<OT>(v[0], v[1], w.x, wl.x); split2<OT>(v[2], v[3], w.y, wl.y);
-                            split2<OT>(v[4], v[5], w.z, wl.z); split2<OT>(v[6], v[7], w.w, wl.w);
+                            split2p<OT>(v[0], v[1], w.x, wl.x); split2p<OT>(v[2], v[3], w.y, wl.y);
+                            split2p<OT>(v[4], v[5], w.z, wl.z); split2p<OT>(v[6], v[7], w.w, wl.w);
                             *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + ocol) = w;
                             if (p.split > 0) *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + p.split + ocol) = wl;
                         }
@@ -786,8 +791,8 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                     }
                     if (row < p.M && col < p.N) {
                         uint4 w, wl;
-                        split2<OT>(v0.x, v0.y, w.x, wl.x); split2<OT>(v0.z, v0.w, w.y, wl.y);
-                        split2<OT>(v1.x, v1.y, w.z, wl.z); split2<OT>(v1.z, v1.w, w.w, wl.w);
+                        split2p<OT>(v0.x, v0.y, w.x, wl.x); split2p<OT>(v0.z, v0.w, w.y, wl.y);
+                        split2p<OT>(v1.x, v1.y, w.z, wl.z); split2p<OT>(v1.z, v1.w, w.w, wl.w);
                         *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + col) = w;
                         if (p.split > 0) *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + p.split + col) = wl;
                     }
@@ -825,8 +830,8 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                             store_hi_lo8(v, (unsigned short*)p.C + (size_t)row * p.ldc, p.split, col, p.oexp + lo8_scale_at(row, col >> 7, p.M), (lane & 15) == 0);
                         } else {
                             uint4 w, wl;
-                            split2<OT>(v[0], v[1], w.x, wl.x); split2<OT>(v[2], v[3], w.y, wl.y);
-                            split2<OT>(v[4], v[5], w.z, wl.z); split2<OT>(v[6], v[7], w.w, wl.w);
+                            split2p<OT>(v[0], v[1], w.x, wl.x); split2p<OT>(v[2], v[3], w.y, wl.y);
+                            split2p<OT>(v[4], v[5], w.z, wl.z); split2p<OT>(v[6], v[7], w.w, wl.w);
                             *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + col) = w;
                             if (p.split > 0) *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + p.split + col) = wl;
                         }
