@@ -93,15 +93,13 @@ template <typename OT> __device__ __forceinline__ void split2(float a, float b, 
 // whose read + store loops are VALU-bound (~10 operations per element before this).  round_pair = Op::from_f32 of both, packed.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 template <typename OT> __device__ __forceinline__ unsigned round_pair(float a, float b);
 template <> __device__ __forceinline__ unsigned round_pair<F16>(float a, float b) {
     const f32x2_t x = {__builtin_fminf(__builtin_fmaxf(a, -65504.f), 65504.f), __builtin_fminf(__builtin_fmaxf(b, -65504.f), 65504.f)};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2_t));
 }
-template <> __device__ __forceinline__ unsigned round_pair<BF16>(float a, float b) {
-    const f32x2_t x = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2_t));
+template <> __device__ __forceinline__ unsigned round_pair<BF16>(float a, float b) {      // (the scalar conversions: the packed bf16 form
+    return pack2<BF16>(a, b);                                                               //  does not round every value the same way)
 }
 template <typename OT> __device__ __forceinline__ void split2p(float a, float b, unsigned& hi, unsigned& lo) {
     hi = round_pair<OT>(a, b);
