@@ -743,7 +743,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                         bu0 = *(const float4*)(p.bias + bc + 32); bu1 = *(const float4*)(p.bias + bc + 36);
                     }
                 }
-#pragma unroll 2
+#pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int rl = it * 32 + wave * 4 + (lane >> 4);
                     const int row = rowq + rl;
