@@ -414,6 +414,32 @@ def test_gemm_persistent_walk_many_tiles(lib, tile, shape):
     assert (out - ref).abs().max().item() < 2e-5 * ref.abs().max().item() * max(1.0, (K / 512) ** 0.5)
 
 
+def test_gemm_dynamic_tile_claims_on_two_streams(lib):
+    """The persistent kernel claims its tiles from per-XCD counters that live with the STREAM (one set per stream, left zero by the
+    last workgroup of every launch).  Two streams launching back to back, many times, different shapes: every result bit-equal to the
+    same launch made alone (a stale or shared counter would drop or repeat tiles)."""
+    M, K = 5284, 1024
+    A = rnd((M, K), 211).to(torch.float16)
+    Ws = [rnd((n, K), 212 + i, 0.05).to(torch.float16) for i, n in enumerate((2048, 3072))]
+    ref = []
+    for W in Ws:
+        out = torch.zeros(M, W.shape[0], device="cuda", dtype=torch.float32)
+        assert lib.lr_op_gemm_bt(P(A), P(W), P(out), P(None), M, W.shape[0], K, K, K, W.shape[0], L.EPI_OUT_F32, 0, L.LR_DT_F16, 6, stream()) == 0
+        torch.cuda.synchronize()
+        ref.append(out.clone())
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[torch.zeros_like(ref[i]) for _ in range(6)] for i in range(2)]
+    for rep in range(6):
+        for i, st in enumerate(streams):
+            W = Ws[i]
+            assert lib.lr_op_gemm_bt(P(A), P(W), P(outs[i][rep]), P(None), M, W.shape[0], K, K, K, W.shape[0], L.EPI_OUT_F32, 0, L.LR_DT_F16, 6,
+                                     C.c_void_p(st.cuda_stream)) == 0
+    torch.cuda.synchronize()
+    for i in range(2):
+        for rep in range(6):
+            assert torch.equal(outs[i][rep], ref[i]), (i, rep)
+
+
 def test_gemm_e4m3_residual_pass_matches_fp64(lib):
     """Split-operand GEMM with the residual pass in e4m3 (precise == 2): A_hi W^T on the f16 instruction + A_lo8 W8^T on the scaled
     e4m3 instruction in the same accumulators.  ~8e-6 of the output scale against fp64 on the un-rounded A (single pass: 2e-4)."""
