@@ -91,8 +91,10 @@ typedef struct lr_model_desc {
      * operand type (f16: 22 mantissa bits), weights stay single (bf16 checkpoints are exact in f16); every contraction
      * costs 2x (linears) / 3x (attention) the MFMA work.  0 = single-pass operands (default).
      * 2 = the same, with the residual pass of every GEMM that runs on the deep-pipelined kernel made in e4m3 (F16 operands only):
-     * the residual half of A is re-encoded in place with one power-of-two scale per row, W gets an e4m3 twin on first use, the
-     * scaled MFMA accumulates both passes in the same registers; 1.5x instead of 2x, ~8e-6 instead of ~1e-6 per GEMM. */
+     * the residual half of A is block-scaled e4m3 (one power-of-two scale per row and 128 columns), written in that form by the
+     * kernel that produces A where it can (norms, SwiGLU / operand-out GEMM epilogues) and re-encoded in place otherwise; W gets
+     * an e4m3 twin on first use; the scaled MFMA accumulates both passes in the same registers; 1.5x instead of 2x, ~8e-6 instead
+     * of ~1e-6 per GEMM. */
     int32_t precise;
     /* rw_model_general_preference.py:398-406 `mean_hidden_state`: the SkipCA block + its RMSNorm are applied to every token and
      * the value head reads the attention-mask-weighted mean (fp32 path; rewards are [B, value_head_dim] in train and eval). */
@@ -208,8 +210,8 @@ int lr_op_gemm_fp8(const void* A8, const float* ascale, const void* W8, const fl
                    int K, int ldc, int epi, int act, int operand_dtype, void* hip_stream);
 /* Split-operand GEMM with the e4m3 residual pass (lr_model_desc.precise == 2): A = [A_hi | A_lo] (2-byte elements, 2K per row),
  * W [N, K], W8 = DEVICE scratch of the size of W (the e4m3 twin), scratch = DEVICE bytes, lr_op_lo8_scratch_bytes(M, K) of them
- * (block scales of A's residuals: one E8M0 byte per row and 128 columns, K / 128 planes of 256 * ceil(M / 256) bytes in the
- * consuming kernel's lane order; then one int32 per row for flag 8), wexp = HOST int (in/out).
+ * (block scales of A's residuals: one E8M0 byte per row and 128 columns, one KB per 4 K-tiles and 256-row tile in the consuming
+ * kernel's lane order, csrc/common.h lo8_scale_at; then one int32 per row for flag 8), wexp = HOST int (in/out).
  * flags: 1 = prepare W8 from W and store its exponent in *wexp (synchronous), 2 = re-encode the residual half of A in place
  * (e4m3 bytes + the block scales), 4 = stop there (no GEMM), 8 = W is NOT exact in the operand type: on entry W8 holds
  * its 16-bit residuals (W's layout); a third segment A_hi(e4m3) x e4m3(W_lo)^T is added (one exponent per row; wexp: int [2]),
