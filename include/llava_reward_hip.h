@@ -34,14 +34,18 @@
 extern "C" {
 #endif
 
-#define LR_ABI_VERSION 6
+#define LR_ABI_VERSION 7
 
 enum { LR_OK = 0, LR_EINVAL = 1, LR_EHIP = 2, LR_ESTATE = 3, LR_ENOTFOUND = 4, LR_ENOMEM = 5 };
 enum { LR_DT_BF16 = 0, LR_DT_F16 = 1, LR_DT_F32 = 2 };
 /* lr_forward flags */
 enum { LR_FWD_TRAINING_LAST_TOKEN = 1,     /* self.training reward selection (rw_model:410-415,429-434) */
-       LR_FWD_NO_FINAL_NORM = 2 };         /* with lr_set_layer_limits(-1, k), k < layers: hidden_states[k] = the residual stream
+       LR_FWD_NO_FINAL_NORM = 2,           /* with lr_set_layer_limits(-1, k), k < layers: hidden_states[k] = the residual stream
                                               entering layer k, which the reference takes when layer_id != 32 (rw_model:349-352) */
+       LR_FWD_KEEP_HIDDEN_STATES = 4 };    /* keep every token's residual stream through the LAST decoder layer.  Without it that layer
+                                              runs its attention, o_proj and MLP only for the one row per sample the reward is read from
+                                              (rw_model:408-421; same arithmetic, bit-identical rewards, ~1/33 of the decoder's work less);
+                                              lr_last_hidden_state and the "x" tap need a forward that carried this flag */
 
 #define LR_MAX_HALF_HEAD 64
 #define LR_MAX_PINPOINTS 8
@@ -129,7 +133,12 @@ int lr_upload_weight(lr_handle h, const char* name, const void* data, const int6
  * integer hash, generated directly in HBM).  Used by bench.py and the full-size parity test. */
 int lr_synth_weights(lr_handle h, uint64_t seed);
 /* The same with flags: 1 = do NOT round the synthetic values to bf16, i.e. fp32-valued weights that are inexact in the operand
- * type, as the merged LoRA weights of a real LLaVA-Reward checkpoint are (bench.py --merged-weights). */
+ * type, as the merged LoRA weights of a real LLaVA-Reward checkpoint are (bench.py --merged-weights);
+ * 2 = outlier profile (llava_reward_amd.synth.PROFILE_OUTLIER: three massive residual-stream channels -- embedding columns and
+ * decoder down_proj rows x 200 --, norm gains of 2..30 on ~1.6 % of the channels, one 50-sigma element and four elements below
+ * f16's normal range per matrix: what trained checkpoints show and N(0, 0.02) init does not);
+ * 4 = every matrix rounded to the OCP e4m3 grid under one power-of-two scale per tensor (the de-quantised weights of an
+ * fp8-weight checkpoint, BASELINE configs[4]). */
 int lr_synth_weights_ex(lr_handle h, uint64_t seed, int flags);
 /* Number of expected weight tensors / name of the i-th one (for loaders and tests). */
 int lr_num_weights(lr_handle h);
@@ -171,6 +180,12 @@ int lr_last_hidden_state(lr_handle h, float* out_dev, size_t capacity, int no_fi
 int lr_read_tap(lr_handle h, const char* name, float* host_out, size_t capacity, size_t* n);
 /* Stop after `n_clip_layers` / `n_layers` (-1 = all); for stage-wise parity tests. */
 int lr_set_layer_limits(lr_handle h, int n_clip_layers, int n_layers);
+/* Operand form per stage (default: lr_model_desc.precise everywhere).  Forms: -1 = the descriptor's, 0 = single-pass operands,
+ * 1 = split operands with 16-bit residual passes, 2 = split operands with e4m3 residual passes; a stage can only take a split form
+ * the handle was created with.  clip_form: the vision tower (CLIP; the Qwen ViT ignores it).  Decoder layers
+ * [decoder_first, layers - decoder_last) take decoder_mid_form, the first / last ones the descriptor's.  A measurement knob
+ * (tools/prec_map_probe.py): the product default is the descriptor's form in every stage. */
+int lr_set_precision_map(lr_handle h, int clip_form, int decoder_mid_form, int decoder_first, int decoder_last);
 /* GEMM tile selection: -1 heuristic, 0 = 128x128, 1 = 256x128, 2 = 256x256. */
 int lr_set_gemm_tile(lr_handle h, int tile);
 

@@ -88,11 +88,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lc = lane & 31, lh = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
-    int S = p.S, qt;
+    int S = p.S, qt, qsel = -1;
     size_t rowbase;
     if (!CAUSAL && p.items) {                      // ragged mode: one segment per workgroup
         const int4 it = p.items[blockIdx.x];
         rowbase = (size_t)it.x; S = it.y; qt = it.z;
+    } else if (CAUSAL && p.qsel) {                 // gathered mode: the query tile that holds the wanted query of sequence b
+        qsel = __builtin_amdgcn_readfirstlane(p.qsel_last ? S - 1 : min(max(p.qsel[b * p.qsel_stride], 0), S - 1));
+        qt = qsel / (NW * 32);
+        rowbase = (size_t)b * S;
     } else {
         const int nqt = (S + NW * 32 - 1) / (NW * 32);
         qt = nqt - 1 - (int)blockIdx.x;            // heavy (late) causal tiles first
@@ -507,9 +511,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
     }
 
     // ---- epilogue: O[q][d], d = dt*32 + (r&3) + 8(r>>2) + 4h : 4 consecutive d per register quad ----
-    if (qpos < S) {
+    if (qsel >= 0 ? qpos == qsel : qpos < S) {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-        unsigned short* dst = (unsigned short*)p.O + (rowbase + qpos) * p.ldo + head * HD + 4 * lh;
+        unsigned short* dst = (unsigned short*)p.O + (qsel >= 0 ? (size_t)b : rowbase + qpos) * p.ldo + head * HD + 4 * lh;
 #pragma unroll
         for (int d = 0; d < DT; ++d)
 #pragma unroll
@@ -525,20 +529,21 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
 
 template <typename OT, int HD, bool CAUSAL>
 static void launch_one(const AttnParams& p, int batch, hipStream_t st) {
-    const int nqt = p.items ? p.n_items : (p.S + 127) / 128;
+    const int nqt = p.items ? p.n_items : p.qsel ? 1 : (p.S + 127) / 128;
+    const int nq8 = p.qsel ? 1 : (p.S + 255) / 256;        // gathered mode: one query tile per (sequence, head)
     // Long sequences: 256-query workgroups on the ping-pong schedule (measured at B=32: HD 128 1.47x, where the 4-wave form
     // fits one workgroup per CU; HD 96 1.03-1.07x; split operands 1.01-1.03x; below ~1k keys the 128-query grid fills better).
     if (p.lo_off == 0 && !p.items && p.S >= 1024) {
-        hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, false, 8, true>), dim3((p.S + 255) / 256, p.heads, batch), dim3(512), 0, st, p);
+        hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, false, 8, true>), dim3(nq8, p.heads, batch), dim3(512), 0, st, p);
     } else if (p.lo_off > 0 && !p.items && p.S >= 1024 && HD != 128) {
         if constexpr (HD != 128)
-            hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true, 8, true>), dim3((p.S + 255) / 256, p.heads, batch), dim3(512), 0, st, p);
+            hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true, 8, true>), dim3(nq8, p.heads, batch), dim3(512), 0, st, p);
     } else if (p.lo_off > 0 && !p.items && HD == 64 && p.S > 128) {
         // head_dim 64 (CLIP, 577 tokens): a 2-slot ring lets two 4-wave workgroups share a CU, and 128-query workgroups waste 10 % of
         // their query slots on 577 tokens where 256-query ones waste 25 %: 4.23 -> 3.53 ms at 544 x 577 x 16 heads, bit-identical
         hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true, 4>), dim3(nqt, p.heads, batch), dim3(256), 0, st, p);
     } else if (p.lo_off > 0 && !p.items && p.S > 128) {      // split-operand mode: 8 waves per workgroup (the ring fills the LDS)
-        hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true, 8>), dim3((p.S + 255) / 256, p.heads, batch), dim3(512), 0, st, p);
+        hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true, 8>), dim3(nq8, p.heads, batch), dim3(512), 0, st, p);
     } else if (p.lo_off > 0) {
         hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true, 4>), dim3(nqt, p.heads, batch), dim3(256), 0, st, p);
     } else {
@@ -552,6 +557,7 @@ void launch_attention(const AttnParams& p, int batch, int head_dim, bool causal,
         throw std::runtime_error("attention: operand rows must be 16-byte aligned");
     if (p.lo_off < 0 || p.lo_off % 8 || p.o_split < 0 || p.o_split % 4) throw std::runtime_error("attention: bad split-operand offsets");
     if (p.items && (causal || p.mask || batch != 1 || p.n_items < 1)) throw std::runtime_error("attention: ragged mode is dense, unmasked, batch 1");
+    if (p.qsel && (!causal || p.items)) throw std::runtime_error("attention: gathered mode is causal and batched");
     if (p.S > ATT_MAX_S) throw std::runtime_error("attention: sequence length above 8192 is not supported");
     if (p.kv_group < 1 || p.heads % p.kv_group) throw std::runtime_error("attention: heads must be a multiple of kv_group");
     const bool f16 = operand_dtype == DT_F16;

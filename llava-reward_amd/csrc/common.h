@@ -191,6 +191,9 @@ struct GemmParams {
     // persistent launches: tile scheduler words (launch8), 8 per-XCD claim counters + 1 count of finished workgroups, all zero
     // between launches; null = every workgroup walks a fixed list of tiles
     int* sched;
+    // ---- caller-provided storage for `sched`: 16 ints of DEVICE memory on the launch device, zero, used by one launch at a time
+    // (an engine passes its own; null = the launcher keeps one set per (device, stream)) ----
+    int* sched_mem;
 };
 
 struct AttnParams {
@@ -214,6 +217,11 @@ struct AttnParams {
     // split-operand mode: lo_off > 0 = Q/K/V rows carry their rounding residuals lo_off columns to the right and the
     // kernel evaluates hi.hi + hi.lo + lo.hi for both contractions; o_split > 0 = O is stored as [O_hi | O_lo]
     int lo_off, o_split;
+    // gathered mode (causal, batched): ONE query per sequence -- position qsel_last ? S - 1 : qsel[b * qsel_stride] -- is wanted
+    // (the row the reward is read from, rw_model:420-421, in the last decoder layer).  One workgroup per (sequence, head) runs the
+    // query tile that holds it, with the arithmetic of the full launch (bit-identical), and stores that query's row to O[b].
+    const int* qsel;
+    int qsel_stride, qsel_last;
 };
 
 }  // namespace lr

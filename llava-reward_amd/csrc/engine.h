@@ -158,6 +158,14 @@ struct lr_engine {
     hipEvent_t tab_ev[NSLOT] = {}; bool tab_used[NSLOT] = {};
     // last forward geometry (for taps)
     int lastB = 0, lastS = 0, lastNC = 0, lastSV = 0;
+    bool last_pruned = false;                        // the last forward ran its final decoder layer for the gathered rows only (x is stale there)
+    // last decoder layer, gathered rows only (run_decoder_stack): compact [max_batch (+ pad), ...] twins of x / h / att / ff
+    float* xg = nullptr; void *hg = nullptr, *attg = nullptr, *ffg = nullptr;
+    int* sched_mem = nullptr;                        // tile-scheduler words of this engine's persistent GEMM launches (GemmParams::sched_mem)
+    // precision map (lr_set_precision_map): operand form per stage, -1 = the descriptor's.  0 single pass, 1 split (16-bit residuals),
+    // 2 split with e4m3 residual passes.  Decoder layers [pm_first, layers - pm_last) take pm_mid, the others the descriptor's form.
+    int prec0 = 0, lo8_0 = 0, pm_clip = -1, pm_mid = -1, pm_first = 0, pm_last = 0;
+    void set_form(int m) { if (m < 0) { prec = prec0; lo8 = lo8_0; } else { prec = m ? 1 : 0; lo8 = m == 2 ? 1 : 0; } pre_enc = nullptr; }
 
     void* dalloc(size_t bytes, bool weight) {
         void* p = nullptr;
@@ -466,11 +474,13 @@ inline void mark_lo8_out(lr_engine* e, const GemmParams& p) {
 // kernel, in the same operand form as the main GEMM -- they read the same rows of x), then the main GEMM with the K-extension.
 // next_W / next_N: the weight of the GEMM that reads this one's output as its operand (lo8_out_target), or null.
 inline void gemm_p(lr_engine* e, hipStream_t st, GemmParams p, const Lora* L = nullptr, const void* next_W = nullptr, int next_N = 0) {
+    p.sched_mem = e->sched_mem;
     if (L && L->k2 > 0) {
         if (e->w8a8) throw std::logic_error("W8A8 mode runs merged weights only (no un-merged adapters)");
         GemmParams probe = p;
         apply_prec_base(e, probe);
         GemmParams t{p.A, L->A, e->lt, nullptr, p.M, L->k2, p.K, p.lda, p.K, L->k2, EPI_OUT_OP, ACT_NONE, nullptr, 0, 0};
+        t.sched_mem = e->sched_mem;
         apply_prec_base(e, t);
         const bool both8 = lo8_eligible(e, probe) && lo8_eligible(e, t);
         if (e->pre_enc == p.A && !both8) throw std::logic_error("operand pre-encoded in e4m3 for a GEMM that takes the 16-bit form");
@@ -516,8 +526,12 @@ inline void register_lora(lr_engine* e, Lora& L, const std::string& mod, int N_f
 }
 
 
-// engine.hip: pre-norm decoder stack shared by the three backbones (x, cs, tstat prepared by the caller)
-void run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_mask, int B, int S);
+// engine.hip: pre-norm decoder stack shared by the three backbones (x, cs, tstat prepared by the caller).
+// gather: 0 = every row through every layer; 1 / 2 = only the row of each sequence the reward is read from is wanted afterwards
+// (1: its last valid position, tstat[4 b]; 2: position S - 1): the LAST layer then runs its attention, o_proj and MLP for those B
+// rows only (rw_model:408-421 reads one row per sample) and leaves them in h->xg [B, hidden]; returns true when it did.
+bool run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_mask, int B, int S, int gather = 0);
+void alloc_gather_ws(lr_engine* h);
 // engine.hip: rw_model:398-406 -- SkipCA for every token (o: per-token term, u: per-sample term, either may be null), masked mean
 // pooling into h->hL, value head.  Vb / voff: image rows of every sample in h->ev (host), Vmax = their maximum.
 void run_mean_pool_head(lr_engine* h, hipStream_t st, const int64_t* attention_mask, int B, int S, const int* voff_host, int Vmax,

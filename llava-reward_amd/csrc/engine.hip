@@ -183,14 +183,25 @@ void validate_desc(const lr_model_desc& d) {
 
 // Pre-norm decoder stack: modeling_phi3_v.py:1144-1205 | modeling_mistral.py MistralDecoderLayer | modeling_qwen2_5_vl.py
 // Qwen2_5_VLDecoderLayer (q/k/v bias).  RoPE comes from the per-token (cos, sin) table h->cs.
-void run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_mask, int B, int S) {
+void alloc_gather_ws(lr_engine* h) {
+    const lr_model_desc& d = h->d;
+    const size_t R = (size_t)d.max_batch + 256, ob = 2 * (size_t)(1 + h->prec);
+    h->xg = (float*)h->dalloc(R * d.hidden * 4, false);
+    h->hg = h->dalloc(R * d.hidden * ob, false);
+    h->attg = h->dalloc(R * h->Hq * ob, false);
+    h->ffg = h->dalloc(R * d.intermediate * ob, false);
+}
+
+bool run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_mask, int B, int S, int gather) {
     const lr_model_desc& d = h->d;
     const int D = d.hidden, I = d.intermediate, Rl = B * S;
     const int nl = h->lim_layers >= 0 && h->lim_layers < d.layers ? h->lim_layers : d.layers;
     const float ascale = 1.0f / std::sqrt((float)h->hd);
     const int Hq = h->Hq, Hkv = h->Hkv, Nqkv = h->Nqkv;
+    bool pruned = false;
     for (int l = 0; l < nl; ++l) {
         const DecLayer& L = h->dl[l];
+        h->set_form((h->pm_mid >= 0 && l >= h->pm_first && l < nl - h->pm_last) ? h->pm_mid : -1);
         {   // qkv projection with RoPE on q,k: fused in the GEMM epilogue when the deep-pipelined kernel runs
             GemmParams gp{h->h, L.qkv_w, h->qkv, L.qkv_b, Rl, Nqkv, D, D, D, Nqkv, EPI_ROPE_OP, ACT_NONE, h->cs, Hq + Hkv, h->hd};
             const bool tiles_ok = (Hq + Hkv) % 256 == 0;
@@ -208,6 +219,24 @@ void run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_ma
         }
         AttnParams ap{h->qkv, h->qkv, h->qkv, h->att, attention_mask, h->tstat + 1, 4, Nqkv, Hq, 0, Hq, Hq + Hkv, S, d.heads, ascale,
                       d.heads / d.kv_heads};
+        if (gather && l == nl - 1) {
+            // Last layer: every row still feeds K and V, but only one row per sequence is read afterwards (rw_model:408-421).  Its
+            // query sits in the qkv rows as usual; the attention kernel runs the one query tile that holds it (same arithmetic as
+            // in the full launch) and stores B rows; the residual rows are gathered and o_proj / norm / MLP run on M = B rows --
+            // the GEMM kernels never look at M when they pick their form, so these rows come out bit-identical to a full layer.
+            ap.O = h->attg;
+            ap.qsel = h->tstat; ap.qsel_stride = 4; ap.qsel_last = gather == 2 ? 1 : 0;
+            apply_prec(h, ap);
+            launch_attention(ap, B, h->hd, true, h->op_dt, st);
+            launch_gather_norm_rows(h->x, h->tstat, S, gather == 2 ? 1 : 0, nullptr, 0.f, h->xg, B, D, st);      // (no weight: a plain row gather)
+            gemm(h, st, h->attg, L.o_w, h->xg, nullptr, B, D, Hq, Hq, Hq, D, EPI_RESADD_F32, ACT_NONE, &L.lo);
+            launch_norm_rows(h->xg, L.ln2, nullptr, h->hg, B, D, d.rms_eps, h->op_dt, st, h->prec, 1,
+                             lo8_norm_target(h, GemmParams{h->hg, L.gu_w, h->ffg, nullptr, B, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE, nullptr, 0, 0}));
+            gemm(h, st, h->hg, L.gu_w, h->ffg, nullptr, B, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE, &L.lgu, L.down_w, D);
+            gemm(h, st, h->ffg, L.down_w, h->xg, nullptr, B, D, I, I, I, D, EPI_RESADD_F32, ACT_NONE, &L.ldown);
+            pruned = true;
+            break;
+        }
         apply_prec(h, ap);
         launch_attention(ap, B, h->hd, true, h->op_dt, st);
         gemm(h, st, h->att, L.o_w, h->x, nullptr, Rl, D, Hq, Hq, Hq, D, EPI_RESADD_F32, ACT_NONE, &L.lo);
@@ -216,6 +245,8 @@ void run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_ma
         gemm(h, st, h->h, L.gu_w, h->ff, nullptr, Rl, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE, &L.lgu, L.down_w, D);      // ff is down's operand
         gemm(h, st, h->ff, L.down_w, h->x, nullptr, Rl, D, I, I, I, D, EPI_RESADD_F32, ACT_NONE, &L.ldown);
     }
+    h->set_form(-1);
+    return pruned;
 }
 
 void alloc_mean_pool(lr_engine* h, size_t rows, size_t vcap) {
@@ -275,8 +306,9 @@ int lr_create(const lr_model_desc* desc, int device, lr_handle* out) {
         e->d = *desc;
         e->device = device;
         e->op_dt = desc->operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16;
-        e->prec = desc->precise ? 1 : 0;
-        e->lo8 = desc->precise == 2 ? 1 : 0;
+        e->prec = e->prec0 = desc->precise ? 1 : 0;
+        e->lo8 = e->lo8_0 = desc->precise == 2 ? 1 : 0;
+        e->sched_mem = (int*)e->dalloc(64, true);
         e->w8a8 = desc->w8a8 ? 1 : 0;
         e->llava = desc->backbone == LR_BACKBONE_LLAVA_NEXT;
         e->qwen = desc->backbone == LR_BACKBONE_QWEN2_5_VL;
@@ -393,7 +425,12 @@ int lr_synth_weights_ex(lr_handle h, uint64_t seed, int flags) {
         for (Slot& s : h->slots) {
             const size_t n = (size_t)s.rows * s.cols;
             ensure_stage(h, 0, n);
-            launch_synth_fill(h->stage_f32, n, tensor_seed(seed, s.name.c_str()), uniform_scale(s.std_), (float)s.offset, (flags & 1) ? 0 : 1, 0);
+            const uint64_t ts = tensor_seed(seed, s.name.c_str());
+            if (flags & 6) {        // weight profiles (outliers / e4m3-valued): applied to the un-rounded fill, then rounded
+                launch_synth_fill(h->stage_f32, n, ts, uniform_scale(s.std_), (float)s.offset, 0, 0);
+                launch_synth_profile(h->stage_f32, s.rows, s.cols, seed, ts, s.name.c_str(), s.std_, s.offset, flags, 0);
+            } else
+                launch_synth_fill(h->stage_f32, n, ts, uniform_scale(s.std_), (float)s.offset, (flags & 1) ? 0 : 1, 0);
             pack_slot(h, s, h->stage_f32);
         }
         h->w8exp.clear(); h->w8exp2.clear(); h->w8.clear();
@@ -439,6 +476,7 @@ int lr_finalize(lr_handle h) {
         h->hL = (float*)W(B * D * 4); h->tq = (float*)W(B * D * 4); h->tkq = (float*)W(B * D * 4);
         h->tsc = (float*)W(B * (size_t)h->Vcap * 4); h->tctx = (float*)W(B * D * 4); h->tao = (float*)W(B * D * 4);
         if (d.mean_hidden_state) alloc_mean_pool(h, Rl, (size_t)h->Vcap);
+        alloc_gather_ws(h);
         // tables: crop_src[NC] | per-sample geometry [B] (HdSample or LlavaSample) | voff[B+1]
         h->tab_bytes = ((NC * 4 + B * sizeof(LlavaSample) + (B + 1) * 4) + 255) & ~(size_t)255;
         LR_HIP_CHECK(hipHostMalloc((void**)&h->tab_host, h->tab_bytes * lr_engine::NSLOT));
@@ -472,6 +510,16 @@ int lr_set_layer_limits(lr_handle h, int n_clip_layers, int n_layers) {
     if (!h) return LR_EINVAL;
     h->lim_clip = n_clip_layers; h->lim_layers = n_layers;
     return LR_OK;
+}
+int lr_set_precision_map(lr_handle h, int clip_form, int decoder_mid_form, int decoder_first, int decoder_last) {
+    if (!h) return LR_EINVAL;
+    return guarded(h, [&] {
+        auto ok = [&](int m) { return m >= -1 && m <= 2 && (m <= 0 || (h->prec0 && h->op_dt == DT_F16) || (m == 1 && h->prec0)) && (m != 2 || h->lo8_0); };
+        if (!ok(clip_form) || !ok(decoder_mid_form) || decoder_first < 0 || decoder_last < 0)
+            throw std::invalid_argument("lr_set_precision_map: a stage can take form 0, or a split form the handle was created with "
+                                        "(precise >= 1 for form 1, precise == 2 for form 2)");
+        h->pm_clip = clip_form; h->pm_mid = decoder_mid_form; h->pm_first = decoder_first; h->pm_last = decoder_last;
+    });
 }
 int lr_set_gemm_tile(lr_handle h, int tile) {
     if (!h || tile < -1 || tile > 15) return LR_EINVAL;
@@ -560,6 +608,7 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
 
         // ---- CLIP tower (utils/utils.py:266-273) ----
         const int Rp = NC * (T - 1), Rc = NC * T;
+        h->set_form(h->pm_clip);
         launch_im2col(pixel_values, pix_dtype == LR_DT_F32 ? DT_F32 : DT_BF16, d_crop_src, NC, img, d.clip_patch, h->Kpad, h->patchA, h->op_dt, st, h->prec);
         gemm(h, st, h->patchA, h->patch_w, h->patch_out, nullptr, Rp, Hc, h->Kpad, h->Kpad, h->Kpad, Hc, EPI_OUT_F32, ACT_NONE);
         launch_clip_embed(h->patch_out, h->cls, h->pos, h->pre_w, h->pre_b, h->clip_x, NC, T, Hc, d.clip_ln_eps, st);
@@ -578,6 +627,7 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
             gemm(h, st, h->clip_h, c.fc1_w, h->clip_ff, c.fc1_b, Rc, Mc, Hc, Hc, Hc, Mc, EPI_OUT_OP, ACT_QUICK_GELU, nullptr, c.fc2_w, Hc);
             gemm(h, st, h->clip_ff, c.fc2_w, h->clip_x, c.fc2_b, Rc, Hc, Mc, Mc, Mc, Hc, EPI_RESADD_F32, ACT_NONE);
         }
+        h->set_form(-1);
         if (h->llava) {
             // ---- per-token projector, then anyres packing (modeling_llava_next.py get_image_features/pack_image_features) ----
             launch_clip_tokens(h->clip_x, h->hdA, NC, T, Hc, h->op_dt, st, h->prec);
@@ -596,7 +646,9 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
                           h->llava ? (long)d.image_token_id : -1L, h->llava ? 1 : 0);
         launch_embed(input_ids, h->img_row, h->wte, h->ev, h->x, Rl, D, d.vocab_size, st);
         launch_rope_table(h->pos_ids, h->tstat, B, S, h->inv_s, h->inv_l, d.rope_scaling, d.orig_max_pos, h->half, h->cs, st);
-        run_decoder_stack(h, st, attention_mask, B, S);
+        const int last_pos = (flags & LR_FWD_TRAINING_LAST_TOKEN) ? 1 : 0;
+        const int gather = (d.mean_hidden_state || (flags & LR_FWD_KEEP_HIDDEN_STATES)) ? 0 : 1 + last_pos;
+        h->last_pruned = run_decoder_stack(h, st, attention_mask, B, S, gather);
         if (d.mean_hidden_state) {      // rw_model:398-406: SkipCA + norm on every token, masked mean, value head
             run_mean_pool_head(h, st, attention_mask, B, S, voff, Vmax, nullptr, !(flags & LR_FWD_NO_FINAL_NORM), rewards_out);
             launch_slot_check(h->tstat, d_voff, rewards_out, B, d.value_head_dim, st);
@@ -604,7 +656,8 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
             return;
         }
         // ---- tail: final norm of the gathered row, SkipCA, value head (rw_model:376-448) ----
-        launch_gather_norm_rows(h->x, h->tstat, S, (flags & LR_FWD_TRAINING_LAST_TOKEN) ? 1 : 0,
+        // (after a gathered last layer the B rows are already compact in xg: S = 1, position 0)
+        launch_gather_norm_rows(h->last_pruned ? h->xg : h->x, h->tstat, h->last_pruned ? 1 : S, h->last_pruned ? 1 : last_pos,
                                 (flags & LR_FWD_NO_FINAL_NORM) ? nullptr : h->norm_w, d.rms_eps, h->hL, B, D, st);
         const float* ao = nullptr;
         if (d.add_cross_attention) {
@@ -626,6 +679,8 @@ int lr_last_hidden_state(lr_handle h, float* out_dev, size_t capacity, int no_fi
     if (!h || !out_dev) return LR_EINVAL;
     return guarded(h, [&] {
         if (!h->finalized || h->lastB <= 0) throw std::logic_error("lr_last_hidden_state: no forward has run on this handle");
+        if (h->last_pruned) throw std::logic_error("lr_last_hidden_state: the last forward ran its final decoder layer for the reward rows only; "
+                                                   "pass LR_FWD_KEEP_HIDDEN_STATES to the forward whose hidden states are wanted");
         const size_t rows = (size_t)h->lastB * h->lastS, D = (size_t)h->d.hidden;
         if (capacity < rows * D) throw std::invalid_argument("lr_last_hidden_state: buffer too small");
         hipStream_t st = (hipStream_t)hip_stream;
@@ -654,7 +709,11 @@ int lr_read_tap(lr_handle h, const char* name, float* host_out, size_t capacity,
             return;
         }
         else if (nm == "ev") { src = h->ev; cnt = (size_t)h->lastSV * h->d.hidden; }
-        else if (nm == "x") { src = h->x; cnt = (size_t)h->lastB * h->lastS * h->d.hidden; }
+        else if (nm == "x") {
+            if (h->last_pruned) throw std::logic_error("lr_read_tap(x): the last forward ran its final decoder layer for the reward rows only; "
+                                                       "pass LR_FWD_KEEP_HIDDEN_STATES to the forward whose residual stream is wanted");
+            src = h->x; cnt = (size_t)h->lastB * h->lastS * h->d.hidden;
+        }
         else if (nm == "hL") { src = h->hL; cnt = (size_t)h->lastB * h->d.hidden; }
         else throw std::invalid_argument("lr_read_tap: unknown tap");
         if (cnt > capacity) throw std::invalid_argument("lr_read_tap: buffer too small");

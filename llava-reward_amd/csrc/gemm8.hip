@@ -28,6 +28,7 @@
 //
 // Column mapping inside a block tile: wave wc owns columns wc*64 + qb*32 + [0,32) for qb = 0,1, so the
 // SwiGLU pair (gate block, up block: weight rows interleaved in 32s) stays in one lane/register.
+#include <map>
 #include <mutex>
 #include <type_traits>
 #include <unordered_map>
@@ -908,18 +909,21 @@ static int num_cus() {
     return n;
 }
 
-// The tile scheduler's words of a stream (GemmParams::sched): launches of one stream run one after the other and each leaves its
-// words zero, so one set per stream is enough.  Allocated (and zeroed) on the stream's first persistent launch, never freed.
+// The tile scheduler's words (GemmParams::sched) for callers that bring none (GemmParams::sched_mem: the lr_op_* entry points;
+// an engine owns its words): one set per (device, stream) -- launches of one stream run one after the other and each leaves its
+// words zero -- allocated and zeroed on that stream's first persistent launch, never freed.  Not for use under stream capture.
 static int* sched_words(hipStream_t st) {
     static std::mutex mu;
-    static std::unordered_map<hipStream_t, int*> words;
+    static std::map<std::pair<int, hipStream_t>, int*> words;
+    int dev = 0;
+    LR_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
-    auto it = words.find(st);
+    auto it = words.find({dev, st});
     if (it != words.end()) return it->second;
     int* w = nullptr;
     LR_HIP_CHECK(hipMalloc((void**)&w, 64));
     LR_HIP_CHECK(hipMemset(w, 0, 64));
-    words[st] = w;
+    words[{dev, st}] = w;
     return w;
 }
 
@@ -938,7 +942,7 @@ static void launch8(const GemmParams& p, bool persistent, hipStream_t st) {
     const int grid = persistent ? std::min(Mt * Nt, num_cus()) : Mt * Nt;
     GemmParams q = p;
     static const bool dynamic = [] { const char* e = getenv("LR_GEMM_DYNAMIC"); return !e || atoi(e) != 0; }();
-    q.sched = (persistent && PB == 2 && DBG != 2 && dynamic && grid % 8 == 0 && Mt * Nt >= 4 * grid) ? sched_words(st) : nullptr;
+    q.sched = (persistent && PB == 2 && DBG != 2 && dynamic && grid % 8 == 0 && Mt * Nt >= 4 * grid) ? (p.sched_mem ? p.sched_mem : sched_words(st)) : nullptr;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), smem, st, q);
 }
 

@@ -106,6 +106,9 @@ void launch_ca_pool(const float* h, const float* o, const float* u, const float*
 
 // weights ---------------------------------------------------------------------------------------
 void launch_synth_fill(float* out, size_t n, uint64_t tseed, float scale, float offset, int bf16_round, hipStream_t st);
+// flags as lr_synth_weights_ex: 1 = no bf16 rounding, 2 = outlier profile, 4 = e4m3-valued matrices; `out` holds the UN-ROUNDED fill
+void launch_synth_profile(float* out, int rows, int cols, uint64_t base_seed, uint64_t tseed, const char* name, double std_, double offset,
+                          int flags, hipStream_t st);
 enum : int { PACK_PLAIN = 0, PACK_SWIGLU = 1, PACK_TRANSPOSE = 2, PACK_ROPE_QKV = 3, PACK_SWIGLU_GATE = 4, PACK_SWIGLU_UP = 5,
              PACK_HEADPAD_COLS = 6 };
 // dst[f(r)][c] (ld_dst elements, zero-padded columns up to cols_dst) = convert(src[r][c])

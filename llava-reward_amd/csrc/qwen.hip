@@ -191,6 +191,7 @@ void finalize_qwen(lr_engine* h) {
     h->tstat = (int*)W(B * 16); h->rstat = (int*)W(B * 16);
     h->hL = (float*)W(B * D * 4); h->tao = (float*)W(B * D * 4);
     if (d.mean_hidden_state) alloc_mean_pool(h, Rl, 0);
+    alloc_gather_ws(h);
     h->tab_bytes = qwen_table_layout(d).total;
     LR_HIP_CHECK(hipHostMalloc((void**)&h->tab_host, h->tab_bytes * lr_engine::NSLOT));
     h->tab_dev = (char*)W(h->tab_bytes * lr_engine::NSLOT);
@@ -367,7 +368,8 @@ extern "C" int lr_forward_qwen(lr_handle h, const int64_t* input_ids, const int6
                          h->rstat, h->pos3, h->img_row, st);
         launch_embed(input_ids, h->img_row, h->wte, h->ev, h->x, Rl, D, d.vocab_size, st);
         launch_mrope_table(h->pos3, Rl, h->inv_s, d.mrope_section[0], d.mrope_section[1], h->half, h->cs, st);
-        run_decoder_stack(h, st, attention_mask, B, S);
+        const int last_pos = (flags & LR_FWD_TRAINING_LAST_TOKEN) ? 1 : 0;
+        h->last_pruned = run_decoder_stack(h, st, attention_mask, B, S, (d.mean_hidden_state || (flags & LR_FWD_KEEP_HIDDEN_STATES)) ? 0 : 1 + last_pos);
         if (d.mean_hidden_state) {      // rw_model:398-406; the as-written SkipCA adds the same vector to every token of a row
             if (d.add_cross_attention) launch_qwen_ca_vec(h->rstat, h->ca_u, B, D, h->tao, st);
             run_mean_pool_head(h, st, attention_mask, B, S, nullptr, 0, h->tao, true, rewards_out);
@@ -375,7 +377,8 @@ extern "C" int lr_forward_qwen(lr_handle h, const int64_t* input_ids, const int6
             return;
         }
         // ---- tail: final norm of the gathered row (hidden_states[-1]), as-written SkipCA, value head (rw_model:387-448) ----
-        launch_gather_norm_rows(h->x, h->tstat, S, (flags & LR_FWD_TRAINING_LAST_TOKEN) ? 1 : 0, h->norm_w, d.rms_eps, h->hL, B, D, st);
+        launch_gather_norm_rows(h->last_pruned ? h->xg : h->x, h->tstat, h->last_pruned ? 1 : S, h->last_pruned ? 1 : last_pos, h->norm_w, d.rms_eps,
+                                h->hL, B, D, st);
         const float* ao = nullptr;
         if (d.add_cross_attention) {
             launch_qwen_ca_vec(h->rstat, h->ca_u, B, D, h->tao, st);

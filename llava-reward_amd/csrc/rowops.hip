@@ -869,6 +869,92 @@ void launch_synth_fill(float* out, size_t n, uint64_t tseed, float scale, float 
     hipLaunchKernelGGL(synth_fill_kernel, dim3(grid), dim3(256), 0, st, out, n, tseed, scale, offset, offset != 0.f ? 1 : 0, bf16_round);
 }
 
+// Weight profiles of llava_reward_amd.synth (PROFILE_OUTLIER / PROFILE_E4M3), applied in place to the un-rounded values of
+// synth_fill_kernel; bit-identical to synth._apply_outlier / synth.round_to_e4m3_np.
+struct SynthProfile {
+    int outlier, e4m3, bf16_round;
+    int gain_vector;               // offset != 0: norm gain vectors take the gain rule, nothing else
+    int matrix;                    // rows > 1 && cols > 1 && std > 0
+    uint64_t tseed;
+    int chan_axis;                 // 0 rows / 1 cols / -1
+    int chan[3];
+    size_t tiny[4], spike;
+    float spike_val;
+    int e4m3_exp;
+    int cols;
+};
+__global__ __launch_bounds__(256) void synth_profile_kernel(float* __restrict__ out, size_t n, SynthProfile p) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v = out[i];
+        if (p.outlier) {
+            if (p.gain_vector) {
+                const uint64_t h = splitmix64((p.tseed ^ 0xA5A5A5A55A5A5A5Aull) + i);
+                if ((h & 63) == 0) v = __fmul_rn(v, (float)(2 + (int)((h >> 8) % 29)));
+            } else if (p.matrix) {
+                if (p.chan_axis >= 0) {
+                    const int c = p.chan_axis == 1 ? (int)(i % (size_t)p.cols) : (int)(i / (size_t)p.cols);
+                    if (c == p.chan[0] || c == p.chan[1] || c == p.chan[2]) v = __fmul_rn(v, 200.f);
+                }
+                if (i == p.tiny[0] || i == p.tiny[1] || i == p.tiny[2] || i == p.tiny[3]) v = __fmul_rn(v, 0x1p-12f);
+                if (i == p.spike) v = p.spike_val;
+            }
+        }
+        if (p.e4m3 && p.matrix && !p.gain_vector) {
+            float x = fminf(fmaxf(ldexpf(v, -p.e4m3_exp), -448.f), 448.f);
+            int ex;
+            (void)frexpf(x, &ex);
+            const int qe = max(ex - 4, -9);
+            v = ldexpf(ldexpf(rintf(ldexpf(x, -qe)), qe), p.e4m3_exp);
+        }
+        if (p.bf16_round) {
+            unsigned u = __builtin_bit_cast(unsigned, v);
+            u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+            v = __builtin_bit_cast(float, u);
+        }
+        out[i] = v;
+    }
+}
+static uint64_t splitmix64_h(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+void launch_synth_profile(float* out, int rows, int cols, uint64_t base_seed, uint64_t tseed, const char* name, double std_, double offset,
+                          int flags, hipStream_t st) {
+    const size_t n = (size_t)rows * cols;
+    if (!n) return;
+    SynthProfile p{};
+    p.outlier = (flags & 2) ? 1 : 0;
+    p.e4m3 = (flags & 4) ? 1 : 0;
+    p.bf16_round = (flags & 1) ? 0 : 1;
+    p.gain_vector = offset != 0.0;
+    p.matrix = rows > 1 && cols > 1 && std_ > 0.0;
+    p.tseed = tseed;
+    p.cols = cols;
+    const std::string nm(name);
+    auto ends_with = [&](const char* suf) { const size_t l = strlen(suf); return nm.size() >= l && nm.compare(nm.size() - l, l, suf) == 0; };
+    p.chan_axis = ends_with("embed_tokens.weight") ? 1 : (ends_with(".mlp.down_proj.weight") && nm.rfind("visual.", 0) != 0) ? 0 : -1;
+    if (p.chan_axis >= 0) {
+        const uint64_t dim = p.chan_axis == 1 ? (uint64_t)cols : (uint64_t)rows;
+        for (int j = 0; j < 3; ++j) p.chan[j] = (int)(splitmix64_h((base_seed ^ 0x5851F42D4C957F2Dull) + (uint64_t)j) % dim);
+    }
+    for (int k = 0; k < 4; ++k) p.tiny[k] = (size_t)(splitmix64_h((tseed ^ 0x0F1E2D3C4B5A6978ull) + (uint64_t)k) % n);
+    const uint64_t hs = splitmix64_h(tseed ^ 0x0123456789ABCDEFull);
+    p.spike = (size_t)(hs % n);
+    p.spike_val = ((hs >> 63) ? -1.f : 1.f) * (50.f * (float)std_);
+    if (p.e4m3) {            // smallest e with 448 * 2^e >= 2^23 * scale (synth.e4m3_tensor_exponent)
+        const float scale = (float)(std_ * std::sqrt(12.0) / 16777216.0);
+        const double bound = (double)(8388608.f * scale);
+        int ex;
+        const double m = std::frexp(bound / 448.0, &ex);
+        p.e4m3_exp = m == 0.5 ? ex - 1 : ex;
+    }
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(synth_profile_kernel, dim3(grid), dim3(256), 0, st, out, n, p);
+}
+
 __device__ __forceinline__ void store_elem(void* dst, size_t i, float v, int dt) {
     if (dt == DT_F32) ((float*)dst)[i] = v;
     else if (dt == DT_F16) ((unsigned short*)dst)[i] = Op<F16>::from_f32(v);

@@ -9,11 +9,12 @@ from ._build import LIB_PATH
 LR_DT_BF16, LR_DT_F16, LR_DT_F32 = 0, 1, 2
 LR_FWD_TRAINING_LAST_TOKEN = 1
 LR_FWD_NO_FINAL_NORM = 2
+LR_FWD_KEEP_HIDDEN_STATES = 4
 LR_MAX_HALF_HEAD = 64
 LR_MAX_PINPOINTS = 8
 LR_MAX_FULLATT = 8
 LR_BACKBONE_PHI3V, LR_BACKBONE_LLAVA_NEXT, LR_BACKBONE_QWEN2_5_VL = 0, 1, 2
-LR_ABI_VERSION = 6
+LR_ABI_VERSION = 7
 EPI_OUT_OP, EPI_OUT_F32, EPI_RESADD_F32, EPI_SWIGLU_OP, EPI_ROPE_OP = 0, 1, 2, 3, 4
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2
 
@@ -72,6 +73,7 @@ _SIGS = {
     "lr_last_hidden_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "lr_read_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "lr_set_layer_limits": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "lr_set_precision_map": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "lr_set_gemm_tile": (C.c_int, [C.c_void_p, C.c_int]),
     "lr_op_gemm_bt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]),
     "lr_op_gemm_bt_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),

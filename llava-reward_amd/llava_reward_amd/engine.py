@@ -151,8 +151,10 @@ class RewardEngine:
         if strict and names:
             raise KeyError(f"missing weights: {sorted(names)[:8]}{' ...' if len(names) > 8 else ''}")
 
-    def synth_weights(self, seed: int, fp32_valued: bool = False) -> None:
-        L.check(self.lib, self.lib.lr_synth_weights_ex(self.h, C.c_uint64(seed), 1 if fp32_valued else 0), self.h, "lr_synth_weights")
+    def synth_weights(self, seed: int, fp32_valued: bool = False, profile: int = 0) -> None:
+        """`profile`: synth.PROFILE_* flags (outlier-bearing / e4m3-valued weights), the same bits lr_synth_weights_ex takes."""
+        L.check(self.lib, self.lib.lr_synth_weights_ex(self.h, C.c_uint64(seed), (1 if fp32_valued else 0) | int(profile)), self.h,
+                "lr_synth_weights")
 
     def finalize(self) -> None:
         L.check(self.lib, self.lib.lr_finalize(self.h), self.h, "lr_finalize")
@@ -160,7 +162,10 @@ class RewardEngine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, pixel_values: torch.Tensor,
-                image_sizes, training: bool = False, out: Optional[torch.Tensor] = None, no_final_norm: bool = False) -> torch.Tensor:
+                image_sizes, training: bool = False, out: Optional[torch.Tensor] = None, no_final_norm: bool = False,
+                keep_hidden_states: bool = False) -> torch.Tensor:
+        """keep_hidden_states: run the last decoder layer for every token (LR_FWD_KEEP_HIDDEN_STATES) -- needed before
+        last_hidden_state() / read_tap("x"); by default that layer computes only the row each reward is read from."""
         dev = torch.device("cuda", self.device)
         ids = input_ids.to(dev, torch.int64).contiguous()
         mask = attention_mask.to(dev, torch.int64).contiguous()
@@ -178,7 +183,8 @@ class RewardEngine:
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = self.lib.lr_forward(self.h, C.c_void_p(ids.data_ptr()), C.c_void_p(mask.data_ptr()), C.c_void_p(pix.data_ptr()),
                                  pdt, C.cast(sizes.data_ptr(), C.POINTER(C.c_int64)), B, S, pix.shape[1],
-                                 (L.LR_FWD_TRAINING_LAST_TOKEN if training else 0) | (L.LR_FWD_NO_FINAL_NORM if no_final_norm else 0),
+                                 (L.LR_FWD_TRAINING_LAST_TOKEN if training else 0) | (L.LR_FWD_NO_FINAL_NORM if no_final_norm else 0)
+                                 | (L.LR_FWD_KEEP_HIDDEN_STATES if keep_hidden_states else 0),
                                  C.c_void_p(out.data_ptr()), C.c_void_p(stream))
         L.check(self.lib, rc, self.h, "lr_forward")
         # keep inputs alive until the stream has consumed them
@@ -187,7 +193,8 @@ class RewardEngine:
         return out
 
     def forward_qwen(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, pixel_values: torch.Tensor,
-                     image_grid_thw, training: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     image_grid_thw, training: bool = False, out: Optional[torch.Tensor] = None,
+                     keep_hidden_states: bool = False) -> torch.Tensor:
         """The qwen branch's inputs_batch (rw_model_general_preference.py:354-357): pixel_values [sum t*h*w, 1176]."""
         dev = torch.device("cuda", self.device)
         ids = input_ids.to(dev, torch.int64).contiguous()
@@ -208,8 +215,8 @@ class RewardEngine:
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = self.lib.lr_forward_qwen(self.h, C.c_void_p(ids.data_ptr()), C.c_void_p(mask.data_ptr()), C.c_void_p(pix.data_ptr()),
                                       pdt, C.cast(grid.data_ptr(), C.POINTER(C.c_int64)), grid.shape[0], B, S,
-                                      L.LR_FWD_TRAINING_LAST_TOKEN if training else 0, C.c_void_p(out.data_ptr()),
-                                      C.c_void_p(stream))
+                                      (L.LR_FWD_TRAINING_LAST_TOKEN if training else 0) | (L.LR_FWD_KEEP_HIDDEN_STATES if keep_hidden_states else 0),
+                                      C.c_void_p(out.data_ptr()), C.c_void_p(stream))
         L.check(self.lib, rc, self.h, "lr_forward_qwen")
         for t in (ids, mask, pix):
             t.record_stream(torch.cuda.current_stream(dev))
@@ -233,6 +240,11 @@ class RewardEngine:
 
     def set_layer_limits(self, n_clip: int = -1, n_layers: int = -1) -> None:
         self.lib.lr_set_layer_limits(self.h, n_clip, n_layers)
+
+    def set_precision_map(self, clip_form: int = -1, decoder_mid_form: int = -1, decoder_first: int = 0, decoder_last: int = 0) -> None:
+        """Operand form per stage (lr_set_precision_map): -1 the descriptor's, 0 single pass, 1 split, 2 split + e4m3 residual passes."""
+        L.check(self.lib, self.lib.lr_set_precision_map(self.h, clip_form, decoder_mid_form, decoder_first, decoder_last), self.h,
+                "lr_set_precision_map")
 
     def set_gemm_tile(self, tile: int) -> None:
         L.check(self.lib, self.lib.lr_set_gemm_tile(self.h, tile), self.h, "lr_set_gemm_tile")

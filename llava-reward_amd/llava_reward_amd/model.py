@@ -20,7 +20,7 @@ from .synth import LlavaConfig, QwenConfig, RewardConfig, llava_geometry
 class RewardModel:
     def __init__(self, cfg, weights: Optional[Dict[str, torch.Tensor]] = None, synth_seed: Optional[int] = None,
                  max_batch: int = 32, max_seq: int = 2816, max_crops: int = 17, operand_dtype: str = "f16x2f8",
-                 layer_id: int = 32, mean_hidden_state=None, max_patches: int = 0):
+                 layer_id: int = 32, mean_hidden_state=None, max_patches: int = 0, synth_profile: int = 0):
         if weights is None and synth_seed is None:
             raise ValueError("RewardModel needs weights or a synth_seed")
         # rw_model:349-352: layer_id == 32 (the literal) -> last_hidden_state, else hidden_states[layer_id] = the input of decoder
@@ -31,6 +31,7 @@ class RewardModel:
         self.model_type = "qwen" if isinstance(cfg, QwenConfig) else "llava" if isinstance(cfg, LlavaConfig) else "phi3v"
         self._weights = weights
         self._synth_seed = synth_seed
+        self._synth_profile = int(synth_profile)      # synth.PROFILE_* (outlier-bearing / e4m3-valued synthetic weights)
         self.mean_hidden_state = bool(mean_hidden_state)      # rw_model:398-406: masked mean of the (SkipCA'd) hidden states
         if self.mean_hidden_state and layer_id != 32 and layer_id < cfg.layers:
             raise NotImplementedError("mean_hidden_state together with an inner layer_id is not implemented")
@@ -38,6 +39,9 @@ class RewardModel:
                           max_patches=max_patches, mean_hidden_state=self.mean_hidden_state)
         self.layer_id = layer_id
         self.engine = None
+        # True: every forward keeps all hidden states through the last layer (read_tap("x") / last_hidden_state afterwards);
+        # custom_forward(return_output=True) does so by itself.  Default: the last layer computes the reward rows only.
+        self.keep_hidden_states = False
         self.training = False
         self.device = torch.device("cpu")
         self.is_general_preference = cfg.is_general_preference
@@ -59,7 +63,7 @@ class RewardModel:
         if self._weights is not None:
             eng.load_state_dict(self._weights, strict=True)
         else:
-            eng.synth_weights(self._synth_seed, getattr(self, "synth_fp32_valued", False))
+            eng.synth_weights(self._synth_seed, getattr(self, "synth_fp32_valued", False), self._synth_profile)
         eng.finalize()
         if self.engine is not None:
             self.engine.close()
@@ -116,7 +120,8 @@ class RewardModel:
                                    f"{expect.tolist()} (modeling_phi3_v.py:247 index_put)")
         inner = self.model_type == "phi3v" and self.layer_id != 32 and self.layer_id < self.config.layers
         self.engine.set_layer_limits(-1, self.layer_id if inner else -1)
-        reward = self.engine.forward(input_ids, attention_mask, pixel_values, sz, training=self.training, no_final_norm=inner)
+        reward = self.engine.forward(input_ids, attention_mask, pixel_values, sz, training=self.training, no_final_norm=inner,
+                                     keep_hidden_states=return_output or self.keep_hidden_states)
         return self._finish(reward, input_ids.shape, return_output, inner)
 
     def _finish(self, reward, shape, return_output, inner=False):
@@ -150,7 +155,8 @@ class RewardModel:
         n_feat = int(grid.prod(dim=1).sum()) // unit
         if n_slots != n_feat:
             raise ValueError(f"Image features and image tokens do not match, tokens: {n_slots}, features: {n_feat}")
-        reward = self.engine.forward_qwen(ids, mask, pix, grid, training=self.training)
+        reward = self.engine.forward_qwen(ids, mask, pix, grid, training=self.training,
+                                          keep_hidden_states=return_output or self.keep_hidden_states)
         return self._finish(reward, ids.shape, return_output)
 
     __call__ = custom_forward

@@ -4,7 +4,7 @@ No checkpoint and no network exist in the build container or on the GPU box, so 
 throughput are measured on seeded synthetic weights.  The generator is a
 counter-based integer hash (splitmix64) so that three implementations produce bit-identical
 tensors: this numpy one (tests, oracle, golden generation), the HIP kernel in
-``csrc/synth_weights.hip`` (full-size weights generated straight into HBM) and any future port.
+``csrc/rowops.hip`` (`synth_fill_kernel`; full-size weights generated straight into HBM) and any future port.
 
 Element i of tensor `name` under base seed s:
     t   = splitmix64(s ^ fnv1a64(name))
@@ -191,9 +191,77 @@ def _gen_chunk(t: np.uint64, s: int, e: int, scale: np.float32, offset: float, o
     out[s:e] = v
 
 
+# Weight profiles (flags shared with lr_synth_weights_ex, include/llava_reward_hip.h).  PROFILE_FP32 = values not rounded to bf16
+# (what a merged LoRA adapter leaves behind).  PROFILE_OUTLIER = the structure trained LLM checkpoints show and N(0, 0.02) init does
+# not: three massive residual-stream channels (embedding columns and decoder down_proj rows x 200), norm gains of 2..30 on ~1.6 % of
+# the channels, one element of 50 sigma and four elements below f16's normal range (x 2^-12) per matrix.  PROFILE_E4M3 = every
+# matrix rounded (RNE) to the OCP e4m3 grid under one power-of-two scale per tensor: the weights of an fp8-weight checkpoint,
+# de-quantised (BASELINE configs[4]); such values are exact in bf16 and f16.
+PROFILE_FP32, PROFILE_OUTLIER, PROFILE_E4M3 = 1, 2, 4
+PROFILE_NAMES = {"": 0, "default": 0, "fp32": PROFILE_FP32, "outlier": PROFILE_OUTLIER, "e4m3": PROFILE_E4M3}
+_C_GAIN, _C_SPIKE, _C_TINY, _C_CHAN = 0xA5A5A5A55A5A5A5A, 0x0123456789ABCDEF, 0x0F1E2D3C4B5A6978, 0x5851F42D4C957F2D
+OUTLIER_CHANNEL_SCALE, OUTLIER_SPIKE_SIGMAS, OUTLIER_N_CHANNELS, OUTLIER_N_TINY = 200.0, 50.0, 3, 4
+
+
+def outlier_channels(base_seed: int, dim: int) -> List[int]:
+    """The massive residual-stream channels of PROFILE_OUTLIER (one set per seed, shared by every tensor)."""
+    return [int(splitmix64_scalar(((base_seed ^ _C_CHAN) + j) & MASK64) % dim) for j in range(OUTLIER_N_CHANNELS)]
+
+
+def channel_axis(name: str) -> int:
+    """0 = rows, 1 = columns of the tensor index the residual stream's channels, -1 = neither (PROFILE_OUTLIER)."""
+    if name.endswith("embed_tokens.weight"):
+        return 1
+    if name.endswith(".mlp.down_proj.weight") and not name.startswith("visual."):
+        return 0
+    return -1
+
+
+def _apply_outlier(v: np.ndarray, base_seed: int, name: str, rows: int, cols: int, std: float, offset: float) -> None:
+    n = v.size
+    t = tensor_seed(base_seed, name)
+    if offset != 0.0:                                   # norm gain vectors
+        with np.errstate(over="ignore"):
+            h = _splitmix64_np(np.uint64(t ^ _C_GAIN) + np.arange(n, dtype=np.uint64))
+        sel = (h & np.uint64(63)) == np.uint64(0)
+        g = (np.uint64(2) + ((h >> np.uint64(8)) % np.uint64(29))).astype(np.float32)
+        v[sel] = v[sel] * g[sel]
+        return
+    if rows <= 1 or cols <= 1 or std <= 0.0:
+        return
+    ax = channel_axis(name)
+    if ax >= 0:
+        m = v.reshape(rows, cols)
+        for c in sorted(set(outlier_channels(base_seed, cols if ax == 1 else rows))):
+            if ax == 1:
+                m[:, c] = m[:, c] * np.float32(OUTLIER_CHANNEL_SCALE)
+            else:
+                m[c, :] = m[c, :] * np.float32(OUTLIER_CHANNEL_SCALE)
+    for i in sorted({int(splitmix64_scalar(((t ^ _C_TINY) + k) & MASK64) % n) for k in range(OUTLIER_N_TINY)}):
+        v[i] = v[i] * np.float32(2.0 ** -12)
+    hs = splitmix64_scalar(t ^ _C_SPIKE)
+    v[int(hs % n)] = np.float32(-1.0 if hs >> 63 else 1.0) * (np.float32(OUTLIER_SPIKE_SIGMAS) * np.float32(std))
+
+
+def e4m3_tensor_exponent(std: float) -> int:
+    """Smallest e with 448 * 2^e >= the largest magnitude gen_tensor can emit for `std` (2^23 * scale)."""
+    bound = float(np.float32(8388608.0) * uniform_scale(std))
+    m, ex = math.frexp(bound / 448.0)
+    return ex - 1 if m == 0.5 else ex
+
+
+def round_to_e4m3_np(v: np.ndarray, e: int) -> np.ndarray:
+    """RNE onto the OCP e4m3 grid scaled by 2^e (normals: 4 significant bits; below 2^-6: steps of 2^-9; clamp at 448)."""
+    x = np.clip(np.ldexp(v, -e), np.float32(-448.0), np.float32(448.0)).astype(np.float32)
+    _, ex = np.frexp(x)
+    qe = np.maximum(ex - 4, -9).astype(np.int32)
+    q = np.ldexp(np.rint(np.ldexp(x, -qe)), qe).astype(np.float32)
+    return np.ldexp(q, e).astype(np.float32)
+
+
 def gen_tensor(base_seed: int, name: str, shape: Tuple[int, ...], std: float, offset: float = 0.0,
-               bf16_valued: bool = True, chunk: int = 1 << 22) -> np.ndarray:
-    """Deterministic fp32 tensor; identical to csrc/synth_weights.hip for the same arguments."""
+               bf16_valued: bool = True, chunk: int = 1 << 22, profile: int = 0) -> np.ndarray:
+    """Deterministic fp32 tensor; identical to csrc/rowops.hip synth_fill_kernel (+ synth_profile_kernel) for the same arguments."""
     n = int(np.prod(shape)) if len(shape) else 1
     out = np.empty(n, dtype=np.float32)
     t = np.uint64(tensor_seed(base_seed, name))
@@ -207,7 +275,13 @@ def gen_tensor(base_seed: int, name: str, shape: Tuple[int, ...], std: float, of
     else:
         for s, e in spans:
             _gen_chunk(t, s, e, scale, offset, out)
-    if bf16_valued:
+    rows = int(shape[0]) if len(shape) > 1 else 1
+    cols = n // max(rows, 1)
+    if profile & PROFILE_OUTLIER:
+        _apply_outlier(out, base_seed, name, rows, cols, std, offset)
+    if profile & PROFILE_E4M3 and rows > 1 and cols > 1 and std > 0.0 and offset == 0.0:
+        out = round_to_e4m3_np(out, e4m3_tensor_exponent(std))
+    if bf16_valued and not (profile & PROFILE_FP32):
         out = round_to_bf16_np(out)
     return out.reshape(shape)
 
@@ -283,13 +357,13 @@ def weight_specs(cfg: RewardConfig) -> List[Tuple[str, Tuple[int, ...], float, f
     return s
 
 
-def iter_weights(cfg: RewardConfig, seed: int) -> Iterator[Tuple[str, np.ndarray]]:
+def iter_weights(cfg: RewardConfig, seed: int, profile: int = 0) -> Iterator[Tuple[str, np.ndarray]]:
     for name, shape, std, offset in weight_specs(cfg):
-        yield name, gen_tensor(seed, name, shape, std, offset)
+        yield name, gen_tensor(seed, name, shape, std, offset, profile=profile)
 
 
-def make_weights(cfg: RewardConfig, seed: int) -> Dict[str, np.ndarray]:
-    return dict(iter_weights(cfg, seed))
+def make_weights(cfg: RewardConfig, seed: int, profile: int = 0) -> Dict[str, np.ndarray]:
+    return dict(iter_weights(cfg, seed, profile))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -581,8 +655,8 @@ def llava_weight_specs(cfg: LlavaConfig) -> List[Tuple[str, Tuple[int, ...], flo
     return s
 
 
-def llava_make_weights(cfg: LlavaConfig, seed: int) -> Dict[str, np.ndarray]:
-    return {n: gen_tensor(seed, n, sh, std, off) for n, sh, std, off in llava_weight_specs(cfg)}
+def llava_make_weights(cfg: LlavaConfig, seed: int, profile: int = 0) -> Dict[str, np.ndarray]:
+    return {n: gen_tensor(seed, n, sh, std, off, profile=profile) for n, sh, std, off in llava_weight_specs(cfg)}
 
 
 def llava_synth_batch(cfg: LlavaConfig, seed: int, caption_lens: List[int], image_sizes, max_crops: int = None,
@@ -850,8 +924,8 @@ def qwen_weight_specs(cfg: QwenConfig) -> List[Tuple[str, Tuple[int, ...], float
     return s
 
 
-def qwen_make_weights(cfg: QwenConfig, seed: int) -> Dict[str, np.ndarray]:
-    return {n: gen_tensor(seed, n, sh, std, off) for n, sh, std, off in qwen_weight_specs(cfg)}
+def qwen_make_weights(cfg: QwenConfig, seed: int, profile: int = 0) -> Dict[str, np.ndarray]:
+    return {n: gen_tensor(seed, n, sh, std, off, profile=profile) for n, sh, std, off in qwen_weight_specs(cfg)}
 
 
 def qwen_synth_batch(cfg: QwenConfig, seed: int, caption_lens: List[int], grids, with_pixels: bool = True):

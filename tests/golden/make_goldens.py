@@ -54,7 +54,7 @@ def import_reference():
     return _get_reward_model, Phi3RMSNorm, Phi3VModel, Phi3VForCausalLM, Phi3VConfig
 
 
-def build_reference_model(ref, cfg: synth.RewardConfig, seed: int, layer_id: int = 32, mean_hidden_state=None):
+def build_reference_model(ref, cfg: synth.RewardConfig, seed: int, layer_id: int = 32, mean_hidden_state=None, profile: int = 0):
     _get_reward_model, Phi3RMSNorm, Phi3VModel, Phi3VForCausalLM, Phi3VConfig = ref
     assert cfg.clip == synth.ClipConfig(), "the reference hard-wires CLIP ViT-L/14-336"
     hcfg = Phi3VConfig(
@@ -91,7 +91,7 @@ def build_reference_model(ref, cfg: synth.RewardConfig, seed: int, layer_id: int
             if canon in specs:
                 shape, std, off = specs[canon]
                 assert tuple(p.shape) == tuple(shape), (name, p.shape, shape)
-                p.copy_(torch.from_numpy(synth.gen_tensor(seed, canon, shape, std, off)))
+                p.copy_(torch.from_numpy(synth.gen_tensor(seed, canon, shape, std, off, profile=profile)))
                 used.add(canon)
     missing = set(specs) - used
     assert not missing, f"weights not consumed by the reference: {sorted(missing)[:5]}"
@@ -101,15 +101,15 @@ def build_reference_model(ref, cfg: synth.RewardConfig, seed: int, layer_id: int
 def fingerprint(t: torch.Tensor, n: int = 16):
     """Deterministic sample of n elements + abs-mean, enough to localise a divergence."""
     f = t.detach().float().reshape(-1)
-    idx = torch.linspace(0, f.numel() - 1, n).long()
+    idx = torch.linspace(0, f.numel() - 1, n, dtype=torch.float64).long()
     return {"shape": list(t.shape), "abs_mean": float(f.abs().mean()), "idx": idx.tolist(),
             "vals": [float(v) for v in f[idx]]}
 
 
 def run_case(ref, name, cfg, seed, caption_lens, grids, max_crops, taps=True, layer_id=32, mean_hidden_state=None, extra_left_pad=0,
-             train=False, right_padded=False):
+             train=False, right_padded=False, profile=0, tap_samples=16, tap_layers=None):
     print(f"[{name}] building", flush=True)
-    model = build_reference_model(ref, cfg, seed, layer_id, mean_hidden_state)
+    model = build_reference_model(ref, cfg, seed, layer_id, mean_hidden_state, profile)
     if train:
         model.train()          # rw_model:410-415 / :429-434: reward read at the last position; every dropout of the path has p = 0
     batch = synth.pad_left(synth.synth_batch(cfg, seed, caption_lens, grids, max_crops=max_crops), extra_left_pad)
@@ -126,16 +126,17 @@ def run_case(ref, name, cfg, seed, caption_lens, grids, max_crops, taps=True, la
            "grids": [list(g) for g in grids] if not isinstance(grids[0], int) else list(grids),
            "max_crops": max_crops, "reward": reward.float().tolist(), "layer_id": layer_id,
            "mean_hidden_state": bool(mean_hidden_state), "extra_left_pad": extra_left_pad, "train": train, "right_padded": right_padded,
-           "reward_shape": list(reward.shape),
+           "reward_shape": list(reward.shape), "weight_profile": profile,
            "reference_forward_seconds": dt, "threads": torch.get_num_threads(),
            "torch": torch.__version__, "dtype": "float32"}
     if taps:
         hs = outputs["hidden_states"]
-        out["taps"] = {"embeds": fingerprint(hs[0]), "vision_embeds": fingerprint(hs[-1]),
-                       "final_norm": fingerprint(outputs["last_hidden_state"])}
+        out["taps"] = {"embeds": fingerprint(hs[0], tap_samples), "vision_embeds": fingerprint(hs[-1], tap_samples),
+                       "final_norm": fingerprint(outputs["last_hidden_state"], tap_samples)}
+        # hs[l + 1] = the residual stream leaving decoder layer l; the LAST layer's output is only there normed (= final_norm)
         for l in range(cfg.layers):
-            if l in (0, 1, cfg.layers // 2, cfg.layers - 1) and l + 1 < len(hs) - 2:
-                out["taps"][f"layer{l}"] = fingerprint(hs[l + 1])
+            if l in (tap_layers or (0, 1, cfg.layers // 2, cfg.layers - 1)) and l + 1 < len(hs) - 2:
+                out["taps"][f"layer{l}"] = fingerprint(hs[l + 1], tap_samples)
     path = os.path.join(HERE, f"{name}.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
@@ -208,7 +209,7 @@ def canon_llava_name(name: str) -> str:
     return n
 
 
-def run_llava_case(name, cfg, seed, caption_lens, image_sizes, max_crops, mean_hidden_state=None):
+def run_llava_case(name, cfg, seed, caption_lens, image_sizes, max_crops, mean_hidden_state=None, profile=0):
     """Reference custom_forward, model_type='llava' (rw_model_general_preference.py:372-375,407-448)."""
     import transformers
     from transformers import CLIPVisionConfig, LlavaNextConfig, LlavaNextForConditionalGeneration, MistralConfig
@@ -240,7 +241,7 @@ def run_llava_case(name, cfg, seed, caption_lens, image_sizes, max_crops, mean_h
             if cn in specs:
                 sh, std, off = specs[cn]
                 assert tuple(p.shape) == tuple(sh), (pname, p.shape, sh)
-                p.copy_(torch.from_numpy(synth.gen_tensor(seed, cn, sh, std, off)))
+                p.copy_(torch.from_numpy(synth.gen_tensor(seed, cn, sh, std, off, profile=profile)))
                 used.add(cn)
     missing = set(specs) - used
     assert not missing, f"weights not consumed by the reference: {sorted(missing)[:6]}"
@@ -253,7 +254,7 @@ def run_llava_case(name, cfg, seed, caption_lens, image_sizes, max_crops, mean_h
     print(f"[{name}] reference llava custom_forward {dt:.1f}s reward={reward.flatten().tolist()}", flush=True)
     out = {"name": name, "backbone": "llava", "config": cfg.to_json(), "seed": seed, "caption_lens": caption_lens,
            "image_sizes": [list(x) for x in image_sizes], "max_crops": max_crops, "reward": reward.float().tolist(),
-           "mean_hidden_state": bool(mean_hidden_state),
+           "mean_hidden_state": bool(mean_hidden_state), "weight_profile": profile,
            "transformers": transformers.__version__, "torch": torch.__version__, "dtype": "float32"}
     with open(os.path.join(HERE, f"{name}.json"), "w") as f:
         json.dump(out, f, indent=1)
@@ -270,7 +271,7 @@ def canon_qwen_name(name: str) -> str:
     return n
 
 
-def run_qwen_case(name, cfg, seed, caption_lens, grids, mean_hidden_state=None):
+def run_qwen_case(name, cfg, seed, caption_lens, grids, mean_hidden_state=None, profile=0):
     """Reference custom_forward, model_type='qwen' (rw_model_general_preference.py:354-371,387-397,407-448).
 
     Shims for running the 4.50-era reference code on transformers 5.x:
@@ -313,7 +314,7 @@ def run_qwen_case(name, cfg, seed, caption_lens, grids, mean_hidden_state=None):
             if cn in specs:
                 sh, std, off = specs[cn]
                 assert tuple(p.shape) == tuple(sh), (pname, p.shape, sh)
-                p.copy_(torch.from_numpy(synth.gen_tensor(seed, cn, sh, std, off)))
+                p.copy_(torch.from_numpy(synth.gen_tensor(seed, cn, sh, std, off, profile=profile)))
                 used.add(cn)
             else:
                 assert cn == "lm_head.weight", f"reference parameter without a spec: {pname}"
@@ -329,7 +330,7 @@ def run_qwen_case(name, cfg, seed, caption_lens, grids, mean_hidden_state=None):
     print(f"[{name}] reference qwen custom_forward {dt:.1f}s reward={reward.flatten().tolist()}", flush=True)
     out = {"name": name, "backbone": "qwen", "config": cfg.to_json(), "seed": seed, "caption_lens": caption_lens,
            "grids": [list(g) for g in grids], "reward": reward.float().tolist(), "mean_hidden_state": bool(mean_hidden_state),
-           "n_ca_rows": (tb["input_ids"] == synth.QWEN_CA_TOKEN_ID).sum(dim=1).tolist(),
+           "n_ca_rows": (tb["input_ids"] == synth.QWEN_CA_TOKEN_ID).sum(dim=1).tolist(), "weight_profile": profile,
            "transformers": transformers.__version__, "torch": torch.__version__, "dtype": "float32"}
     with open(os.path.join(HERE, f"{name}.json"), "w") as f:
         json.dump(out, f, indent=1)
@@ -400,6 +401,48 @@ def main():
     elif which == "full_gpm":
         run_case(ref, "ref_full_gpm2_ca", synth.full_config(is_general_preference=True, value_head_dim=2),
                  1234, [128], (4, 4), None)
+    elif which == "full_b2":
+        # full size, B = 2, ragged captions AND ragged crop grids -> left padding (4-D causal + padding mask,
+        # modeling_phi3_v.py:1453-1459) and V_max zero padding + index_put scatter (:242-249) at full depth; 64-element taps
+        run_case(ref, "ref_full_b2_ragged_bt_ca", synth.full_config(), 2024, [128, 37], [(4, 4), (2, 3)], 16, tap_samples=64,
+                 tap_layers=(0, 1, 15, 16, 30))
+    elif which.startswith("full_seed"):
+        # more full-size rows: other seeds, caption lengths and crop grids (B = 1 each)
+        cases = {"full_seed1": (101, [64], (3, 5)), "full_seed2": (202, [200], (2, 8)), "full_seed3": (303, [17], (1, 1)),
+                 "full_seed4": (404, [128], (4, 4)), "full_seed5": (505, [96], (4, 3))}
+        seed, caps, grid = cases[which]
+        run_case(ref, f"ref_full_s{seed}_bt_ca", synth.full_config(), seed, caps, grid, 16, taps=False)
+    elif which == "outlier_small":
+        P = synth.PROFILE_OUTLIER
+        C = synth.ref_small_config
+        run_case(ref, "ref_small_outlier_bt_ca", C(), 51, [6, 3], (1, 1), None, profile=P)
+        run_case(ref, "ref_small_outlier_gpm2_ca_ragged", C(is_general_preference=True, value_head_dim=2), 52, [5, 9], [(1, 1), (1, 2)], 3, profile=P)
+        run_case(ref, "ref_small_outlier_bt_noca", C(add_cross_attention=False), 53, [4], (1, 1), None, profile=P)
+    elif which == "outlier_full":
+        run_case(ref, "ref_full_outlier_bt_ca", synth.full_config(), 606, [128], (4, 4), None, taps=False, profile=synth.PROFILE_OUTLIER)
+    elif which == "outlier_full_gpm":
+        run_case(ref, "ref_full_outlier_gpm2_ca", synth.full_config(is_general_preference=True, value_head_dim=2), 707, [77], (3, 4), 16, taps=False,
+                 profile=synth.PROFILE_OUTLIER)
+    elif which == "e4m3_small":
+        run_case(ref, "ref_small_e4m3_bt_ca", synth.ref_small_config(), 61, [6, 3], (1, 1), None, profile=synth.PROFILE_E4M3)
+        run_llava_case("ref_llava_tiny_e4m3_bt", synth.llava_tiny_config(), 62, [6, 3], [(336, 336), (512, 640)], 5, profile=synth.PROFILE_E4M3)
+        run_llava_case("ref_llava_tiny_outlier_bt", synth.llava_tiny_config(), 63, [6, 3], [(336, 336), (300, 900)], 5, profile=synth.PROFILE_OUTLIER)
+        run_qwen_case("ref_qwen_tiny_outlier_bt", synth.qwen_tiny_config(), 64, [6, 3], [(16, 16), (10, 6)], profile=synth.PROFILE_OUTLIER)
+    elif which == "llava_full_e4m3":
+        # BASELINE configs[4] "fp8 MFMA weight path": the reference on the DE-QUANTISED weights of an e4m3-weight LLaVA-v1.6-Mistral-7B
+        run_llava_case("ref_llava_full_e4m3_bt", synth.llava_full_config(), 1234, [128], [(336, 336)], None, profile=synth.PROFILE_E4M3)
+    elif which.startswith("llava_full_seed"):
+        cases = {"llava_full_seed1": (111, [64], [(512, 640)]), "llava_full_seed2": (222, [150], [(336, 336)])}
+        seed, caps, sizes = cases[which]
+        run_llava_case(f"ref_llava_full_s{seed}_bt", synth.llava_full_config(), seed, caps, sizes, None)
+    elif which == "llava_full_outlier":
+        run_llava_case("ref_llava_full_outlier_bt", synth.llava_full_config(), 333, [128], [(336, 336)], None, profile=synth.PROFILE_OUTLIER)
+    elif which.startswith("qwen_full_seed"):
+        cases = {"qwen_full_seed1": (121, [64], [(24, 40)]), "qwen_full_seed2": (232, [200], [(32, 32)])}
+        seed, caps, grids = cases[which]
+        run_qwen_case(f"ref_qwen_full_s{seed}_bt", synth.qwen_full_config(), seed, caps, grids)
+    elif which == "qwen_full_outlier":
+        run_qwen_case("ref_qwen_full_outlier_bt", synth.qwen_full_config(), 343, [128], [(32, 32)], profile=synth.PROFILE_OUTLIER)
     else:
         raise SystemExit(f"unknown set {which}")
 
