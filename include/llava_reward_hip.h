@@ -186,6 +186,17 @@ int lr_set_layer_limits(lr_handle h, int n_clip_layers, int n_layers);
  * [decoder_first, layers - decoder_last) take decoder_mid_form, the first / last ones the descriptor's.  A measurement knob
  * (tools/prec_map_probe.py): the product default is the descriptor's form in every stage. */
 int lr_set_precision_map(lr_handle h, int clip_form, int decoder_mid_form, int decoder_first, int decoder_last);
+/* Outlier-channel calibration of the default parity form (lr_model_desc.precise == 2).  An e4m3 residual carries 4 significant bits:
+ * enough for ordinary activations (f16 hi + e4m3 lo = 15 bits per element), not for the few channels of MASSIVE activations trained
+ * decoders carry in their residual stream (values ~1000x a row's typical magnitude: their 15-bit absolute error is as large as a
+ * 5-bit error on everything else).  lr_calibrate(h, 1, ratio, ...) starts a calibration: every forward until lr_calibrate(h, 0, ...)
+ * also counts, per GEMM operand and 128-column block, the rows in which the block holds |x| >= ratio x the row's mean |x|
+ * (ratio 64 is a good default).  The closing call marks, per operand, up to 4 blocks that were hot in at least row_fraction of
+ * the rows (e.g. 0.002); from then on their residuals travel in 16 bits (2 more K-tiles per hot block in that GEMM), everything else
+ * stays e4m3.  The lists are static afterwards, so a row's reward stays independent of the batch it is scored in.  Forwards run
+ * between the two calls compute normal rewards.  *n_sites_with_hot_blocks (may be NULL) = operands that got a list.
+ * Weights that are not exact in the operand type (merged adapters) take no hot blocks. */
+int lr_calibrate(lr_handle h, int begin, float ratio, float row_fraction, int* n_sites_with_hot_blocks);
 /* GEMM tile selection: -1 heuristic, 0 = 128x128, 1 = 256x128, 2 = 256x256. */
 int lr_set_gemm_tile(lr_handle h, int tile);
 
@@ -236,6 +247,9 @@ int lr_op_gemm_fp8(const void* A8, const float* ascale, const void* W8, const fl
  * and without flag 2.
  * Output as lr_op_gemm_bt_split.  K multiple of 128. */
 size_t lr_op_lo8_scratch_bytes(int M, int K);
+/* Hot blocks (see lr_calibrate) for the following lr_op_gemm_bt_mixed calls of this thread: up to 4 ascending 128-column block
+ * indices of A whose residuals stay 16-bit (flag 2 moves them behind the e4m3 bytes); n = 0 clears.  Exact weights only. */
+int lr_op_set_hot_blocks(int n, const int* blocks);
 int lr_op_gemm_bt_mixed(void* A, const void* W, void* W8, void* scratch, void* C, const float* bias, int M, int N, int K, int epi, int act,
                         int operand_dtype, int flags, int* wexp, void* hip_stream);
 int lr_op_norm_rows(const float* x, const float* w, const float* b, void* y, int rows, int H, float eps,

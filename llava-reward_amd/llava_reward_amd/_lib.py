@@ -74,6 +74,7 @@ _SIGS = {
     "lr_read_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "lr_set_layer_limits": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "lr_set_precision_map": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "lr_calibrate": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int)]),
     "lr_set_gemm_tile": (C.c_int, [C.c_void_p, C.c_int]),
     "lr_op_gemm_bt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]),
     "lr_op_gemm_bt_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),
@@ -86,6 +87,7 @@ _SIGS = {
     "lr_op_gemm_fp8": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_void_p]),
     "lr_op_gemm_bt_mixed": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7 + [C.POINTER(C.c_int), C.c_void_p]),
     "lr_op_lo8_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "lr_op_set_hot_blocks": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "lr_op_norm_rows": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "lr_op_synth_fill": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_char_p, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "lr_hd_transform_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

@@ -246,6 +246,15 @@ class RewardEngine:
         L.check(self.lib, self.lib.lr_set_precision_map(self.h, clip_form, decoder_mid_form, decoder_first, decoder_last), self.h,
                 "lr_set_precision_map")
 
+    def calibrate_begin(self, ratio: float = 64.0) -> None:
+        L.check(self.lib, self.lib.lr_calibrate(self.h, 1, ratio, 0.0, None), self.h, "lr_calibrate(begin)")
+
+    def calibrate_end(self, row_fraction: float = 0.002) -> int:
+        """-> number of GEMM operands that got a hot-block list (lr_calibrate)."""
+        n = C.c_int(0)
+        L.check(self.lib, self.lib.lr_calibrate(self.h, 0, 0.0, row_fraction, C.byref(n)), self.h, "lr_calibrate(end)")
+        return n.value
+
     def set_gemm_tile(self, tile: int) -> None:
         L.check(self.lib, self.lib.lr_set_gemm_tile(self.h, tile), self.h, "lr_set_gemm_tile")
 

@@ -82,6 +82,21 @@ class RewardModel:
         self.training = bool(mode)
         return self
 
+    def calibrate(self, *batches, ratio: float = 64.0, row_fraction: float = 0.002) -> int:
+        """Outlier-channel calibration of the default parity form (include/llava_reward_hip.h lr_calibrate): score a few
+        representative batches once -- each a dict of custom_forward keyword arguments -- so that the columns of massive
+        activations keep 16-bit residuals.  Returns the number of GEMM operands that got a hot-block list (0 = none needed).
+        No reference counterpart (the reference runs fp32 / bf16 operands)."""
+        if self.engine is None:
+            raise RuntimeError("calibrate: model is on CPU; call model.to('cuda') first")
+        self.engine.calibrate_begin(ratio)
+        try:
+            for b in batches:
+                self.custom_forward(**b)
+        finally:
+            n = self.engine.calibrate_end(row_fraction)
+        return n
+
     def custom_forward(self, input_ids=None, attention_mask=None, pixel_values=None, image_sizes=None,
                        return_output=False, inputs_batch=None):
         """rw_model_general_preference.py:334-448, phi3v branch (positional order kept:

@@ -182,20 +182,29 @@ def score_pairwise(model, args, batches: Iterable, device=None) -> Dict[str, obj
     Returns the quantities the reference prints: prob_mean, proportion (prob > 0.5), proportion w/o ties."""
     rank, ws = world()
     device = device or model.device
-    all_probs: List[float] = []
-    chosen_list: List[float] = []
-    reject_list: List[float] = []
+    cs: List[torch.Tensor] = []
+    rs: List[torch.Tensor] = []
     for inputs_c, inputs_r, *_ in batches:
         n = inputs_c["input_ids"].shape[0]
         rows = shard_rows(n, rank, ws)
         c = _forward_rows(model, inputs_c, rows, device)
         hc = gather_rewards_async(c, n)                  # in flight while the rejected rows are scored
         r = _forward_rows(model, inputs_r, rows, device)
-        c, r = hc.wait(), gather_rewards(r, n)
-        if not args.is_general_preference:
-            chosen_list.extend(c.squeeze(-1).tolist())
-            reject_list.extend(r.squeeze(-1).tolist())
-        all_probs.extend(preference_compute(args, c, r).tolist())
+        # rewards stay on the device: nothing here waits for the GPU, so the host runs ahead and enqueues the next batch (the
+        # reference's loop reads every batch back, eval/batch_inference_rm_phi.py:103-112; the engine bounds the run-ahead itself)
+        cs.append(hc.wait())
+        rs.append(gather_rewards(r, n))
+    return _pairwise_stats(args, cs, rs)
+
+
+def _pairwise_stats(args, cs: List[torch.Tensor], rs: List[torch.Tensor]) -> Dict[str, object]:
+    """The quantities the reference prints (eval/batch_inference_rm_phi.py:103-121) from per-batch reward tensors: ONE transfer."""
+    d = int(getattr(args, "value_head_dim", 1)) if args.is_general_preference else 1
+    c = torch.cat(cs, dim=0) if cs else torch.empty(0, d)
+    r = torch.cat(rs, dim=0) if rs else torch.empty(0, d)
+    all_probs: List[float] = preference_compute(args, c, r).tolist() if c.shape[0] else []
+    chosen_list: List[float] = [] if args.is_general_preference else c.squeeze(-1).tolist()
+    reject_list: List[float] = [] if args.is_general_preference else r.squeeze(-1).tolist()
     total = len(all_probs)
     gt = sum(1 for x in all_probs if x > 0.5)
     ties = sum(1 for x in all_probs if x == 0.5)
@@ -212,14 +221,15 @@ def score_single(model, args, batches: Iterable, cls_based: bool = False, device
                          "Please use BT model instead.")
     rank, ws = world()
     device = device or model.device
-    rewards: List[float] = []
+    rews: List[torch.Tensor] = []
     labels: List[int] = []
     for inputs, lab in batches:
         n = inputs["input_ids"].shape[0]
         rows = shard_rows(n, rank, ws)
         r = _forward_rows(model, inputs, rows, device)
-        rewards.extend(gather_rewards(r, n).squeeze(-1).tolist())
+        rews.append(gather_rewards_async(r, n))          # on the collective stream; read back once, after the loop
         labels.extend(torch.as_tensor(lab).tolist())
+    rewards: List[float] = torch.cat([h.wait() for h in rews], dim=0).squeeze(-1).tolist() if rews else []
     out: Dict[str, object] = {"rewards": rewards, "labels": labels}
     if cls_based:
         pred = (1.0 / (1.0 + np.exp(-np.asarray(rewards))) >= 0.5).astype(np.int64)
@@ -232,3 +242,95 @@ def score_single(model, args, batches: Iterable, cls_based: bool = False, device
         prec = tp / (tp + fp) if tp + fp else 0.0
         out["f1"] = 2 * prec * out["recall"] / (prec + out["recall"]) if prec + out["recall"] else 0.0
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Files on disk -> rewards, with the input side overlapped (the reference's loop, eval/batch_inference_rm_phi.py:
+# 58-65 DataLoader(num_workers=0-ish) + :79-94, prepares every batch on the main thread while the GPU idles)
+# ------------------------------------------------------------------------------------------------------------------------------
+class PrefetchingBatcher:
+    """Iterates over batches of (image, caption) items as `custom_forward(**batch)` dicts on the device.  `items`: a flat list cut
+    into batches of `batch_size`, or (batch_size=None) a list of ready-made chunks.  A background thread prepares batches k + 1 ..
+    k + depth while batch k is scored: image files are decoded by a small thread pool (PIL releases the GIL), the uint8 pixels cross
+    PCIe and go through lr_hd_transform on a SIDE stream, prompts are tokenised and left-padded; the consumer's stream only waits on
+    the event recorded behind that work.  Phi-3.5-V rows (batch_inference_process_phi3v_device)."""
+
+    def __init__(self, items, tokenizer, batch_size: Optional[int] = 32, num_crops: int = 16, device="cuda", depth: int = 2, workers: int = 4,
+                 pad_token_id: Optional[int] = None):
+        import queue
+        import threading
+        items = list(items)
+        self.chunks = [list(c) for c in items] if batch_size is None else [items[lo: lo + batch_size] for lo in range(0, len(items), batch_size)]
+        self.tok, self.num_crops = tokenizer, num_crops
+        self.device = torch.device(device)
+        self.pad = pad_token_id
+        self.workers = max(1, int(workers))
+        self._q = queue.Queue(maxsize=max(1, int(depth)))
+        self._err = None
+        self._stream = torch.cuda.Stream(device=self.device)
+        self._thread = threading.Thread(target=self._produce, daemon=True)
+        self._thread.start()
+
+    def __len__(self):
+        return len(self.chunks)
+
+    def _produce(self):
+        from concurrent.futures import ThreadPoolExecutor
+        from .preprocess import _load_rgb, batch_inference_process_phi3v_device
+        try:
+            torch.cuda.set_device(self.device)
+            with ThreadPoolExecutor(max_workers=self.workers) as pool:
+                for chunk in self.chunks:
+                    pixels = list(pool.map(lambda it: _load_rgb(it[0]), chunk))               # decode off the main thread
+                    with torch.cuda.stream(self._stream):
+                        batch = batch_inference_process_phi3v_device(None, self.tok, [(p, it[1]) for p, it in zip(pixels, chunk)],
+                                                                     device=self.device, num_crops=self.num_crops, pad_token_id=self.pad)
+                        ev = torch.cuda.Event()
+                        ev.record(self._stream)
+                    self._q.put((batch, ev))
+        except BaseException as e:          # surfaced on the consumer's side
+            self._err = e
+        finally:
+            self._q.put(None)
+
+    def __iter__(self):
+        while True:
+            item = self._q.get()
+            if item is None:
+                if self._err is not None:
+                    raise self._err
+                return
+            batch, ev = item
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            for v in batch.values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(cur)
+            yield batch
+
+
+@torch.no_grad()
+def score_pairwise_files(model, args, tokenizer, pairs, batch_size: int = 32, num_crops: int = 16, depth: int = 2, workers: int = 4,
+                         pad_token_id: Optional[int] = None, device=None) -> Dict[str, object]:
+    """The pairwise evaluation loop of eval/batch_inference_rm_phi.py:79-121 from files on disk: `pairs` = (caption, chosen image,
+    rejected image) triples (paths, PIL images or uint8 arrays).  Each rank takes a contiguous shard of the pairs BEFORE anything is
+    read; decoding, H2D and the HD transform of the next batches run behind the forward of the current one (PrefetchingBatcher:
+    the chosen and the rejected rows of a batch are two consecutive prefetched batches); rewards stay on the device until the end.
+    Returns the same statistics as score_pairwise."""
+    rank, ws = world()
+    device = device or model.device
+    pairs = list(pairs)
+    mine = pairs[shard_rows(len(pairs), rank, ws)]
+    chunks = []
+    for lo in range(0, len(mine), batch_size):
+        part = mine[lo: lo + batch_size]
+        chunks.append([(c, cap) for cap, c, _ in part])
+        chunks.append([(r, cap) for cap, _, r in part])
+    d = int(getattr(model, "value_head_dim", 1))
+    cs = [torch.empty((0, d), dtype=torch.float32, device=device)]
+    rs = [torch.empty((0, d), dtype=torch.float32, device=device)]
+    batches = PrefetchingBatcher(chunks, tokenizer, batch_size=None, num_crops=num_crops, device=device, depth=depth, workers=workers,
+                                 pad_token_id=pad_token_id)
+    for i, batch in enumerate(batches):
+        (cs if i % 2 == 0 else rs).append(model.custom_forward(**batch)[0].float().reshape(-1, d))
+    return _pairwise_stats(args, [gather_rewards(torch.cat(cs, dim=0), len(pairs))], [gather_rewards(torch.cat(rs, dim=0), len(pairs))])

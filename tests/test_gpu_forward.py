@@ -32,14 +32,15 @@ TOL_BF16 = 8e-3
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _model(cfg, seed, dtype, upload, max_batch=4, max_seq=1024, max_crops=5, layer_id=32, mean=False):
+def _model(cfg, seed, dtype, upload, max_batch=4, max_seq=1024, max_crops=5, layer_id=32, mean=False, profile=0, keep=False):
     if upload:
-        W = {k: torch.from_numpy(v) for k, v in synth.make_weights(cfg, seed).items()}
+        W = {k: torch.from_numpy(v) for k, v in synth.make_weights(cfg, seed, profile).items()}
         m = RewardModel(cfg, weights=W, max_batch=max_batch, max_seq=max_seq, max_crops=max_crops, operand_dtype=dtype, layer_id=layer_id,
                         mean_hidden_state=mean)
     else:
         m = RewardModel(cfg, synth_seed=seed, max_batch=max_batch, max_seq=max_seq, max_crops=max_crops, operand_dtype=dtype,
-                        layer_id=layer_id, mean_hidden_state=mean)
+                        layer_id=layer_id, mean_hidden_state=mean, synth_profile=profile)
+    m.keep_hidden_states = keep          # True: the "x" tap is read afterwards (by default the last layer computes the reward rows only)
     return m.to("cuda").eval()
 
 
@@ -77,6 +78,31 @@ def test_tiny_vs_oracle(dtype, tol, variant):
     assert torch.equal(_fwd(m2, batch), got)
 
 
+@pytest.mark.parametrize("profile", [synth.PROFILE_OUTLIER, synth.PROFILE_E4M3])
+def test_weight_profiles_device_equals_numpy(profile):
+    """The outlier-bearing and e4m3-valued synthetic weight sets (synth.PROFILE_*) are generated in HBM by synth_profile_kernel and
+    on the host by numpy: same bits (a single differing weight bit would move the reward), and the engine matches the oracle on them."""
+    cfg = synth.tiny_config(is_general_preference=True, value_head_dim=2)
+    seed = 13
+    batch = synth.synth_batch(cfg, seed, [7, 3, 5], [(1, 1), (1, 2), (2, 1)], max_crops=4)
+    Wn = synth.make_weights(cfg, seed, profile)
+    if profile & synth.PROFILE_E4M3:          # matrices sit on the e4m3 grid of their tensor's power-of-two scale
+        w = Wn["model.layers.0.mlp.down_proj.weight"]
+        q = torch.from_numpy(w * np.float32(2.0 ** -synth.e4m3_tensor_exponent(0.02)))
+        assert torch.equal(q.to(torch.float8_e4m3fn).float(), q)
+    if profile & synth.PROFILE_OUTLIER:
+        ch = synth.outlier_channels(seed, cfg.hidden)
+        emb = np.abs(Wn["model.embed_tokens.weight"])
+        assert emb[:, ch].mean() > 50 * np.delete(emb, ch, axis=1).mean() and Wn["model.norm.weight"].max() > 2.0
+    ref = orc.custom_forward(orc.weights_to_torch(Wn), cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"])
+    up = _fwd(_model(cfg, seed, "f16x2", upload=True, profile=profile), batch)
+    dev = _fwd(_model(cfg, seed, "f16x2", upload=False, profile=profile), batch)
+    assert torch.equal(up, dev)
+    err = (dev - ref).abs().max().item()
+    print(f"[weight profile {profile}] max |reward err| vs oracle = {err:.2e}")
+    assert err < TOL_X2
+
+
 def test_stage_taps_tiny():
     """Localise divergences: CLIP output, projected vision tokens, residual stream after the stack."""
     cfg = synth.tiny_config()
@@ -85,7 +111,7 @@ def test_stage_taps_tiny():
     W = orc.weights_to_torch(synth.make_weights(cfg, seed))
     taps = {}
     orc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"], taps=taps)
-    m = _model(cfg, seed, "f16", upload=True)
+    m = _model(cfg, seed, "f16", upload=True, keep=True)
     _fwd(m, batch)
     e = m.engine
     Hc, D, T = cfg.clip.hidden, cfg.hidden, cfg.clip.tokens
@@ -207,7 +233,7 @@ def test_reference_goldens_small(path, dtype, tol):
         batch = synth.right_pad(batch)
     ref = torch.tensor(g["reward"], dtype=torch.float32)
     m = _model(cfg, g["seed"], dtype, upload=False, max_batch=2, max_seq=1024, max_crops=5, layer_id=g.get("layer_id", 32),
-               mean=g.get("mean_hidden_state", False))
+               mean=g.get("mean_hidden_state", False), profile=g.get("weight_profile", 0))
     if g.get("train"):          # model.train(): reward of the last position; the BT head returns [B] (rw_model:413-415), GPM [B, d]
         m.train()
     got = _fwd(m, batch)
@@ -216,9 +242,14 @@ def test_reference_goldens_small(path, dtype, tol):
     err = (got - ref).abs().max().item()
     print(f"[{g['name']} {dtype}] max |reward err| vs reference = {err:.3e}")
     assert err < tol
+    # by default the last decoder layer runs its attention / o_proj / MLP for the reward rows only (rw_model:408-421 reads one row per
+    # sample): bit-identical to the forward that keeps every token through it (eval and train selection, left and right padding)
+    m.keep_hidden_states = True
+    assert torch.equal(_fwd(m, batch).reshape(ref.shape), got)
+    m.keep_hidden_states = False
     if g.get("layer_id", 32) != 32:      # the same engine gives the last-layer reward again once layer_id is the literal 32
         m.layer_id = 32
-        W = orc.weights_to_torch(synth.make_weights(cfg, g["seed"]))
+        W = orc.weights_to_torch(synth.make_weights(cfg, g["seed"], g.get("weight_profile", 0)))
         full = orc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"])
         assert (_fwd(m, batch) - full).abs().max().item() < tol
 
@@ -227,23 +258,23 @@ TAP_CASES = [p for p in CASES if json.load(open(p)).get("taps")]
 TOL_TAP = 5e-5
 
 
-@pytest.mark.parametrize("path", TAP_CASES, ids=[os.path.basename(p)[:-5] for p in TAP_CASES])
-def test_reference_golden_stage_taps(path):
+def _check_golden_taps(g, max_seq=1024, max_crops=5, tol=None):
     """Stage-level pins against the REFERENCE itself (not the oracle): the fingerprints make_goldens.py took of the reference's
-    hidden_states -- `embeds` (hs[0]), `layer0` (hs[1]), `final_norm` (last_hidden_state), `vision_embeds` (hs[-1], zero-padded to
-    V_max) -- are read back from the HIP engine through lr_read_tap in the strict parity mode (f16x2) and compared at 5e-5 on
-    valid (un-padded) token rows.  The engine keeps one residual stream, so the stack is stopped after 0 / 1 / all layers
-    (lr_set_layer_limits via layer_id) to observe each state; the final norm of every row is applied on the host from the
-    engine's un-normed stream and its norm weight (the engine itself only norms the gathered row)."""
-    g = json.load(open(path))
+    hidden_states -- `embeds` (hs[0]), `layerL` (hs[L + 1]: the stream leaving decoder layer L), `final_norm` (last_hidden_state),
+    `vision_embeds` (hs[-1], zero-padded to V_max) -- are read back from the HIP engine through lr_read_tap in the strict parity
+    mode (f16x2) and compared at 5e-5 (relative to 1 + |value|) on valid (un-padded) token rows.  The engine keeps one residual
+    stream, so the stack is stopped after 0 / L + 1 / all layers (lr_set_layer_limits via layer_id) to observe each state; the final
+    norm of every row is applied on the host from the engine's un-normed stream and its norm weight (the engine itself only norms
+    the gathered row)."""
     cfg = synth.RewardConfig.from_json(g["config"])
     grids = g["grids"]
     grids = tuple(grids) if isinstance(grids[0], int) else [tuple(x) for x in grids]
     batch = synth.pad_left(synth.synth_batch(cfg, g["seed"], g["caption_lens"], grids, max_crops=g["max_crops"]), g.get("extra_left_pad", 0))
     B, S = batch["input_ids"].shape
     D = cfg.hidden
+    prof = g.get("weight_profile", 0)
     valid = torch.from_numpy(batch["attention_mask"]).bool().reshape(-1)
-    m = _model(cfg, g["seed"], "f16x2", upload=False, max_batch=2, max_seq=1024, max_crops=5)
+    m = _model(cfg, g["seed"], "f16x2", upload=False, max_batch=B, max_seq=max(max_seq, S), max_crops=max_crops, profile=prof, keep=True)
     taps = g["taps"]
 
     def stream_after(n_layers):
@@ -259,15 +290,16 @@ def test_reference_golden_stage_taps(path):
         assert keep.any(), name
         a = mine_flat_rows[rows[keep], cols[keep]]
         b = torch.tensor(fp["vals"])[keep]
-        err = (a - b).abs().max().item()
+        err = ((a - b).abs() / (1.0 + b.abs())).max().item()          # (outlier goldens carry |x| ~ 500 in three channels)
         print(f"[{g['name']}] tap {name}: {int(keep.sum())} samples, max err {err:.2e}")
-        assert err < TOL_TAP, (name, a, b)
+        assert err < (tol or TOL_TAP), (name, a, b)
 
     check("embeds", stream_after(0), valid)
-    if "layer0" in taps:
-        check("layer0", stream_after(1), valid)
+    for name in sorted(taps):
+        if name.startswith("layer"):
+            check(name, stream_after(int(name[5:]) + 1), valid)
     x = stream_after(cfg.layers)
-    w = torch.from_numpy(synth.gen_tensor(g["seed"], "model.norm.weight", (D,), 0.05, 1.0))
+    w = torch.from_numpy(synth.gen_tensor(g["seed"], "model.norm.weight", (D,), 0.05, 1.0, profile=prof))
     normed = w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + cfg.rms_eps))          # modeling_phi3_v.py:377-391 on the engine's stream
     check("final_norm", normed, valid)
     # vision_embeds: [B, V_max, D] zero-padded per sample (modeling_phi3_v.py:242-245); the engine keeps the rows packed
@@ -283,38 +315,65 @@ def test_reference_golden_stage_taps(path):
     check("vision_embeds", padded, torch.ones(B * Vmax, dtype=torch.bool))
 
 
+@pytest.mark.parametrize("path", TAP_CASES, ids=[os.path.basename(p)[:-5] for p in TAP_CASES])
+def test_reference_golden_stage_taps(path):
+    _check_golden_taps(json.load(open(path)))
+
+
 FULL = [p for p in sorted(glob.glob(os.path.join(GOLD, "ref_full_*.json"))) if "pair_sample" not in p]     # (the pair has its own test)
+# every full-size golden in both parity forms; the single-pass fast mode (not a parity mode) on the first two rows only
+FULL_PARAMS = [(p, d) for p in FULL for d in ("f16x2", "f16x2f8")] + [(p, "f16") for p in FULL if os.path.basename(p) in
+                                                                       ("ref_full_bt_ca.json", "ref_full_gpm2_ca.json")]
 
 
-@pytest.mark.parametrize("dtype", ["f16x2", "f16x2f8", "f16"])
-@pytest.mark.parametrize("path", FULL, ids=[os.path.basename(p)[:-5] for p in FULL])
+@pytest.mark.parametrize("path,dtype", FULL_PARAMS, ids=[os.path.basename(p)[:-5] + "-" + d for p, d in FULL_PARAMS])
 def test_reference_golden_full_size(path, dtype):
-    """Full Phi-3.5-V shapes (32 layers, D=3072, 17 crops, V=2509, S=2643): reward of the reference's
-    fp32 CPU custom_forward vs the HIP path with weights regenerated in HBM."""
+    """Full Phi-3.5-V shapes (32 layers, D=3072, up to 17 crops, V=2509, S=2643): reward of the reference's fp32 CPU custom_forward vs
+    the HIP path with weights regenerated in HBM.  Rows: several seeds / caption lengths / crop grids, a B=2 batch with ragged
+    captions AND ragged crop grids (left padding, V_max zero padding, SkipCA over the padded vision rows), and rows on the
+    outlier-bearing weight profile (synth.PROFILE_OUTLIER: massive residual channels, large norm gains, 50-sigma and sub-normal
+    weight elements)."""
     g = json.load(open(path))
     cfg = synth.RewardConfig.from_json(g["config"])
     grids = g["grids"]
     grids = tuple(grids) if isinstance(grids[0], int) else [tuple(x) for x in grids]
     batch = synth.synth_batch(cfg, g["seed"], g["caption_lens"], grids, max_crops=g["max_crops"])
     ref = torch.tensor(g["reward"], dtype=torch.float32)
-    S = batch["input_ids"].shape[1]
-    m = _model(cfg, g["seed"], dtype, upload=False, max_batch=2, max_seq=S, max_crops=17)
+    B, S = batch["input_ids"].shape
+    m = _model(cfg, g["seed"], dtype, upload=False, max_batch=2 * B, max_seq=S, max_crops=17, profile=g.get("weight_profile", 0))
     got = _fwd(m, batch).reshape(ref.shape)
     err = (got - ref).abs().max().item()
     print(f"[{g['name']} {dtype}] reward hip={got.flatten().tolist()} ref={ref.flatten().tolist()} err={err:.3e}")
     if dtype == "f16x2":
         assert err < TOL_X2                      # parity mode: measured 2.6e-6 / 5.5e-6
     elif dtype == "f16x2f8":
-        assert err < TOL_X8                      # default parity mode (e4m3 residual pass): measured 4.8e-7 on the BT row
+        # default parity mode (e4m3 residual passes): <= 7e-5 on every benign row.  The outlier-bearing weight set amplifies ANY operand
+        # rounding 15-25x (single-pass f16 lands 1.3e-2 from the strict form there against 5e-4 on benign weights, tools/prec_map_probe.py):
+        # those rows are held to the north-star bar itself, measured 4.8e-4 (BT) -- the strict form stays at 5e-6 (DESIGN.md §4)
+        assert err < (TOL_F16 if g.get("weight_profile", 0) & synth.PROFILE_OUTLIER else TOL_X8)
     else:
         # single-pass f16: 1e-3 in the assert_close sense (atol = rtol = 1e-3).  At full depth (23 + 32 layers) numerically
         # equivalent builds land anywhere within about +-1e-3 of the reference on this row (sigma ~ 7e-4 at |r| = 1.3,
         # tools/noise_probe.py; bf16 operands: +-8e-3), see DESIGN.md §4.
         assert (((got - ref).abs() <= TOL_F16 + TOL_F16 * ref.abs()).all())
-    # same row twice in one batch: bit-identical rewards
+    # the same rows twice in one batch: bit-identical rewards
     dup = {k: np.concatenate([v, v]) for k, v in batch.items()}
     r2 = _fwd(m, dup)
-    assert torch.equal(r2[0], r2[1]) and torch.equal(r2[0], got.reshape(r2[0].shape))
+    assert torch.equal(r2[:B], r2[B:]) and torch.equal(r2[:B].reshape(got.shape), got)
+    # the gathered last layer (default) against the same forward with every token kept through it: bit-identical
+    m.keep_hidden_states = True
+    assert torch.equal(_fwd(m, batch).reshape(got.shape), got)
+
+
+FULL_TAPS = [p for p in FULL if json.load(open(p)).get("taps")]
+
+
+@pytest.mark.parametrize("path", FULL_TAPS, ids=[os.path.basename(p)[:-5] for p in FULL_TAPS])
+def test_reference_golden_full_size_stage_taps(path):
+    """64-element slices of the reference's hidden states at full size (B = 2, left padding, ragged crop grids):
+    embeddings, the stream after layers 0 / 1 / 15 / 16 / 30, the final norm and the zero-padded vision rows."""
+    g = json.load(open(path))
+    _check_golden_taps(g, max_crops=17, tol=2e-4)        # (fp32 summation-order noise grows with depth: 1e-5 after layer 1, 5e-5 after 15)
 
 
 def test_config0_sample_pair_through_the_drop_in_api(tmp_path):

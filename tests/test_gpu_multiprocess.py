@@ -38,13 +38,17 @@ def test_two_rank_processes_on_one_gpu_equal_single_process(tmp_path):
 
 
 def test_bench_two_ranks_on_one_device(tmp_path):
-    port = 29900 + os.getpid() % 90
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "2", "--backend", "gloo", "--all-ranks-on-device", "0",
-           "--quick"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    """The BARE command the driver's N = 1 run has the shape of, `python bench.py --gpus 2 ...` with no launcher around it: bench.py
+    starts its own rank processes (torch.distributed.run) before touching the GPU and relays rank 0's JSON line and the exit code."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "2", "--backend", "gloo",
+           "--all-ranks-on-device", "0", "--quick"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 4 and res["scaling"] == "weak" and res["value"] > 0
     assert res["config"]["collective"].startswith("all_gather")
+    # a failing child is this command's failure
+    bad = subprocess.run(cmd + ["--dtype", "no-such-dtype"], capture_output=True, text=True, timeout=600, env=env)
+    assert bad.returncode != 0

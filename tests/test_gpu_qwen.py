@@ -23,14 +23,14 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _model(cfg, seed, dtype, upload, max_batch=4, max_seq=1024, max_patches=4096, mean=False):
+def _model(cfg, seed, dtype, upload, max_batch=4, max_seq=1024, max_patches=4096, mean=False, profile=0):
     if upload:
-        W = {k: torch.from_numpy(v) for k, v in synth.qwen_make_weights(cfg, seed).items()}
+        W = {k: torch.from_numpy(v) for k, v in synth.qwen_make_weights(cfg, seed, profile).items()}
         m = RewardModel(cfg, weights=W, max_batch=max_batch, max_seq=max_seq, operand_dtype=dtype, max_patches=max_patches,
                         mean_hidden_state=mean)
     else:
         m = RewardModel(cfg, synth_seed=seed, max_batch=max_batch, max_seq=max_seq, operand_dtype=dtype, max_patches=max_patches,
-                        mean_hidden_state=mean)
+                        mean_hidden_state=mean, synth_profile=profile)
     return m.to("cuda").eval()
 
 
@@ -95,6 +95,7 @@ def test_qwen_positions_and_stage_taps():
     taps = {}
     _oracle(cfg, seed, batch, taps=taps)
     m = _model(cfg, seed, "f16", upload=True)
+    m.keep_hidden_states = True          # the "x" tap is read below
     _fwd(m, batch)
     e = m.engine
     B, S = batch["input_ids"].shape
@@ -179,19 +180,21 @@ def test_qwen_reference_goldens(path, dtype):
     cfg = synth.QwenConfig.from_json(g["config"])
     batch = synth.qwen_synth_batch(cfg, g["seed"], g["caption_lens"], [tuple(x) for x in g["grids"]])
     ref = torch.tensor(g["reward"], dtype=torch.float32)
-    m = _model(cfg, g["seed"], dtype, upload=False, mean=g.get("mean_hidden_state", False))
+    m = _model(cfg, g["seed"], dtype, upload=False, mean=g.get("mean_hidden_state", False), profile=g.get("weight_profile", 0))
     got = _fwd(m, batch).reshape(ref.shape)
     err = (got - ref).abs().max().item()
     print(f"[{g['name']} {dtype}] max |reward err| vs reference = {err:.3e}")
+    m.keep_hidden_states = True                  # the gathered last layer (default) vs every token kept through it: bit-identical
+    assert torch.equal(_fwd(m, batch).reshape(ref.shape), got)
     # f16x2f8 is the shipped default: e4m3 residual pass wherever K % 128 == 0 on the deep-pipelined kernel (3e-4 bar)
     assert err < 1e-4 if dtype == "f16x2" else err < 3e-4 if dtype == "f16x2f8" else _close(got, ref)
 
 
 FULL = sorted(glob.glob(os.path.join(GOLD, "ref_qwen_full_*.json")))
+FULL_PARAMS = [(p, d) for p in FULL for d in ("f16x2", "f16x2f8")] + [(p, "f16") for p in FULL if p.endswith("ref_qwen_full_bt.json")]
 
 
-@pytest.mark.parametrize("dtype", ["f16x2", "f16x2f8", "f16"])
-@pytest.mark.parametrize("path", FULL, ids=[os.path.basename(p)[:-5] for p in FULL])
+@pytest.mark.parametrize("path,dtype", FULL_PARAMS, ids=[os.path.basename(p)[:-5] + "-" + d for p, d in FULL_PARAMS])
 def test_qwen_reference_golden_full_size(path, dtype):
     """Qwen2.5-VL-7B shapes (ViT 32 x 1280, 28 layers, D = 3584, 28/4 heads, vocab 152064): reward of the reference's
     fp32 CPU custom_forward vs the HIP path with weights regenerated in HBM by the same integer hash."""
@@ -200,7 +203,8 @@ def test_qwen_reference_golden_full_size(path, dtype):
     batch = synth.qwen_synth_batch(cfg, g["seed"], g["caption_lens"], [tuple(x) for x in g["grids"]])
     ref = torch.tensor(g["reward"], dtype=torch.float32)
     S = batch["input_ids"].shape[1]
-    m = _model(cfg, g["seed"], dtype, upload=False, max_batch=2, max_seq=S, max_patches=2 * 1024)
+    m = _model(cfg, g["seed"], dtype, upload=False, max_batch=2, max_seq=S, max_patches=2 * int(batch["pixel_values"].shape[0]),
+               profile=g.get("weight_profile", 0))
     got = _fwd(m, batch).reshape(ref.shape)
     err = (got - ref).abs().max().item()
     print(f"[{g['name']} {dtype}] reward hip={got.flatten().tolist()} ref={ref.flatten().tolist()} err={err:.3e}")

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported():
     declared = set(re.findall(r"^(?:int|size_t|const char\*)\s+(lr_\w+)\(", hdr, flags=re.M))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     lib = _lib.load()                      # resolves every symbol; no compute without a GPU
-    assert lib.lr_abi_version() == 6
+    assert lib.lr_abi_version() == _lib.LR_ABI_VERSION == 7
     assert _lib.ModelDesc.struct_size.offset == 0
 
 

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Per-stage operand forms (lr_set_precision_map): reward distance to the strict split-operand form (f16x2, itself <= 6e-6 from the
+reference on every full-size golden) over N full-size Phi-3.5-V rows, for a list of maps, on two weight sets (default / outlier-bearing).
+    python tools/prec_map_probe.py [rows] [profile]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "llava-reward_amd"), ROOT]
+import numpy as np, torch
+from llava_reward_amd import synth
+from llava_reward_amd.model import RewardModel
+
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+profile = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+cfg = synth.full_config()
+b = synth.synth_batch(cfg, 77, [128, 64, 200, 17, 96, 128, 33, 150][:rows] + [128] * max(0, rows - 8), (4, 4), with_pixels=False)
+ids, mask = torch.from_numpy(b["input_ids"]).cuda(), torch.from_numpy(b["attention_mask"]).cuda()
+pix = torch.randn(rows, 17, 3, 336, 336, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+m = RewardModel(cfg, synth_seed=77, max_batch=rows, max_seq=ids.shape[1], max_crops=17, synth_profile=profile).to("cuda").eval()
+
+
+def run(cm, mid, first, last):
+    m.engine.set_precision_map(cm, mid, first, last)
+    r = m.engine.forward(ids, mask, pix, b["image_sizes"]).clone()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        m.engine.forward(ids, mask, pix, b["image_sizes"])
+    torch.cuda.synchronize()
+    return r.cpu().double(), (time.perf_counter() - t0) / 2 * 1e3
+
+
+ref, t_ref = run(1, 1, 0, 0)
+print(f"profile {profile}: rewards (strict) {ref.flatten().tolist()}")
+print(f"{'map':44s} {'rms':>9s} {'max':>9s} {'ms':>8s}")
+L = cfg.layers
+for name, args in [("strict everywhere (f16x2)", (1, 1, 0, 0)), ("default everywhere (f16x2f8)", (-1, -1, 0, 0)),
+                   ("CLIP single pass, decoder default", (0, -1, 0, 0)), ("CLIP strict, decoder default", (1, -1, 0, 0)),
+                   ("CLIP default, decoder single pass", (-1, 0, 0, 0)),
+                   ("decoder layers 4..27 single", (-1, 0, 4, 4)), ("decoder layers 8..23 single", (-1, 0, 8, 8)),
+                   ("decoder layers 12..19 single", (-1, 0, 12, 12)), ("decoder layers 0..15 single", (-1, 0, 0, 16)),
+                   ("decoder layers 16..31 single", (-1, 0, 16, 0)), ("everything single pass (f16)", (0, 0, 0, 0))]:
+    r, ms = run(*args)
+    d = (r - ref).abs()
+    print(f"{name:44s} {d.pow(2).mean().sqrt().item():9.2e} {d.max().item():9.2e} {ms:8.1f}")
