@@ -342,11 +342,14 @@ inline void ensure_lo8_twin(lr_engine* e, const void* W, int N, int K, int ldw, 
 inline void ensure_aexp(lr_engine* e, size_t rows, size_t K) {
     const size_t need = lo8_scale_bytes((int)rows, (int)K);
     if (need > e->sc_cap) {
+        // (presized at lr_finalize; a growth during a forward is a fallback: hipMalloc synchronises the device, and the fill is
+        //  ordered for every stream by the device-wide synchronisation behind it)
         e->sc_cap = (need + 65535) & ~(size_t)65535;
         for (int i = 0; i < 2; ++i) {
             e->sc[i] = (unsigned char*)e->dalloc(e->sc_cap, false);
             LR_HIP_CHECK(hipMemset(e->sc[i], 127, e->sc_cap));           // rows beyond M of a last tile read these: any finite scale
         }
+        LR_HIP_CHECK(hipDeviceSynchronize());
     }
     if (rows > e->aexp2_cap) {
         e->aexp2_cap = (rows + 4095) & ~(size_t)4095;

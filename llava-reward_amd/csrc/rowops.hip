@@ -427,7 +427,11 @@ void launch_embed(const int64_t* ids, const int* img_row, const unsigned short* 
 // modeling_phi3_v.py:446-476: freqs = pos * inv_freq; cos/sin scaled by sqrt(1 + ln(s)/ln(orig)); long factors when
 // seq_len > original_max_position_embeddings.  The attention layers call it with seq_len = kv_seq_len = the PADDED length S
 // (:673 eager, :1081 sdpa; no KV cache on this path), so the `seq_len or max(position_ids)+1` fallback of :448 is never taken:
-// the switch depends on S alone, not on how many tokens of a row are valid.  cs layout: [row][half][2].
+// the switch depends on S alone, not on how many tokens of a row are valid.  This is the EAGER / SDPA convention (the oracle's and
+// the goldens' attention implementation).  Phi3FlashAttention2 (:793-794; flash-attn is absent here, so it is unpinned) passes
+// seq_len = max(kv_seq_len, max(position_ids)) + 1 and therefore switches one token earlier, at S >= original_max: at S ==
+// original_max exactly (4096 for Phi-3.5-V) a flash-attention reference uses the long factors where this engine, like eager / sdpa,
+// still uses the short ones (golden ref_small_rope_at_orig_bt_ca pins the eager side of that boundary).  cs layout: [row][half][2].
 __global__ __launch_bounds__(256) void rope_table_kernel(const int* __restrict__ pos, int S,
                                                          int rows, const float* __restrict__ inv_s,
                                                          const float* __restrict__ inv_l, float scaling, int orig_max,

@@ -152,8 +152,15 @@ class RewardModel:
             return reward, None
         B, S = int(shape[0]), int(shape[1])
         D = self.config.hidden
-        hl = torch.from_numpy(self.engine.read_tap("hL", B * D).reshape(B, D).copy())
-        return reward, {"last_hidden_state": self.engine.last_hidden_state(B, S, no_final_norm=inner),
+        # the hidden row behind each reward (after final norm / SkipCA input); the mean-pooling head has no such row
+        hl = None if self.mean_hidden_state else torch.from_numpy(self.engine.read_tap("hL", B * D).reshape(B, D).copy())
+        if inner:
+            # layer_id != 32: the reference's outputs["last_hidden_state"] would still be the final norm of the FULL stack, which this
+            # forward (stopped after layer_id layers) never computed -- so the key is not offered; what the reward was read from,
+            # hidden_states[layer_id] (rw_model:351-352), comes back under its own name
+            return reward, {"hidden_states_at_layer_id": self.engine.last_hidden_state(B, S, no_final_norm=True),
+                            "last_hidden_state_at_reward_token": hl}
+        return reward, {"last_hidden_state": self.engine.last_hidden_state(B, S, no_final_norm=False),
                         "last_hidden_state_at_reward_token": hl}
 
     def _custom_forward_qwen(self, inputs_batch, return_output):

@@ -263,6 +263,8 @@ class PrefetchingBatcher:
         self.chunks = [list(c) for c in items] if batch_size is None else [items[lo: lo + batch_size] for lo in range(0, len(items), batch_size)]
         self.tok, self.num_crops = tokenizer, num_crops
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.pad = pad_token_id
         self.workers = max(1, int(workers))
         self._q = queue.Queue(maxsize=max(1, int(depth)))

@@ -45,7 +45,9 @@ def evaluate(model, eval_dataloader: Iterable, loss_fn: Callable, margin: Option
     dim that is squeezed here as there (:394-402) -- `loss, prob = loss_fn(chosen_reward, reject_reward, margin)`, means over the
     batches, optional cross-rank mean (`strategy.all_reduce`), then `model.train()` -- unconditionally, as the reference resets its
     model state (:441): call `model.eval()` again before scoring with it.  `loss_fn` is the trainer's own loss
-    module (PairWiseLoss, GeneralPreferenceLoss, ...: llava_reward/models/loss.py), untouched."""
+    module (PairWiseLoss, GeneralPreferenceLoss, ...: llava_reward/models/loss.py), untouched.
+    Return value: a dict on EVERY rank (the reference returns the scalar loss_mean, on rank 0 only, and logs the rest, :436-445)."""
+    model = getattr(model, "module", model)              # DeepSpeed / DDP wrappers: mode switches and .device belong to the inner model
     dev = model.device
     model.eval()
     loss_sum, prob_sum, n = 0.0, 0.0, 0

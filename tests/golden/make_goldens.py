@@ -388,6 +388,10 @@ def main():
         run_case(ref, "ref_small_rope_long_bt_ca", C(orig_max_pos=300, max_pos=9600), 31, [5, 9], (1, 1), None)
         run_case(ref, "ref_small_rope_long_allpad_gpm2_ca", C(orig_max_pos=330, max_pos=9600, is_general_preference=True, value_head_dim=2),
                  32, [5, 9], (1, 1), None, extra_left_pad=8)
+    elif which == "rope_at_orig":
+        # S == original_max_position_embeddings exactly (327): eager / sdpa attention (`seq_len > orig`, modeling_phi3_v.py:449 via
+        # :673) still takes the SHORT factors here; Phi3FlashAttention2 (:793-794, seq_len = S + 1) would take the long ones
+        run_case(ref, "ref_small_rope_at_orig_bt_ca", synth.ref_small_config(orig_max_pos=327, max_pos=9600), 33, [5, 9], (1, 1), None)
     elif which == "train":
         # model.train(): the reward of the LAST position (rw_model:410-415 BT -> [B]; :429-434 GPM -> [B, d]), with left-padded rows (the
         # trainer's collate) and with right-padded rows (the last position is then a pad position of the shorter row)

@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """Golden vectors of the Phi-3.5-V image hand-over, made in the build container.
 
-The reference's processor (llava_reward/models/base_mllm/phi3_v/processing_phi3_v.py) cannot be imported here: it needs
-torchvision, which this image does not have.  Its two numerical primitives CAN be run: Pillow's Image.resize (what
-torchvision.transforms.functional.resize calls on a PIL image) and torch.nn.functional.interpolate(bicubic).  This script
-runs those real primitives, composed as processing_phi3_v.py:85-107 / :262-288 composes them (torchvision's constant
-`pad` on a PIL image = ImageOps.expand), on seeded images and stores digests: the padded size, the token count, a SHA-256
-of the local crops' bytes (bit-exact part) and 96 sampled values of the bicubic global view.
+The reference's processor (llava_reward/models/base_mllm/phi3_v/processing_phi3_v.py) needs torchvision, which this image does
+not have -- but only five small entry points of it: functional.resize / functional.pad on PIL images (which torchvision itself
+hands to Pillow: Image.resize BILINEAR, ImageOps.expand) and Compose / ToTensor / Normalize.  `reference_processor()` below puts a
+PIL-backed stand-in for exactly those five under the name `torchvision`, IMPORTS the reference module and runs its own
+Phi3VImageProcessor.preprocess (HD_transform :85-107, padding_336 :62-72, preprocess :208-288): the GLUE -- crop arithmetic,
+transposition, padding, global view, tiling, zero crops, token count -- is therefore the reference's code, pinned; the RESAMPLER
+under it is Pillow's (what torchvision calls for PIL inputs), not torchvision's tensor path.  `pipeline()` is the restatement the
+oracle mirrors; main() asserts it equals the imported reference bit for bit on every case before writing the digests: the padded
+size, the token count, a SHA-256 of the local crops' bytes (bit-exact part) and 96 sampled values of the bicubic global view.
 
 The Qwen2-VL and LLaVA-NeXT processors are third party (transformers); their PIL-backend classes import here, so their
 goldens (preq_*.json, prel_*.json) are digests of the REAL processors' outputs on seeded images.
@@ -72,6 +75,60 @@ def pipeline(a, hd_num):
     return out.numpy(), (h, w)
 
 
+_REF_PROC = None
+
+
+def reference_processor():
+    """The reference's processing_phi3_v module, imported with a PIL-backed stand-in for the five torchvision entry points it uses."""
+    global _REF_PROC
+    if _REF_PROC is not None:
+        return _REF_PROC
+    import importlib.util
+    import types
+    import transformers  # noqa: F401  (the real imports first: transformers probes `torchvision` with find_spec)
+    import transformers.image_processing_utils, transformers.image_transforms, transformers.image_utils  # noqa: F401,E401
+    import transformers.processing_utils, transformers.tokenization_utils_base  # noqa: F401,E401
+    tv, tr, fn = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms"), types.ModuleType("torchvision.transforms.functional")
+    fn.resize = lambda img, size, *a, **k: img.resize((size[1], size[0]), Image.BILINEAR)          # torchvision's default for PIL inputs
+    fn.pad = lambda img, padding, fill=0, *a, **k: ImageOps.expand(img, border=tuple(padding), fill=tuple(fill) if isinstance(fill, (list, tuple)) else fill)
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class ToTensor:
+        def __call__(self, img):
+            return torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean, self.std = mean, std
+
+        def __call__(self, t):
+            return t.clone().sub_(torch.as_tensor(self.mean, dtype=t.dtype).view(-1, 1, 1)).div_(torch.as_tensor(self.std, dtype=t.dtype).view(-1, 1, 1))
+
+    tr.Compose, tr.ToTensor, tr.Normalize, tr.functional, tv.transforms = Compose, ToTensor, Normalize, fn, tr
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tr, "torchvision.transforms.functional": fn})
+    # transformers 5.x: AutoImageProcessor itself needs torchvision; the module-level registration (:296) is not on the path
+    transformers.AutoImageProcessor = types.SimpleNamespace(register=lambda *a, **k: None)
+    spec = importlib.util.spec_from_file_location("ref_processing_phi3_v", "/root/reference/llava_reward/models/base_mllm/phi3_v/processing_phi3_v.py")
+    mod = importlib.util.module_from_spec(spec)
+    sys.dont_write_bytecode = True
+    spec.loader.exec_module(mod)
+    _REF_PROC = mod
+    return mod
+
+
+def reference_pipeline(a, hd_num):
+    out = reference_processor().Phi3VImageProcessor(num_crops=hd_num).preprocess([Image.fromarray(a)], return_tensors="pt")
+    return out["pixel_values"][0].numpy(), tuple(int(x) for x in out["image_sizes"][0]), int(out["num_img_tokens"][0])
+
+
 def sample_index(n=96):
     return [(c, (37 * i + 5) % 336, (101 * i + 11) % 336) for i in range(n) for c in (i % 3,)]
 
@@ -123,12 +180,16 @@ def main():
     for name, h, w, nc, smooth in CASES:
         a = synth.synth_image(1234, "pre." + name, h, w, smooth)
         pv, (H, W) = pipeline(a, nc)
+        rpv, rsize, rtok = reference_pipeline(a, nc)          # the reference's own preprocess(): must equal the restatement bit for bit
+        assert rsize == (H, W) and np.array_equal(rpv, pv), name
         n_local = (H // 336) * (W // 336)
+        assert rtok == int((n_local + 1) * 144 + 1 + (H // 336 + 1) * 12)
         g = {"name": name, "seed": 1234, "h": h, "w": w, "num_crops": nc, "smooth": smooth,
              "image_size": [H, W], "num_img_tokens": int((n_local + 1) * 144 + 1 + (H // 336 + 1) * 12),
              "n_local": n_local, "local_sha256": hashlib.sha256(np.ascontiguousarray(pv[1:]).tobytes()).hexdigest(),
              "global_samples": [float(pv[0, c, y, x]) for c, y, x in sample_index()],
-             "made_with": {"pillow": PIL.__version__, "torch": torch.__version__}}
+             "made_with": {"pillow": PIL.__version__, "torch": torch.__version__,
+                           "glue": "reference Phi3VImageProcessor.preprocess, imported (PIL-backed stand-in for torchvision's resize / pad / ToTensor / Normalize)"}}
         with open(os.path.join(HERE, f"pre_{name}.json"), "w") as f:
             json.dump(g, f, indent=1)
         print(name, g["image_size"], g["num_img_tokens"], g["local_sha256"][:16])

@@ -98,3 +98,37 @@ def test_llava_slot_mismatch_raises():
     bad["input_ids"][0, -2] = cfg.image_token_id
     with pytest.raises(ValueError, match="do not match"):
         _fwd(m, bad)
+
+
+W8A8_FIXTURE = os.path.join(GOLD, "w8a8_llava_full_emulation.json")
+
+
+@pytest.mark.skipif(not os.path.exists(W8A8_FIXTURE), reason="tests/golden/make_w8a8_emulation.py has not been run")
+def test_w8a8_full_size_batch64():
+    """BASELINE configs[4] as literally stated: LLaVA-v1.6-Mistral-7B shapes, every GEMM on e4m3 operands (operand_dtype="fp8"), 64 rows
+    per forward, on the e4m3-VALUED weight set.  W8A8 is not a parity mode: the bar is the quantisation-aware
+    emulation -- the oracle with the engine's operand quantisation -- and, because an e4m3 model is chaotic in its inputs, the
+    distance between two such emulations (with / without the f16 storage rounding) is the yardstick.  Row 0 is the golden row;
+    the other 63 carry other pixels.  Also: finite, deterministic, and a row's reward is the same alone as in the batch."""
+    fx = json.load(open(W8A8_FIXTURE))
+    g = json.load(open(os.path.join(GOLD, fx["row_golden"] + ".json")))
+    cfg = synth.LlavaConfig.from_json(g["config"])
+    B = 64
+    one = synth.llava_synth_batch(cfg, g["seed"], g["caption_lens"], [tuple(x) for x in g["image_sizes"]], max_crops=g["max_crops"])
+    ids = torch.from_numpy(np.repeat(one["input_ids"], B, axis=0)).cuda()
+    mask = torch.from_numpy(np.repeat(one["attention_mask"], B, axis=0)).cuda()
+    sizes = torch.from_numpy(np.repeat(one["image_sizes"], B, axis=0))
+    pix = torch.randn((B,) + one["pixel_values"].shape[1:], device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    pix[0] = torch.from_numpy(one["pixel_values"][0]).cuda()
+    m = RewardModel(cfg, synth_seed=g["seed"], max_batch=B, max_seq=ids.shape[1], max_crops=5, operand_dtype="fp8",
+                    synth_profile=g["weight_profile"]).to("cuda").eval()
+    kw = dict(input_ids=ids, attention_mask=mask, pixel_values=pix, image_sizes=sizes)
+    r, _ = m.custom_forward(inputs_batch=kw)
+    r2, _ = m.custom_forward(inputs_batch=kw)
+    r0, _ = m.custom_forward(inputs_batch={k: v[:1] for k, v in kw.items()})
+    torch.cuda.synchronize()
+    emu, twin, ref = fx["w8a8"][0], fx["w8a8_twin"][0], g["reward"][0][0]
+    got = float(r[0, 0])
+    print(f"[w8a8 LLaVA-7B B=64] row 0 hip {got:.5f}  emulation {emu:.5f}  twin emulation {twin:.5f}  fp32 reference {ref:.5f}")
+    assert r.shape == (B, 1) and torch.isfinite(r).all() and torch.equal(r, r2) and torch.equal(r0[0], r[0])
+    assert abs(got - emu) < 3.0 * max(abs(twin - emu), 1e-2)

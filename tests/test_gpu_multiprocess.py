@@ -50,5 +50,5 @@ def test_bench_two_ranks_on_one_device(tmp_path):
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 4 and res["scaling"] == "weak" and res["value"] > 0
     assert res["config"]["collective"].startswith("all_gather")
     # a failing child is this command's failure
-    bad = subprocess.run(cmd + ["--dtype", "no-such-dtype"], capture_output=True, text=True, timeout=600, env=env)
+    bad = subprocess.run(cmd + ["--model", "qwen", "--config", "gpm_pairwise"], capture_output=True, text=True, timeout=600, env=env)   # rejected by the ranks
     assert bad.returncode != 0
