@@ -15,9 +15,11 @@ algorithms:
   * torch.nn.functional.interpolate(mode='bicubic', align_corners=False): cubic convolution with A = -0.75, source index
     scale * (o + 0.5) - 0.5, border taps clamped (ATen UpSampleKernel / UpSample.h).
 Pinning: the resampler restatement is checked bit-for-bit against Pillow itself (tests/test_preprocess_oracle.py, Pillow
-12.2 in this image and on the GPU box) and the bicubic restatement against torch on CPU (1e-6); HD_transform's own glue
-(scale search, padding, transposition) has no vector in the reference (it holds no tests) and cannot be imported (it needs
-torchvision): "glue unpinned", restated line by line.
+12.2 in this image and on the GPU box) and the bicubic restatement against torch on CPU (1e-6); the glue (scale search,
+padding, transposition, tiling, zero crops, token count) is pinned against the reference's own Phi3VImageProcessor.preprocess,
+imported in the build container with a PIL-backed stand-in for the five torchvision entry points it uses
+(tests/golden/make_preprocess_goldens.py reference_processor: every pre_*.json digest is that function's output; what is pinned
+under it is Pillow's resampler, which torchvision calls for PIL inputs, not torchvision's tensor path).
 """
 from __future__ import annotations
 

@@ -103,6 +103,32 @@ def test_weight_profiles_device_equals_numpy(profile):
     assert err < TOL_X2
 
 
+def test_outlier_channel_calibration_keeps_parity_and_batch_invariance():
+    """model.calibrate (lr_calibrate): on the outlier-bearing weight set the decoder's norm outputs carry massive channels, so their
+    GEMMs get hot blocks (16-bit residuals there); the rewards stay within the default form's tolerance of the oracle, a row's
+    reward stays independent of the batch it is scored in (the lists are static), and a benign weight set gets no hot blocks."""
+    cfg = synth.tiny_config(hidden=1024, intermediate=2048, heads=16, layers=3)
+    seed = 19
+    batch = synth.synth_batch(cfg, seed, [7, 3, 5], [(1, 1), (1, 2), (2, 1)], max_crops=4)
+    kw = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
+    for profile, expect_hot in ((synth.PROFILE_OUTLIER, True), (0, False)):
+        W = orc.weights_to_torch(synth.make_weights(cfg, seed, profile))
+        ref = orc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"])
+        m = _model(cfg, seed, "f16x2f8", upload=False, profile=profile)
+        m.engine.set_gemm_tile(6)                  # the e4m3 residual form on every GEMM of this small config
+        before = _fwd(m, batch)
+        n = m.calibrate(kw)
+        after = _fwd(m, batch)
+        print(f"[calibrate, profile {profile}] {n} operands with hot blocks; err before {(before - ref).abs().max().item():.2e} after {(after - ref).abs().max().item():.2e}")
+        assert (n > 0) == expect_hot
+        assert (after - ref).abs().max().item() < TOL_X8
+        assert torch.equal(_fwd(m, batch), after)
+        for b in range(3):
+            assert torch.equal(_fwd(m, batch, rows=slice(b, b + 1))[0], after[b])
+        if not expect_hot:
+            assert torch.equal(before, after)
+
+
 def test_stage_taps_tiny():
     """Localise divergences: CLIP output, projected vision tokens, residual stream after the stack."""
     cfg = synth.tiny_config()
