@@ -240,7 +240,8 @@ def golden_check(model, model_name, name=None, current=(1234, 0)):
     e4m3-valued weight sets) with the engine that was just timed -- its weights re-synthesised per (seed, weight profile), the timed
     set restored afterwards -- and report |reward - reference| per golden and the maximum.  name: one golden only."""
     from llava_reward_amd import synth
-    per, worst, cur = {}, None, current
+    per, worst, cur, forms = {}, None, current, {}
+    calibrate = model._opts["operand_dtype"] == "f16x2f8"
     head = (bool(model.is_general_preference), int(model.value_head_dim), bool(model.add_cross_attention))
     for g in _goldens(model_name):
         if name and g["name"] != name:
@@ -252,10 +253,13 @@ def golden_check(model, model_name, name=None, current=(1234, 0)):
                 or b["input_ids"].shape[1] > model.engine.max_seq:
             continue
         want = (g["seed"], g.get("weight_profile", 0))
+        tb = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
         if want != cur:
             model.engine.synth_weights(want[0], getattr(model, "synth_fp32_valued", False), want[1])
             cur = want
-        tb = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+            if calibrate:        # what a user does once after loading weights: the default form checked against the strict one on them
+                info = model.calibrate(tb if model_name == "phi3v" else {"inputs_batch": tb})
+                forms[g["name"]] = dict(info)
         if model_name == "phi3v":
             r, _ = model.custom_forward(tb["input_ids"], tb["attention_mask"], tb["pixel_values"], tb["image_sizes"])
         else:
@@ -267,12 +271,17 @@ def golden_check(model, model_name, name=None, current=(1234, 0)):
             worst = g["name"]
     if cur != current:
         model.engine.synth_weights(current[0], getattr(model, "synth_fp32_valued", False), current[1])
+        if calibrate:
+            model.engine.clear_calibration()
+            model.operand_form = "default"
     if not per:
         return None
     benign = {k: v for k, v in per.items() if "outlier" not in k}
     return {"golden": f"{len(per)} full-size goldens (reference fp32 CPU custom_forward; tests/golden/{GOLDEN_GLOBS[model_name]})",
             "abs_err": per[worst], "worst": worst, "per_golden": per, "max_abs_err_benign_weights": max(benign.values()) if benign else None,
-            "tolerance": 1e-3}
+            "calibrate": forms or None, "tolerance": 1e-3,
+            "note": "weights re-synthesised per golden; default-mode engines run model.calibrate() on each new weight set (the self-check a user runs "
+                    "once after loading: default form vs strict form on the loaded weights) and score in the form it selects"}
 
 
 def main():

@@ -181,10 +181,12 @@ int lr_read_tap(lr_handle h, const char* name, float* host_out, size_t capacity,
 /* Stop after `n_clip_layers` / `n_layers` (-1 = all); for stage-wise parity tests. */
 int lr_set_layer_limits(lr_handle h, int n_clip_layers, int n_layers);
 /* Operand form per stage (default: lr_model_desc.precise everywhere).  Forms: -1 = the descriptor's, 0 = single-pass operands,
- * 1 = split operands with 16-bit residual passes, 2 = split operands with e4m3 residual passes; a stage can only take a split form
- * the handle was created with.  clip_form: the vision tower (CLIP; the Qwen ViT ignores it).  Decoder layers
- * [decoder_first, layers - decoder_last) take decoder_mid_form, the first / last ones the descriptor's.  A measurement knob
- * (tools/prec_map_probe.py): the product default is the descriptor's form in every stage. */
+ * 1 = split operands with 16-bit residual passes (the strict form), 2 = split operands with e4m3 residual passes; a stage can only
+ * take a split form the handle was created with.  clip_form: the vision tower (CLIP / the Qwen ViT, up to the projector / merger).
+ * Decoder layers [decoder_first, layers - decoder_last) take decoder_mid_form, the first / last ones the descriptor's.  Two uses:
+ * (1) a handle created with precise == 2 can run the strict form (1, 1, 0, 0) without being rebuilt -- what the Python layer's
+ * calibrate() switches to when the default form's rewards sit further from the strict form's than its parity budget on the
+ * caller's own weights and data; (2) measurements (tools/prec_map_probe.py). */
 int lr_set_precision_map(lr_handle h, int clip_form, int decoder_mid_form, int decoder_first, int decoder_last);
 /* Outlier-channel calibration of the default parity form (lr_model_desc.precise == 2).  An e4m3 residual carries 4 significant bits:
  * enough for ordinary activations (f16 hi + e4m3 lo = 15 bits per element), not for the few channels of MASSIVE activations trained

@@ -674,7 +674,6 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
             gemm(h, st, h->clip_h, c.fc1_w, h->clip_ff, c.fc1_b, Rc, Mc, Hc, Hc, Hc, Mc, EPI_OUT_OP, ACT_QUICK_GELU, nullptr, c.fc2_w, Hc);
             gemm(h, st, h->clip_ff, c.fc2_w, h->clip_x, c.fc2_b, Rc, Hc, Mc, Mc, Mc, Hc, EPI_RESADD_F32, ACT_NONE);
         }
-        h->set_form(-1);
         if (h->llava) {
             // ---- per-token projector, then anyres packing (modeling_llava_next.py get_image_features/pack_image_features) ----
             launch_clip_tokens(h->clip_x, h->hdA, NC, T, Hc, h->op_dt, st, h->prec);
@@ -687,6 +686,7 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
             gemm(h, st, h->hdA, h->p0_w, h->proj1, h->p0_b, SV, D, 4 * Hc, 4 * Hc, 4 * Hc, D, EPI_OUT_OP, ACT_GELU_ERF, nullptr, h->p2_w, D);
             gemm(h, st, h->proj1, h->p2_w, h->ev, h->p2_b, SV, D, D, D, D, D, EPI_OUT_F32, ACT_NONE);
         }
+        h->set_form(-1);          // (the vision stage's operand form, lr_set_precision_map, covers the projector)
         // ---- embeddings, positions (modeling_phi3_v.py:228-249, rw_model:344-345 | llava: masked_scatter, arange positions) ----
         const int Rl = B * S;
         launch_token_plan(input_ids, attention_mask, B, S, d_voff, h->img_row, h->pos_ids, h->tstat, st,

@@ -321,6 +321,7 @@ extern "C" int lr_forward_qwen(lr_handle h, const int64_t* input_ids, const int6
         h->lastB = B; h->lastS = S; h->lastP = N; h->lastSV = M;
 
         // ---- ViT (Qwen2_5_VisionTransformerPretrainedModel.forward), window order throughout ----
+        h->set_form(h->pm_clip);          // lr_set_precision_map: the vision tower's operand form
         launch_qwen_patch_gather(pixel_values, pix_dtype == LR_DT_F32 ? DT_F32 : DT_BF16, d_src, N, h->vK, h->vKpad, h->vA, h->op_dt, st, h->prec);
         gemm(h, st, h->vA, h->vpatch_w, h->vx, nullptr, N, vH, h->vKpad, h->vKpad, h->vKpad, vH, EPI_OUT_F32, ACT_NONE);
         launch_vit_rope_table(d_hw, N, h->vinv, h->vhd / 4, vhdp / 2, h->vcs, st);
@@ -359,6 +360,7 @@ extern "C" int lr_forward_qwen(lr_handle h, const int64_t* input_ids, const int6
         gemm(h, st, h->vhn, h->m0_w, h->vm1, h->m0_b, M, vHm, vHm, vHm, vHm, vHm, EPI_OUT_OP, ACT_GELU_ERF, nullptr, h->m2_w, D);
         gemm(h, st, h->vm1, h->m2_w, h->ev, h->m2_b, M, D, vHm, vHm, vHm, D, EPI_OUT_F32, ACT_NONE);
 
+        h->set_form(-1);
         // ---- embeddings + 3-D positions (Qwen2_5_VLModel.forward: masked_scatter, get_rope_index) ----
         const int Rl = B * S;
         // token_plan fills tstat (last / first valid index); its slot ranks are superseded by qwen_plan, so the offsets are don't-cares

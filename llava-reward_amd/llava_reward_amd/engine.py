@@ -255,6 +255,12 @@ class RewardEngine:
         L.check(self.lib, self.lib.lr_calibrate(self.h, 0, 0.0, row_fraction, C.byref(n)), self.h, "lr_calibrate(end)")
         return n.value
 
+    def clear_calibration(self) -> None:
+        """Forget the hot-block lists and return every stage to the descriptor's operand form."""
+        self.calibrate_begin()
+        self.calibrate_end()
+        self.set_precision_map(-1, -1, 0, 0)
+
     def set_gemm_tile(self, tile: int) -> None:
         L.check(self.lib, self.lib.lr_set_gemm_tile(self.h, tile), self.h, "lr_set_gemm_tile")
 
