@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r3f
-timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -8 > gpurun_out/r3f/pytest.log; tail -4 gpurun_out/r3f/pytest.log
+echo skip-tests
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r3f/kstats -- python3 $R/bench.py --steps 3 --warmup 1 --quick --no-cpu-baseline > $R/gpurun_out/r3f/kstats.log 2>&1)
 f=$(ls gpurun_out/r3f/kstats/*/*kernel_stats.csv | head -1); cp $f gpurun_out/r3f/r3_bench_kernel_stats_default.csv; head -8 $f | cut -c1-160
 bash tools/pmc_run.sh r3f/pmc "mixed" 2>&1 | tail -3
