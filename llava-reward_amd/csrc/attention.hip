@@ -370,20 +370,26 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
             if (act(0)) qk(0);
             for (int t = 0; t < ntiles; ++t) {
                 // ---- vector segment ----
+#if !(defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 8))          // diagnostic 8: no DMA in the loop (tiles 0, 1 only), results invalid
                 if (t + 2 < ntiles) issue(t + 2);         // (the issuing group only)
+#endif
                 if (act(t)) soft(t);
                 if (!PREC && grp == 0) {
                     if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPT) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
+#if !(defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 4))          // diagnostic 4: no barriers in the loop, results invalid
                 __syncthreads();
+#endif
                 // ---- matrix segment ----
                 __builtin_amdgcn_s_setprio(1);            // the wave in its matrix segment goes first (2-4 % on every shape)
                 if (act(t)) pv(t);
                 if (t + 1 < ntiles && act(t + 1)) qk(t + 1);
                 __builtin_amdgcn_s_setprio(0);
                 if (PREC && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !(defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 4))
                 if (t + 1 < ntiles || grp == 0) __syncthreads();
+#endif
             }
         }
     } else {

@@ -4,7 +4,10 @@ sys.path.insert(0, os.path.join(ROOT, "llava-reward_amd")); sys.path.insert(0, o
 import torch
 from llava_reward_amd import _lib as L
 libs = {"new": L.load()}
-for k, f in (("no_softmax", "lib_attd1.so"), ("no_lds_reads", "lib_attd2.so"), ("mfma_only", "lib_attd3.so")):
+# LR_ATT_DIAG bits: 1 no softmax arithmetic, 2 no LDS fragment reads, 4 no barriers in the loop, 8 no DMA in the loop
+for v, k in ((1, "no_softmax"), (2, "no_lds_reads"), (3, "skeleton(1+2)"), (7, "skeleton_no_barriers(1+2+4)"), (11, "skeleton_no_dma(1+2+8)"),
+             (15, "mfma_loop_only(1+2+4+8)")):
+    f = f"lib_attd{v}.so"
     if os.path.exists(os.path.join(ROOT, "tools", "dbg", f)):
         libs[k] = L.load(os.path.join(ROOT, "tools", "dbg", f))
 def bench(lib, B, S, H, hd, causal, Hkv, reps=5):
