@@ -95,7 +95,8 @@ class RewardModel:
              what the default form can carry (outlier-bearing weight sets do: 15-25x) and the engine STAYS in the
              strict form from then on; else it returns to the default form.
         Returns {"form": "default" | "strict", "default_vs_strict": max |difference|, "hot_operands": n}.  Static afterwards: a row's
-        reward stays independent of the batch it is scored in.  No reference counterpart (the reference runs fp32 / bf16 operands)."""
+        reward stays independent of the batch it is scored in.  Under torch.distributed call it on every rank with the SAME batches
+        (the decision is all-reduced; identical batches also give identical hot-block lists).  No reference counterpart (the reference runs fp32 / bf16 operands)."""
         if self.engine is None:
             raise RuntimeError("calibrate: model is on CPU; call model.to('cuda') first")
         if self._opts["operand_dtype"] != "f16x2f8":
@@ -114,6 +115,13 @@ class RewardModel:
         eng.set_precision_map(1, 1, 0, 0)
         strict = [self.custom_forward(**b)[0].float() for b in batches]
         d = max((float((a - s).abs().max()) for a, s in zip(default, strict)), default=0.0)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # every rank must end in the same form (rewards are bit-identical across shardings only then): give every rank the SAME
+            # batches -- the hot-block lists are then identical too -- and take the largest distance any rank saw
+            t = torch.tensor([d], dtype=torch.float64, device=self.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d = float(t.item())
         self.operand_form = "strict" if d > parity_budget else "default"
         if self.operand_form == "default":
             eng.set_precision_map(-1, -1, 0, 0)
