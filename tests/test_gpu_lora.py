@@ -173,3 +173,38 @@ def test_loader_to_engine_phi3v(tmp_path):
     args2, merged = load_reward_adaptor(args2, "phi3v", os.path.join(pm, "reward_config.yaml"))
     gm, _ = merged.to("cuda").eval().custom_forward(tb["input_ids"], tb["attention_mask"], tb["pixel_values"], tb["image_sizes"])
     assert (gm.cpu() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("backbone,rank", [("phi3v", 128), ("qwen", 8)])
+def test_unmerged_adapter_with_hot_blocks_and_calibration(backbone, rank):
+    """Un-merged adapters on the outlier-bearing weight set.  (1) With a budget that keeps the default form, calibrate() marks hot
+    blocks: the norm outputs carry massive channels, so the base GEMM AND the adapter's t = x A^T GEMM (same operand rows) take the
+    hot blocks' 16-bit residual segments -- the forward runs, is bit-stable and stays near the oracle (evaluated un-merged).  (2) The
+    outlier adapters inject further massive channels (a 50-sigma element of B puts t straight into one output channel), so this model
+    amplifies rounding beyond the default form's budget (5e-4 / 3e-3 measured): with the standard budget calibrate() keeps the engine
+    strict, and the rewards are on the oracle."""
+    seed = 41
+    if backbone == "phi3v":
+        cfg = synth.tiny_config(lora_rank=rank, hidden=1024, intermediate=2048, heads=16, layers=3)
+        Wn = synth.make_weights(cfg, seed, synth.PROFILE_OUTLIER)
+        batch = synth.synth_batch(cfg, seed, [7, 3, 5], (1, 1))
+        ref = orc.custom_forward(orc.weights_to_torch(Wn), cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"])
+    else:
+        cfg = synth.qwen_tiny_config(lora_rank=rank, hidden=1024, intermediate=2048, heads=8, kv_heads=2)
+        Wn = synth.qwen_make_weights(cfg, seed, synth.PROFILE_OUTLIER)
+        batch = synth.qwen_synth_batch(cfg, seed, [7, 3, 5], [(16, 16), (10, 6), (18, 22)])
+        ref = qorc.custom_forward(orc.weights_to_torch(Wn), cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_grid_thw"])
+    m = RewardModel(cfg, weights={k: torch.from_numpy(v) for k, v in Wn.items()}, max_batch=4, max_seq=1024, max_crops=5, max_patches=4096).to("cuda").eval()
+    m.engine.set_gemm_tile(6)
+    tb = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
+    kw = tb if backbone == "phi3v" else {"inputs_batch": tb}
+    before = m.custom_forward(**kw)[0].cpu()
+    info = m.calibrate(kw, parity_budget=1.0)          # (a budget that keeps the default form: the hot blocks' own path)
+    after = m.custom_forward(**kw)[0].cpu()
+    print(f"[lora + hot blocks, {backbone}] {info}; err before {(before - ref).abs().max().item():.2e} after {(after - ref).abs().max().item():.2e}")
+    assert info["hot_operands"] > 0 and info["form"] == "default" and (after - ref).abs().max().item() < 5e-3
+    assert torch.equal(m.custom_forward(**kw)[0].cpu(), after)
+    info = m.calibrate(kw)
+    strict = m.custom_forward(**kw)[0].cpu()
+    print(f"[lora + calibrate, {backbone}] {info}; err {(strict - ref).abs().max().item():.2e}")
+    assert info["form"] == "strict" and (strict - ref).abs().max().item() < TOL["f16x2f8"]
