@@ -6,7 +6,12 @@ writes holds data only: config, seed, input recipe and the reference's outputs. 
 are regenerated anywhere from (config, seed) by llava_reward_amd.synth, so nothing large is stored.
 
     python tests/golden/make_goldens.py small        # ref_small_* cases (minutes)
-    python tests/golden/make_goldens.py full         # full-size Phi-3.5-V, B=1 (~20 min, ~35 GB RSS)
+    python tests/golden/make_goldens.py full         # full-size Phi-3.5-V, B=1 (~5-10 min, ~35 GB RSS: one full-size job at a time)
+    ... full_b2 | full_seed1..5 | full_gpm | pair_sample        more full-size Phi rows (B=2 ragged with 64-element taps; seeds / grids)
+    ... outlier_small | outlier_full | outlier_full_gpm          outlier-bearing weights (synth.PROFILE_OUTLIER)
+    ... e4m3_small | llava_full_e4m3                             e4m3-valued weights (synth.PROFILE_E4M3; BASELINE configs[4])
+    ... llava | llava_full | llava_full_seed1..2 | llava_full_outlier | qwen | qwen_full | qwen_full_seed1..2 | qwen_full_outlier
+    ... mean | layer_id | rope_long | rope_at_orig | train                           the small special cases
 
 Import recipe = SURVEY.md Appendix A (stubs for deepspeed/peft/loralib, use_cache=False, eager
 attention, un-patched get_img_features == hidden_states[-2][:,1:]).
