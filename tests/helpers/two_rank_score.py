@@ -16,7 +16,7 @@ import torch.distributed as dist  # noqa: E402
 
 from llava_reward_amd import synth  # noqa: E402
 from llava_reward_amd.model import RewardModel  # noqa: E402
-from llava_reward_amd.scoring import score_candidates, score_pairwise  # noqa: E402
+from llava_reward_amd.scoring import score_candidates, score_pairwise, score_pairwise_files  # noqa: E402
 
 
 def batches(cfg, seed):
@@ -45,7 +45,12 @@ def main():
     # a population of 5 candidate images for one prompt (reward-guided sampling): in memory, on the GPU, sharded 3 + 2 over two ranks
     cands = [torch.from_numpy(synth.synth_image(seed, f"cand.{i}", 336, 336)).cuda() for i in range(5)]
     cr = score_candidates(model, synth.StandInTokenizer(), "a photo of a cat", cands, num_crops=1, batch_size=2, pad_token_id=cfg.vocab_size - 1)
-    json.dump({"rank": rank, "probs": res["probs"], "proportion": res["proportion"], "candidates": cr.cpu().tolist()}, open(out_path, "w"))
+    # the files-to-rewards loop: 5 (caption, chosen, rejected) triples, sharded 3 + 2 BEFORE anything is decoded, prefetched batches of 2;
+    # same-sized images so that every row sees the same V_max whatever its shard (the reference's SkipCA attends over padded rows)
+    pairs = [(f"caption {i}", synth.synth_image(seed, f"c.{i}", 200, 300), synth.synth_image(seed, f"r.{i}", 200, 300)) for i in range(5)]
+    fr = score_pairwise_files(model, args, synth.StandInTokenizer(), pairs, batch_size=2, num_crops=1, pad_token_id=cfg.vocab_size - 1)
+    json.dump({"rank": rank, "probs": res["probs"], "proportion": res["proportion"], "candidates": cr.cpu().tolist(), "file_probs": fr["probs"]},
+              open(out_path, "w"))
     if ws > 1:
         dist.barrier()
         dist.destroy_process_group()

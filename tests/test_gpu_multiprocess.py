@@ -35,6 +35,7 @@ def test_two_rank_processes_on_one_gpu_equal_single_process(tmp_path):
         got = json.load(open(outs[r]))
         assert got["rank"] == r and got["probs"] == ref["probs"] and got["proportion"] == ref["proportion"]      # bit-identical on every rank
         assert len(got["candidates"]) == 5 and got["candidates"] == ref["candidates"]                            # score_candidates: sharded 3 + 2
+        assert len(got["file_probs"]) == 5 and got["file_probs"] == ref["file_probs"]                            # score_pairwise_files: pairs sharded 3 + 2
 
 
 def test_bench_two_ranks_on_one_device(tmp_path):
