@@ -240,8 +240,8 @@ def golden_check(model, model_name, name=None, current=(1234, 0)):
     e4m3-valued weight sets) with the engine that was just timed -- its weights re-synthesised per (seed, weight profile), the timed
     set restored afterwards -- and report |reward - reference| per golden and the maximum.  name: one golden only."""
     from llava_reward_amd import synth
-    per, worst, cur, forms = {}, None, current, {}
-    calibrate = model._opts["operand_dtype"] == "f16x2f8"
+    per, worst, cur, forms, per_default = {}, None, current, {}, {}
+    default_mode = model._opts["operand_dtype"] == "f16x2f8"
     head = (bool(model.is_general_preference), int(model.value_head_dim), bool(model.add_cross_attention))
     for g in _goldens(model_name):
         if name and g["name"] != name:
@@ -255,33 +255,43 @@ def golden_check(model, model_name, name=None, current=(1234, 0)):
         want = (g["seed"], g.get("weight_profile", 0))
         tb = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
         if want != cur:
+            # new weights behind the handle: the next custom_forward notices (lr_weights_epoch) and locks the operand form again on ITS
+            # probe rows, exactly as .to('cuda') does for a freshly loaded checkpoint -- nothing is called here that a user would not call
             model.engine.synth_weights(want[0], getattr(model, "synth_fp32_valued", False), want[1])
             cur = want
-            if calibrate:        # what a user does once after loading weights: the default form checked against the strict one on them
-                info = model.calibrate(tb if model_name == "phi3v" else {"inputs_batch": tb})
-                forms[g["name"]] = dict(info)
-        if model_name == "phi3v":
-            r, _ = model.custom_forward(tb["input_ids"], tb["attention_mask"], tb["pixel_values"], tb["image_sizes"])
-        else:
-            r, _ = model.custom_forward(inputs_batch=tb)
-        torch.cuda.synchronize()
+
+        def score():
+            if model_name == "phi3v":
+                r, _ = model.custom_forward(tb["input_ids"], tb["attention_mask"], tb["pixel_values"], tb["image_sizes"])
+            else:
+                r, _ = model.custom_forward(inputs_batch=tb)
+            torch.cuda.synchronize()
+            return r.cpu()
         ref = torch.tensor(g["reward"], dtype=torch.float32)
-        per[g["name"]] = (r.cpu().reshape(ref.shape) - ref).abs().max().item()
+        per[g["name"]] = (score().reshape(ref.shape) - ref).abs().max().item()
+        if default_mode:
+            forms[g["name"]] = dict(model.form_info) if model.form_info else None
+            if model.operand_form != "default":      # what the default form would have given on this weight set (reported, never used)
+                model.engine.set_precision_map(-1, -1, 0, 0)
+                try:
+                    per_default[g["name"]] = (score().reshape(ref.shape) - ref).abs().max().item()
+                finally:
+                    model._apply_form()
+            else:
+                per_default[g["name"]] = per[g["name"]]
         if worst is None or per[g["name"]] > per[worst]:
             worst = g["name"]
     if cur != current:
-        model.engine.synth_weights(current[0], getattr(model, "synth_fp32_valued", False), current[1])
-        if calibrate:
-            model.engine.clear_calibration()
-            model.operand_form = "default"
+        model.engine.synth_weights(current[0], getattr(model, "synth_fp32_valued", False), current[1])      # (the next forward re-locks the form)
     if not per:
         return None
     benign = {k: v for k, v in per.items() if "outlier" not in k}
     return {"golden": f"{len(per)} full-size goldens (reference fp32 CPU custom_forward; tests/golden/{GOLDEN_GLOBS[model_name]})",
             "abs_err": per[worst], "worst": worst, "per_golden": per, "max_abs_err_benign_weights": max(benign.values()) if benign else None,
-            "calibrate": forms or None, "tolerance": 1e-3,
-            "note": "weights re-synthesised per golden; default-mode engines run model.calibrate() on each new weight set (the self-check a user runs "
-                    "once after loading: default form vs strict form on the loaded weights) and score in the form it selects"}
+            "operand_form": forms or None, "per_golden_if_default_form_were_forced": per_default or None, "tolerance": 1e-3,
+            "note": "weights re-synthesised per golden through the bare drop-in sequence: the engine locks its operand form on each new weight "
+                    "set by itself (seeded probe rows, default form vs strict form, no reference) and scores in that form; "
+                    "per_golden_if_default_form_were_forced = the same rows with the default form pinned (reported only)"}
 
 
 def main():
@@ -298,7 +308,11 @@ def main():
                     help="bt = BASELINE configs[1] (BT head, B=32): the metric; gpm_pairwise = configs[2]: GPM head d=2 + SkipCA, a step = chosen and "
                          "rejected forward of B=64 rows each + preference_compute (reports preference-pairs/s beside reward-pairs/s)")
     ap.add_argument("--lora-rank", type=int, default=0, help="run the main workload with an un-merged rank-r adapter on the decoder linears")
-    ap.add_argument("--quick", action="store_true", help="main line only: no secondary legs (for profiler runs)")
+    ap.add_argument("--quick", action="store_true", help="main line only: no secondary legs and no golden sweep -- only the timed workload's "
+                                                          "launches (plus the dominant-kernel probe's) reach a profiler")
+    ap.add_argument("--no-golden", action="store_true", help="skip the live golden sweep (parity_check)")
+    ap.add_argument("--profile-weights", default="", choices=["", "outlier", "e4m3"], help="synthetic weight profile of the main workload "
+                    "(synth.PROFILE_*): outlier = massive channels / large norm gains, what trained checkpoints show")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the secondary single-pass f16 measurement")
     ap.add_argument("--no-other-backbones", action="store_true", help="skip the Qwen2.5-VL-7B / LLaVA-1.6-7B sub-lines of the default run")
     ap.add_argument("--tile", type=int, default=-1)
@@ -387,14 +401,14 @@ def main():
         mask = torch.from_numpy(gb["attention_mask"][rows]).cuda()
         return dict(model=model_name, cfg=cfg, B=B, S=ids.shape[1], ids=ids, mask=mask, pix=pix, sizes=sizes, ncrop=ncrop, flop=flop, name=name)
 
-    def build_model(w, dtype, fp32_valued=False):
+    def build_model(w, dtype, fp32_valued=False, profile=0):
         cfg, B, S = w["cfg"], w["B"], w["S"]
         if w["model"] == "qwen":
             m = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=max(S, GOLDEN_MAX_SEQ.get("qwen", 0)), max_patches=max(B * 32 * 32, 2048),
-                            operand_dtype=dtype)
+                            operand_dtype=dtype, synth_profile=profile)
         else:
             m = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=max(S, GOLDEN_MAX_SEQ.get(w["model"], 0)),
-                            max_crops=max(w["ncrop"], 5 if w["model"] == "llava" else 17), operand_dtype=dtype)
+                            max_crops=max(w["ncrop"], 5 if w["model"] == "llava" else 17), operand_dtype=dtype, synth_profile=profile)
         m.synth_fp32_valued = fp32_valued
         m = m.to(f"cuda:{local}").eval()
         if a.tile >= 0:
@@ -427,7 +441,8 @@ def main():
     w = workload(a.model, B, a.num_crops, gpm=pairwise, lora_rank=a.lora_rank)
     cfg, S, flop_per_pair = w["cfg"], w["S"], w["flop"]
     precise = "x2" in a.dtype
-    model = build_model(w, a.dtype)
+    main_profile = synth.PROFILE_NAMES[a.profile_weights]
+    model = build_model(w, a.dtype, profile=main_profile)
     if pairwise:       # the rejected image of every pair: other pixels, same caption
         pix_r = torch.randn(w["pix"].shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4321 + rank))
     pargs = type("A", (), dict(is_general_preference=cfg.is_general_preference, value_head_dim=cfg.value_head_dim,
@@ -475,6 +490,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": f"{a.dtype} MFMA operands (bf16-valued weights), f32 accumulate/residual/softmax",
+            "operand_form": dict(model.form_info) if model.form_info else None,
             "data": "synthetic (seeded weights and inputs; no checkpoint offline)",
             "hbm_bytes": {"workspace": model.engine.workspace_bytes(), "note": "activation workspace sized for (rows_per_gpu, seq_len) at lr_finalize; weights "
                           "(operand copies + residual / e4m3 twins in the split-operand modes) are extra"},
@@ -493,7 +509,7 @@ def main():
         headline = a.model == "phi3v" and a.num_crops == 16 and not pairwise and not a.lora_rank
         if world == 1:
             full = (a.model != "phi3v" or a.num_crops == 16) and not a.lora_rank      # the golden rows: 17-crop images, no adapter
-            res["parity_check"] = golden_check(model, a.model) if full else None
+            res["parity_check"] = golden_check(model, a.model, current=(1234, main_profile)) if (full and not a.quick and not a.no_golden) else None
             if a.model == "phi3v" and a.num_crops == 16:
                 dk = dominant_kernel_probe(L.LR_DT_F16 if a.dtype.startswith("f16") else L.LR_DT_BF16, a.tile, split=precise, lo8=a.dtype == "f16x2f8")
                 # the roofline object proper: the dominant kernel, algorithmic FLOPs per launch / its live HIP-event duration
@@ -546,14 +562,15 @@ def main():
                         nb = sub_steps + 1
                         items = [(files[i % len(files)], cap) for i in range(nb * B)]
                         torch.cuda.synchronize()
-                        it = iter(PrefetchingBatcher(items, tok, batch_size=B, num_crops=a.num_crops, device=f"cuda:{local}", depth=2, workers=8))
-                        outs = [model.custom_forward(**next(it))[0]]          # warm-up batch (the producer is already filling the queue)
-                        torch.cuda.synchronize()
-                        t1 = time.perf_counter()
-                        for bt in it:
-                            outs.append(model.custom_forward(**bt)[0])
-                        torch.cuda.synchronize()
-                        ms_e2e = 1e3 * (time.perf_counter() - t1) / (nb - 1)
+                        with PrefetchingBatcher(items, tok, batch_size=B, num_crops=a.num_crops, device=f"cuda:{local}", depth=2, workers=8) as pb:
+                            it = iter(pb)
+                            outs = [model.custom_forward(**next(it))[0]]          # warm-up batch (the producer is already filling the queue)
+                            torch.cuda.synchronize()
+                            t1 = time.perf_counter()
+                            for bt in it:
+                                outs.append(model.custom_forward(**bt)[0])
+                            torch.cuda.synchronize()
+                            ms_e2e = 1e3 * (time.perf_counter() - t1) / (nb - 1)
                     assert all(torch.isfinite(o).all() for o in outs)
                     res["end_to_end"] = {"value": B / (ms_e2e * 1e-3), "unit": "reward-pairs/sec", "ms_per_step": ms_e2e, "vs_resident_inputs": (B / (ms_e2e * 1e-3)) / value,
                                          "what": f"{B} PNG files (336x336) per step from disk -> decode (8 threads) -> uint8 H2D -> lr_hd_transform on a side stream, "
@@ -561,17 +578,56 @@ def main():
             release(model)
             del model
 
-            def leg(wl, dtype, steps=sub_steps, fp32_valued=False, golden=None):
-                m = build_model(wl, dtype, fp32_valued)
+            def leg(wl, dtype, steps=sub_steps, fp32_valued=False, golden=None, profile=0):
+                m = build_model(wl, dtype, fp32_valued, profile)
                 ms = timed_steps(lambda: forward(m, wl), 1, steps)
                 out = {"dtype": dtype, "value": wl["B"] / (ms * 1e-3), "unit": "reward-pairs/sec", "ms_per_step": ms, "rows_per_step": wl["B"],
                        "workspace_bytes": m.engine.workspace_bytes(),
+                       "operand_form": dict(m.form_info) if m.form_info else None,
                        "roofline_frac_whole_pass": wl["B"] / (ms * 1e-3) * wl["flop"] / 1e12 / PEAK_TFLOPS}
-                if golden:
-                    out["parity_check"] = golden_check(m, wl["model"])
+                if golden and not a.no_golden:
+                    out["parity_check"] = golden_check(m, wl["model"], current=(1234, profile))
                 release(m)
                 return out
 
+            def golden_check_one(wl, dtype, golden_name, profile):
+                """One golden row on a small engine of its own (B = 2): weights of that golden, scored through the bare sequence."""
+                if a.no_golden:
+                    return None
+                g1 = [g for g in _goldens(wl["model"]) if g["name"] == golden_name]
+                if not g1:
+                    return None
+                wl1 = dict(wl, B=2)
+                m = build_model(wl1, dtype, profile=profile)
+                out = golden_check(m, wl["model"], name=golden_name, current=(1234, profile))
+                release(m)
+                return out
+
+            if headline and a.dtype == "f16x2f8":
+                # What the headline costs when the loaded weights do NOT let the default form through.  `value` above is the default
+                # form, which .to('cuda') kept because the benign N(0, 0.02) weight set passes its probe; outlier-bearing weights
+                # (massive channels, large norm gains: what trained checkpoints show) make the same call lock the strict form.
+                res["strict_form"] = dict(leg(w, "f16x2"), vs_headline=None,
+                                          note="the strict form (16-bit residual passes everywhere): what the engine runs when its probe rejects the default "
+                                               "form on the loaded weights")
+                res["strict_form"]["vs_headline"] = res["strict_form"]["value"] / value
+                # ... and the likely shape of a real LLaVA-Reward checkpoint: outlier-bearing weights AND the un-merged rank-128 adapter of the
+                # training recipes on every decoder linear, scored in whatever form the probe locks on them
+                wr = workload(a.model, B, a.num_crops, lora_rank=128)
+                rc = leg(wr, a.dtype, profile=synth.PROFILE_OUTLIER)
+                res["real_checkpoint"] = dict(rc, rank=128, weight_profile="outlier", vs_headline=rc["value"] / value,
+                                              note="synth.PROFILE_OUTLIER weights + un-merged LoRA r=128, through the bare sequence (.to('cuda') -> "
+                                                   "custom_forward); operand_form = what the probe locked")
+                # latency of ONE row (BASELINE configs[0] shape, eval/simple_inference.py: B = 1, 17 crops, S = 2642)
+                w1 = workload(a.model, 1, a.num_crops)
+                m1 = build_model(w1, a.dtype)
+                ms_sync = timed_steps(lambda: (forward(m1, w1), torch.cuda.synchronize()), 2, 10)
+                ms_b2b = timed_steps(lambda: forward(m1, w1), 2, 10)
+                res["latency_b1"] = {"ms_per_forward": ms_sync, "ms_per_forward_enqueued_back_to_back": ms_b2b, "rows": 1, "seq_len": w1["S"],
+                                     "operand_form": dict(m1.form_info) if m1.form_info else None,
+                                     "note": "one (caption, image) row per custom_forward call, synchronised after each call"}
+                release(m1)
+                del m1
             if headline and precise:
                 # what a real LLaVA-Reward checkpoint costs: every decoder linear carries the un-merged rank-128 adapter of the training
                 # recipes (scripts/run_train_rm_single_lora_phi.sh: --lora_rank 128 --lora_alpha 256, vision tower frozen)
@@ -605,6 +661,21 @@ def main():
                     if precise:      # what a real checkpoint of this backbone costs: un-merged rank-128 adapters on q/k/v/o/gate/up/down
                         ll = leg(workload(mname, bb, lora_rank=128), a.dtype)
                         res[mname]["lora_unmerged"] = dict(ll, rank=128, vs_plain=ll["value"] / res[mname]["value"])
+                    if mname == "llava" and a.dtype == "f16x2f8":
+                        # BASELINE configs[4] names an "fp8 MFMA weight path".  (1) its parity definition: the reference run on the
+                        # DE-QUANTISED weights of an e4m3-weight checkpoint (synth.PROFILE_E4M3) -- the default form scores that model
+                        # (f16 main pass, residual pass on the e4m3 twins) and is checked against the reference's golden row;
+                        e4 = leg(wl, a.dtype, profile=synth.PROFILE_E4M3)
+                        pc = golden_check_one(wl, a.dtype, "ref_llava_full_e4m3_bt", synth.PROFILE_E4M3)
+                        res[mname]["e4m3_valued_weights"] = dict(e4, parity_check=pc, note="default parity form on e4m3-VALUED weights (parity holds: "
+                                                                 "the golden row is the reference on the de-quantised weights)")
+                        # (2) the literal all-fp8 mode: every GEMM on e4m3 operands.  NOT a parity mode -- labelled with its distance to
+                        # the reference on the same golden row.
+                        w8 = leg(wl, "fp8", profile=synth.PROFILE_E4M3)
+                        pc8 = golden_check_one(wl, "fp8", "ref_llava_full_e4m3_bt", synth.PROFILE_E4M3)
+                        res[mname]["w8a8"] = dict(w8, parity="NOT A PARITY MODE", abs_err_vs_reference=pc8["abs_err"] if pc8 else None,
+                                                  note="operand_dtype='fp8': e4m3 x e4m3 on every GEMM with K % 128 == 0 (DESIGN.md §11); the reward moves "
+                                                       "by abs_err_vs_reference on the reference's golden row -- quantisation noise of a random-weight model")
             if precise and not a.no_fast_mode:
                 # secondary figure: the single-pass f16 mode of the same workload.  NOT a parity mode (noise-limited):
                 # it counts as a product number only where its live golden check says PASS.

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LR_ABI_VERSION 7
+#define LR_ABI_VERSION 8
 
 enum { LR_OK = 0, LR_EINVAL = 1, LR_EHIP = 2, LR_ESTATE = 3, LR_ENOTFOUND = 4, LR_ENOMEM = 5 };
 enum { LR_DT_BF16 = 0, LR_DT_F16 = 1, LR_DT_F32 = 2 };
@@ -117,6 +117,12 @@ typedef struct lr_model_desc {
      * t B^T rides in the K loop of the base GEMM (r rounded up to 64 extra columns), so the base weights stay bf16-exact and
      * the layer costs ~6 % more instead of the 33-50 % of merged (inexact) weights.  Not available with w8a8. */
     int32_t lora_rank;
+    /* ABI 8.  Which sequence length switches the su-RoPE tables from the short to the long factors (Phi-3-V only).  0 (default): the
+     * eager / sdpa attention classes pass seq_len = the padded length S (modeling_phi3_v.py:673, :1081) -> long factors iff
+     * S > original_max_position_embeddings.  1: Phi3FlashAttention2 (what every --flash_attn script of the reference runs) passes
+     * max(S, position_ids[:, -1].max()) + 1 (:793-794) = S + 1 -> long factors iff S >= original_max_position_embeddings.  The two
+     * differ at S == original_max (4096 for Phi-3.5-V) only. */
+    int32_t rope_flash_convention;
 } lr_model_desc;
 
 int lr_abi_version(void);
@@ -185,20 +191,13 @@ int lr_set_layer_limits(lr_handle h, int n_clip_layers, int n_layers);
  * take a split form the handle was created with.  clip_form: the vision tower (CLIP / the Qwen ViT, up to the projector / merger).
  * Decoder layers [decoder_first, layers - decoder_last) take decoder_mid_form, the first / last ones the descriptor's.  Two uses:
  * (1) a handle created with precise == 2 can run the strict form (1, 1, 0, 0) without being rebuilt -- what the Python layer's
- * calibrate() switches to when the default form's rewards sit further from the strict form's than its parity budget on the
- * caller's own weights and data; (2) measurements (tools/prec_map_probe.py). */
+ * operand-form probe (RewardModel.to) locks in when, on the loaded weights, the default form's rewards sit further from the strict
+ * form's than its parity budget; (2) measurements (tools/prec_map_probe.py).  The map survives weight uploads; callers that
+ * derive it from the weights re-derive it when lr_weights_epoch has moved. */
 int lr_set_precision_map(lr_handle h, int clip_form, int decoder_mid_form, int decoder_first, int decoder_last);
-/* Outlier-channel calibration of the default parity form (lr_model_desc.precise == 2).  An e4m3 residual carries 4 significant bits:
- * enough for ordinary activations (f16 hi + e4m3 lo = 15 bits per element), not for the few channels of MASSIVE activations trained
- * decoders carry in their residual stream (values ~1000x a row's typical magnitude: their 15-bit absolute error is as large as a
- * 5-bit error on everything else).  lr_calibrate(h, 1, ratio, ...) starts a calibration: every forward until lr_calibrate(h, 0, ...)
- * also counts, per GEMM operand and 128-column block, the rows in which the block holds |x| >= ratio x the row's mean |x|
- * (ratio 64 is a good default).  The closing call marks, per operand, up to 4 blocks that were hot in at least row_fraction of
- * the rows (e.g. 0.002); from then on their residuals travel in 16 bits (2 more K-tiles per hot block in that GEMM), everything else
- * stays e4m3.  The lists are static afterwards, so a row's reward stays independent of the batch it is scored in.  Forwards run
- * between the two calls compute normal rewards.  *n_sites_with_hot_blocks (may be NULL) = operands that got a list.
- * Weights that are not exact in the operand type (merged adapters) take no hot blocks. */
-int lr_calibrate(lr_handle h, int begin, float ratio, float row_fraction, int* n_sites_with_hot_blocks);
+/* Counts the calls that changed this handle's weights (lr_upload_weight, lr_synth_weights*): anything derived from the weights --
+ * the operand form the Python layer locks at .to('cuda') -- is stale once it has moved. */
+uint64_t lr_weights_epoch(lr_handle h);
 /* GEMM tile selection: -1 heuristic, 0 = 128x128, 1 = 256x128, 2 = 256x256. */
 int lr_set_gemm_tile(lr_handle h, int tile);
 
@@ -249,9 +248,6 @@ int lr_op_gemm_fp8(const void* A8, const float* ascale, const void* W8, const fl
  * and without flag 2.
  * Output as lr_op_gemm_bt_split.  K multiple of 128. */
 size_t lr_op_lo8_scratch_bytes(int M, int K);
-/* Hot blocks (see lr_calibrate) for the following lr_op_gemm_bt_mixed calls of this thread: up to 4 ascending 128-column block
- * indices of A whose residuals stay 16-bit (flag 2 moves them behind the e4m3 bytes); n = 0 clears.  Exact weights only. */
-int lr_op_set_hot_blocks(int n, const int* blocks);
 int lr_op_gemm_bt_mixed(void* A, const void* W, void* W8, void* scratch, void* C, const float* bias, int M, int N, int K, int epi, int act,
                         int operand_dtype, int flags, int* wexp, void* hip_stream);
 int lr_op_norm_rows(const float* x, const float* w, const float* b, void* y, int rows, int H, float eps,

@@ -185,7 +185,7 @@ struct GemmParams {
     // W2lo at column w_col + 64 i.  Segments are ordered 16-bit first (K-tiles [0, nk_f16)), then the e4m3 residual tiles
     // [nk_f16, nk_e1) scaled by aexp / wexp, then the e4m3 tiles [nk_e1, nk) scaled by aexp2 / wexp2.
     struct KSeg { int kt_end, src, a_col, w_col; };
-    enum : int { SRC_A2 = 1, SRC_W2 = 2, SRC_LO = 4, SRC_LO16 = 8, MAX_SEG = 12, MAX_HOT = 4 };
+    enum : int { SRC_A2 = 1, SRC_W2 = 2, SRC_LO = 4, SRC_LO16 = 8, MAX_SEG = 12 };
     int nseg, nk_f16, nk_e1, nk;
     KSeg seg[MAX_SEG];
     // persistent launches: tile scheduler words (launch8), 8 per-XCD claim counters + 1 count of finished workgroups, all zero
@@ -194,15 +194,7 @@ struct GemmParams {
     // ---- caller-provided storage for `sched`: 16 ints of DEVICE memory on the launch device, zero, used by one launch at a time
     // (an engine passes its own; null = the launcher keeps one set per (device, stream)) ----
     int* sched_mem;
-    // e4m3-residual form only: "hot" 128-column blocks of A (columns of massive activations, found by lr_calibrate) whose residuals
-    // are carried in 16 bits instead: block hotblk[j] of a row has its 16-bit residuals at 2-byte column kw + kw / 2 + 128 j (the
-    // second half of the residual space) and zeros in its e4m3 bytes; the K loop adds 2 K-tiles x_lo16 x W per hot block.
-    int nhot;
-    int hotblk[4];
 };
-
-// "hot" 128-column blocks of an operand (GemmParams::nhot): at most 4, ascending block indices
-struct HotBlocks { int n; int blk[4]; };
 
 struct AttnParams {
     const void* Q;  // operand dtype rows [b*S + t][ldq], head h at column qoff + h*HD

@@ -86,6 +86,7 @@ struct lr_engine {
     std::vector<int> inexact;
     size_t ws_bytes = 0, weight_bytes = 0;
     int gemm_tile = -1, lim_clip = -1, lim_layers = -1;
+    uint64_t weights_epoch = 0;        // lr_weights_epoch: bumped by every call that changes a weight
 
     // derived
     int T = 0, G = 0, Kpatch = 0, Kpad = 0, hd = 0, half = 0, Vcap = 0;
@@ -106,6 +107,9 @@ struct lr_engine {
     const void* pre_enc = nullptr;                   // operand buffer whose residual half its producer has already written in e4m3
     bool pre_enc_hi8 = false;                        // ... together with the e4m3 copy of its hi half (third e4m3 segment)
     std::unordered_map<const void*, void*> own8;     // adapter A matrices: weight base pointer -> its e4m3 twin in a buffer of its own
+    // weights that are NOT exact in the operand type: their rows [e4m3(W) | e4m3(W_lo)] live in a buffer of their own, so that the
+    // 16-bit residuals stay intact in the residual twin and the handle can still run the strict form (lr_set_precision_map)
+    std::unordered_map<const void*, void*> pair8;
     int lora_rp = 0, lora_k2max = 0;                 // adapter rank padded to a K-tile (64); widest K-extension of any linear
     void* lt = nullptr;                              // t = x A^T of the linear being launched, [rows, k2 (x2 in split-operand mode)]
     int w8a8 = 0;              // W8A8 mode (desc.w8a8): e4m3 GEMM operands with per-row / per-channel fp32 scales
@@ -161,14 +165,6 @@ struct lr_engine {
     bool last_pruned = false;                        // the last forward ran its final decoder layer for the gathered rows only (x is stale there)
     // last decoder layer, gathered rows only (run_decoder_stack): compact [max_batch (+ pad), ...] twins of x / h / att / ff
     float* xg = nullptr; void *hg = nullptr, *attg = nullptr, *ffg = nullptr;
-    // Outlier-channel calibration (lr_calibrate): per consumer weight (the site), the 128-column blocks of its operand that hold
-    // massive activations; their residuals are carried in 16 bits (GemmParams::nhot).  `counts` = device counters of a running calibration.
-    struct HotSite { HotBlocks hb{0, {0, 0, 0, 0}}; unsigned* counts = nullptr; int nblk = 0; };
-    std::unordered_map<const void*, HotSite> hot;
-    bool calibrating = false;
-    float calib_ratio = 64.f;
-    HotBlocks pre_enc_hot{0, {0, 0, 0, 0}};          // hot blocks of the operand buffer `pre_enc` as its producer wrote it
-    const HotBlocks* hot_of(const void* W) const { auto it = hot.find(W); return it == hot.end() || it->second.hb.n == 0 ? nullptr : &it->second.hb; }
     int* sched_mem = nullptr;                        // tile-scheduler words of this engine's persistent GEMM launches (GemmParams::sched_mem)
     // precision map (lr_set_precision_map): operand form per stage, -1 = the descriptor's.  0 single pass, 1 split (16-bit residuals),
     // 2 split with e4m3 residual passes.  Decoder layers [pm_first, layers - pm_last) take pm_mid, the others the descriptor's form.
@@ -331,7 +327,10 @@ inline void ensure_lo8_twin(lr_engine* e, const void* W, int N, int K, int ldw, 
     } else if (inexact) {
         const size_t need = (size_t)N * ldw * 2;
         if (need > e->w8tmp_cap) { e->w8tmp_cap = need; e->w8tmp = e->dalloc(need, false); }
-        prepare_weight_e4m3_pair(W, twin, ldw, K, N, e->w8tmp, e->op_dt, e->amax_word, st, &E, &E2);
+        void*& pair = e->pair8[W];
+        if (!pair) pair = e->dalloc(need, true);
+        LR_HIP_CHECK(hipMemcpyAsync(pair, twin, need, hipMemcpyDeviceToDevice, st));      // the 16-bit residuals: converted in the copy
+        prepare_weight_e4m3_pair(W, pair, ldw, K, N, e->w8tmp, e->op_dt, e->amax_word, st, &E, &E2);
     } else {
         E = prepare_weight_e4m3(W, ldw, K, N, twin, e->op_dt, e->amax_word, st);
     }
@@ -361,19 +360,9 @@ inline unsigned char* next_scales(lr_engine* e) { e->sc_i ^= 1; return e->sc[e->
 
 // keep_enc: another GEMM reads the same operand buffer next (the main GEMM behind an adapter's t GEMM): leave the "already encoded"
 // mark on it.  force_hi8: that next GEMM needs the e4m3 copy of the hi half as well, so the one in-place encoding pass writes it now.
-// site: the weight whose hot-block list applies to this operand (the main weight of a linear; an adapter's t GEMM passes it along)
-inline void upgrade_lo8(lr_engine* e, GemmParams& p, hipStream_t st, bool keep_enc = false, bool force_hi8 = false, const void* site = nullptr) {
+inline void upgrade_lo8(lr_engine* e, GemmParams& p, hipStream_t st, bool keep_enc = false, bool force_hi8 = false) {
     if (p.aexp) return;
     if (lo8_eligible(e, p)) {
-        if (!site) site = p.W;
-        if (e->calibrating && site == p.W) {            // column statistics of this operand's hi half (lr_calibrate)
-            lr_engine::HotSite& hs = e->hot[site];
-            if (!hs.counts) {
-                hs.nblk = p.kw / 128;
-                hs.counts = (unsigned*)e->dalloc((size_t)(hs.nblk + 1) * 4, true);
-            }
-            launch_block_outlier_stats(p.A, p.lda, p.kw, p.M, hs.counts, e->calib_ratio, e->op_dt, st);
-        }
         // Weights inexact in the operand type (Wlo set by apply_prec_base: a merged LoRA adapter, fp32-trained weights): a third
         // e4m3 segment, A_hi8 x e4m3(W_lo)^T, replaces the 16-bit [x_hi] x [W_lo] segment (2x instead of 3x the single pass).
         // Adapter matrices (own8) keep the 16-bit third segment: their e4m3 twin lives in a buffer of its own.
@@ -390,23 +379,18 @@ inline void upgrade_lo8(lr_engine* e, GemmParams& p, hipStream_t st, bool keep_e
         if (!(e->pre_enc == p.A && (!hi8 || e->pre_enc_hi8))) {
             if (e->pre_enc == p.A) throw std::logic_error("operand buffer already carries e4m3 residuals without the e4m3 copy of its hi half");
             unsigned char* sc = next_scales(e);
-            const HotBlocks* hb = hi8 ? nullptr : e->hot_of(site);       // (the hi-half copy and the hot blocks' 16-bit residuals share bytes)
-            launch_quantize_lo_inplace(const_cast<void*>(p.A), p.lda, p.kw, p.M, sc, e->op_dt, st, hi8 ? aexp2 : nullptr, hb);
+            launch_quantize_lo_inplace(const_cast<void*>(p.A), p.lda, p.kw, p.M, sc, e->op_dt, st, hi8 ? aexp2 : nullptr);
             e->pre_enc_hi8 = hi8;
             e->pre_enc_sc = sc;
-            e->pre_enc_hot = hb ? *hb : HotBlocks{0, {0, 0, 0, 0}};
         }
         p.aexp = e->pre_enc_sc;
-        p.nhot = e->pre_enc_hot.n;
-        for (int j = 0; j < 4; ++j) p.hotblk[j] = e->pre_enc_hot.blk[j];
         e->pre_enc = keep_enc ? p.A : nullptr;      // (a norm kernel may have written [hi | e4m3(lo)] and the scales itself: lo8_norm_target)
         if (own != e->own8.end()) { p.Wlo16 = inexact ? lo_rows : nullptr; p.Wlo = own->second; }
+        else if (inexact) p.Wlo = e->pair8.at(p.W);
         else p.Wlo = lo_rows;
         p.wexp = w8->second;
         p.aexp2 = third8 ? aexp2 : nullptr;
         p.wexp2 = e->w8exp2[p.W];
-    } else if (e->lo8 && p.Wlo && e->w8exp.count(p.W) && !e->own8.count(p.W)) {
-        throw std::runtime_error("this weight's residual twin has been converted to e4m3; re-upload the weights before changing the GEMM tile");
     }
 }
 inline void apply_prec(lr_engine* e, GemmParams& p, hipStream_t st) {
@@ -417,7 +401,6 @@ inline void apply_prec(lr_engine* e, GemmParams& p, hipStream_t st) {
 // that GEMM will take the e4m3 residual form with exact weights, else null (the norm then writes 16-bit residuals as usual).
 inline unsigned char* lo8_norm_target(lr_engine* e, GemmParams probe) {
     e->pre_enc = nullptr;
-    e->pre_enc_hot = HotBlocks{0, {0, 0, 0, 0}};
     if (!e->lo8) return nullptr;
     apply_prec_base(e, probe);
     if (!lo8_eligible(e, probe) || probe.Wlo) return nullptr;
@@ -426,7 +409,6 @@ inline unsigned char* lo8_norm_target(lr_engine* e, GemmParams probe) {
     e->pre_enc_hi8 = false;
     unsigned char* sc = next_scales(e);
     e->pre_enc_sc = sc;
-    if (const HotBlocks* hb = e->hot_of(probe.W)) e->pre_enc_hot = *hb;      // the norm kernel takes &e->pre_enc_hot beside the scale array
     return sc;
 }
 inline void apply_prec(const lr_engine* e, AttnParams& p) {
@@ -487,7 +469,6 @@ inline unsigned char* lo8_out_target(lr_engine* e, const GemmParams& p, const vo
     GemmParams probe{p.C, next_W, nullptr, nullptr, p.M, next_N, Kout, Kout, Kout, next_N, EPI_OUT_F32, ACT_NONE, nullptr, 0, 0};
     apply_prec_base(e, probe);
     if (!lo8_eligible(e, probe) || probe.Wlo) return nullptr;
-    if (e->hot_of(next_W)) return nullptr;            // hot blocks: 16-bit residuals out of this epilogue, the in-place pass sorts them
     ensure_aexp(e, (size_t)p.M, (size_t)Kout);
     return next_scales(e);
 }
@@ -496,7 +477,6 @@ inline void mark_lo8_out(lr_engine* e, const GemmParams& p) {
     e->pre_enc = p.C;
     e->pre_enc_hi8 = false;
     e->pre_enc_sc = p.oexp;
-    e->pre_enc_hot = HotBlocks{0, {0, 0, 0, 0}};
 }
 
 // One linear layer, p in LOGICAL shapes (as gemm() takes them).  With an adapter L: t = x A^T first (always on the deep-pipelined
@@ -513,7 +493,7 @@ inline void gemm_p(lr_engine* e, hipStream_t st, GemmParams p, const Lora* L = n
         apply_prec_base(e, t);
         const bool both8 = lo8_eligible(e, probe) && lo8_eligible(e, t);
         if (e->pre_enc == p.A && !both8) throw std::logic_error("operand pre-encoded in e4m3 for a GEMM that takes the 16-bit form");
-        if (both8) upgrade_lo8(e, t, st, true, probe.Wlo != nullptr, p.W);
+        if (both8) upgrade_lo8(e, t, st, true, probe.Wlo != nullptr);
         launch_gemm_bt(t, e->op_dt, 6, st);
         p.A2 = e->lt; p.lda2 = L->k2 * (1 + e->prec); p.W2 = L->B; p.ldw2 = L->k2; p.k2 = L->k2;
         auto it = e->wbuf_of.find(L->B);

@@ -177,6 +177,7 @@ void validate_desc(const lr_model_desc& d) {
     if (d.layers < 0 || d.clip_layers < 0) bad("layer counts must be non-negative");
     if (d.lora_rank < 0 || d.lora_rank > 1024) bad("lora_rank out of range");
     if (d.lora_rank > 0 && d.w8a8) bad("w8a8 runs merged weights only: merge the adapter on the host (lora_rank = 0)");
+    if (d.rope_flash_convention != 0 && d.rope_flash_convention != 1) bad("rope_flash_convention must be 0 or 1");
 }
 
 }  // namespace
@@ -201,11 +202,11 @@ bool run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_ma
     bool pruned = false;
     for (int l = 0; l < nl; ++l) {
         const DecLayer& L = h->dl[l];
-        h->set_form((h->pm_mid >= 0 && l >= h->pm_first && l < nl - h->pm_last) ? h->pm_mid : -1);
+        h->set_form((h->pm_mid >= 0 && l >= h->pm_first && l < d.layers - h->pm_last) ? h->pm_mid : -1);
         {   // qkv projection with RoPE on q,k: fused in the GEMM epilogue when the deep-pipelined kernel runs
             GemmParams gp{h->h, L.qkv_w, h->qkv, L.qkv_b, Rl, Nqkv, D, D, D, Nqkv, EPI_ROPE_OP, ACT_NONE, h->cs, Hq + Hkv, h->hd};
             const bool tiles_ok = (Hq + Hkv) % 256 == 0;
-            launch_norm_rows(h->x, L.ln1, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st, h->prec, 1, tiles_ok ? lo8_norm_target(h, gp) : nullptr, &h->pre_enc_hot);
+            launch_norm_rows(h->x, L.ln1, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st, h->prec, 1, tiles_ok ? lo8_norm_target(h, gp) : nullptr);
             GemmParams probe = gp;
             apply_prec_base(h, probe);
             if (tiles_ok && (L.lqkv.k2 > 0 || w8a8_eligible(h, probe) || lo8_eligible(h, probe) || gemm_bt_is_deep(probe, h->gemm_tile))) {
@@ -231,7 +232,7 @@ bool run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_ma
             launch_gather_norm_rows(h->x, h->tstat, S, gather == 2 ? 1 : 0, nullptr, 0.f, h->xg, B, D, st);      // (no weight: a plain row gather)
             gemm(h, st, h->attg, L.o_w, h->xg, nullptr, B, D, Hq, Hq, Hq, D, EPI_RESADD_F32, ACT_NONE, &L.lo);
             launch_norm_rows(h->xg, L.ln2, nullptr, h->hg, B, D, d.rms_eps, h->op_dt, st, h->prec, 1,
-                             lo8_norm_target(h, GemmParams{h->hg, L.gu_w, h->ffg, nullptr, B, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE, nullptr, 0, 0}), &h->pre_enc_hot);
+                             lo8_norm_target(h, GemmParams{h->hg, L.gu_w, h->ffg, nullptr, B, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE, nullptr, 0, 0}));
             gemm(h, st, h->hg, L.gu_w, h->ffg, nullptr, B, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE, &L.lgu, L.down_w, D);
             gemm(h, st, h->ffg, L.down_w, h->xg, nullptr, B, D, I, I, I, D, EPI_RESADD_F32, ACT_NONE, &L.ldown);
             pruned = true;
@@ -241,7 +242,7 @@ bool run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_ma
         launch_attention(ap, B, h->hd, true, h->op_dt, st);
         gemm(h, st, h->att, L.o_w, h->x, nullptr, Rl, D, Hq, Hq, Hq, D, EPI_RESADD_F32, ACT_NONE, &L.lo);
         launch_norm_rows(h->x, L.ln2, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st, h->prec, 1,
-                         lo8_norm_target(h, GemmParams{h->h, L.gu_w, h->ff, nullptr, Rl, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE, nullptr, 0, 0}), &h->pre_enc_hot);
+                         lo8_norm_target(h, GemmParams{h->h, L.gu_w, h->ff, nullptr, Rl, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE, nullptr, 0, 0}));
         gemm(h, st, h->h, L.gu_w, h->ff, nullptr, Rl, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE, &L.lgu, L.down_w, D);      // ff is down's operand
         gemm(h, st, h->ff, L.down_w, h->x, nullptr, Rl, D, I, I, I, D, EPI_RESADD_F32, ACT_NONE, &L.ldown);
     }
@@ -399,17 +400,17 @@ int lr_upload_weight(lr_handle h, const char* name, const void* data, const int6
             const lr_engine::WBuf& wb = h->wbufs[s.wid];
             if (h->own8.count(wb.hi)) {        // adapter matrix: its e4m3 twin is a separate buffer, rebuilt at the next launch
                 h->w8exp.erase(wb.hi); h->w8exp2.erase(wb.hi);
-            } else if (h->w8exp.count(wb.hi)) {       // ... which now holds e4m3 data (default parity mode, after lr_finalize)
+            } else if (h->w8exp.count(wb.hi)) {       // its e4m3 twin has been prepared (default parity mode, after lr_finalize)
                 const bool whole = (size_t)s.rows * s.ld_dst * 2 == wb.bytes && s.dst == wb.hi;
                 const bool was_inexact = !h->inexact.empty() && h->inexact[s.wid];
-                if (!whole && was_inexact)
-                    throw std::logic_error(std::string("lr_upload_weight: ") + name + " shares a buffer whose 16-bit residuals have been "
-                                           "converted to e4m3; create a new handle to replace part of an inexact weight group");
-                if (!whole) LR_HIP_CHECK(hipMemset(wb.lo, 0, wb.bytes));      // the other tensors of the group were exact: residuals 0
+                // an exact buffer's residual twin holds e4m3(W) now (its 16-bit residuals were all zero); an inexact buffer's still
+                // holds the 16-bit residuals (its e4m3 rows live in pair8)
+                if (!whole && !was_inexact) LR_HIP_CHECK(hipMemset(wb.lo, 0, wb.bytes));
                 h->w8exp.erase(wb.hi); h->w8exp2.erase(wb.hi);
             }
         }
         pack_slot(h, s, f32);
+        ++h->weights_epoch;
         h->w8.clear();             // W8A8 twins are separate buffers, rebuilt from the packed weights at the next launch
         LR_HIP_CHECK(hipStreamSynchronize(0));
         if (h->finalized && h->inexact_dev)      // a re-upload after lr_finalize may have made a buffer inexact
@@ -434,7 +435,12 @@ int lr_synth_weights_ex(lr_handle h, uint64_t seed, int flags) {
             pack_slot(h, s, h->stage_f32);
         }
         h->w8exp.clear(); h->w8exp2.clear(); h->w8.clear();
+        ++h->weights_epoch;
         LR_HIP_CHECK(hipStreamSynchronize(0));
+        if (h->finalized && h->inexact_dev) {    // re-synthesised after lr_finalize (fp32-valued profile): a buffer may have become inexact
+            h->inexact.resize(h->wbufs.size(), 0);
+            LR_HIP_CHECK(hipMemcpy(h->inexact.data(), h->inexact_dev, h->wbufs.size() * sizeof(int), hipMemcpyDeviceToHost));
+        }
     });
 }
 
@@ -521,53 +527,7 @@ int lr_set_precision_map(lr_handle h, int clip_form, int decoder_mid_form, int d
         h->pm_clip = clip_form; h->pm_mid = decoder_mid_form; h->pm_first = decoder_first; h->pm_last = decoder_last;
     });
 }
-int lr_calibrate(lr_handle h, int begin, float ratio, float row_fraction, int* n_sites_with_hot_blocks) {
-    if (!h) return LR_EINVAL;
-    return guarded(h, [&] {
-        if (!h->finalized) throw std::logic_error("lr_calibrate: call lr_finalize first");
-        if (begin) {
-            if (!(ratio > 1.f)) throw std::invalid_argument("lr_calibrate: ratio must be > 1");
-            LR_HIP_CHECK(hipDeviceSynchronize());
-            for (auto& kv : h->hot) {
-                kv.second.hb = HotBlocks{0, {0, 0, 0, 0}};
-                if (kv.second.counts) LR_HIP_CHECK(hipMemset(kv.second.counts, 0, (size_t)(kv.second.nblk + 1) * 4));
-            }
-            h->calib_ratio = ratio;
-            h->calibrating = true;
-            return;
-        }
-        if (!h->calibrating) throw std::logic_error("lr_calibrate(end) without lr_calibrate(begin)");
-        h->calibrating = false;
-        LR_HIP_CHECK(hipDeviceSynchronize());
-        int sites = 0;
-        std::vector<unsigned> c;
-        for (auto& kv : h->hot) {
-            lr_engine::HotSite& hs = kv.second;
-            if (!hs.counts) continue;
-            c.assign(hs.nblk + 1, 0);
-            LR_HIP_CHECK(hipMemcpy(c.data(), hs.counts, c.size() * 4, hipMemcpyDeviceToHost));
-            const unsigned rows = c[hs.nblk];
-            const unsigned need = std::max(1u, (unsigned)std::ceil((double)row_fraction * rows));
-            // weights inexact in the operand type keep the e4m3 copy of the hi half where the hot residuals would go: no hot blocks there
-            auto wb = h->wbuf_of.find(kv.first);
-            const bool inexact = wb != h->wbuf_of.end() && !h->inexact.empty() && h->inexact[wb->second];
-            std::vector<std::pair<unsigned, int>> cand;
-            for (int b = 0; b < hs.nblk; ++b) if (rows && c[b] >= need) cand.push_back({c[b], b});
-            std::sort(cand.begin(), cand.end(), [](auto& a, auto& b2) { return a.first != b2.first ? a.first > b2.first : a.second < b2.second; });
-            const int cap = std::min<int>(GemmParams::MAX_HOT, hs.nblk / 2);       // 256 bytes per hot block in K spare bytes
-            if (!inexact && (int)cand.size() > 0) {
-                cand.resize(std::min<size_t>(cand.size(), (size_t)std::max(cap, 0)));
-                std::vector<int> blks;
-                for (auto& x : cand) blks.push_back(x.second);
-                std::sort(blks.begin(), blks.end());
-                hs.hb.n = (int)blks.size();
-                for (int j = 0; j < hs.hb.n; ++j) hs.hb.blk[j] = blks[j];
-                if (hs.hb.n) ++sites;
-            }
-        }
-        if (n_sites_with_hot_blocks) *n_sites_with_hot_blocks = sites;
-    });
-}
+uint64_t lr_weights_epoch(lr_handle h) { return h ? h->weights_epoch : 0; }
 int lr_set_gemm_tile(lr_handle h, int tile) {
     if (!h || tile < -1 || tile > 15) return LR_EINVAL;
     h->gemm_tile = tile;
@@ -663,14 +623,14 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
         for (int l = 0; l < ncl; ++l) {
             const ClipLayer& c = h->cl[l];
             launch_norm_rows(h->clip_x, c.ln1_w, c.ln1_b, h->clip_h, Rc, Hc, d.clip_ln_eps, h->op_dt, st, h->prec, 1,
-                             lo8_norm_target(h, GemmParams{h->clip_h, c.qkv_w, h->clip_qkv, c.qkv_b, Rc, 3 * Hc, Hc, Hc, Hc, 3 * Hc, EPI_OUT_OP, ACT_NONE, nullptr, 0, 0}), &h->pre_enc_hot);
+                             lo8_norm_target(h, GemmParams{h->clip_h, c.qkv_w, h->clip_qkv, c.qkv_b, Rc, 3 * Hc, Hc, Hc, Hc, 3 * Hc, EPI_OUT_OP, ACT_NONE, nullptr, 0, 0}));
             gemm(h, st, h->clip_h, c.qkv_w, h->clip_qkv, c.qkv_b, Rc, 3 * Hc, Hc, Hc, Hc, 3 * Hc, EPI_OUT_OP, ACT_NONE);
             AttnParams ap{h->clip_qkv, h->clip_qkv, h->clip_qkv, h->clip_att, nullptr, nullptr, 0, 3 * Hc, Hc, 0, Hc, 2 * Hc, T, d.clip_heads, 0.125f, 1};
             apply_prec(h, ap);
             launch_attention(ap, NC, 64, false, h->op_dt, st);
             gemm(h, st, h->clip_att, c.out_w, h->clip_x, c.out_b, Rc, Hc, Hc, Hc, Hc, Hc, EPI_RESADD_F32, ACT_NONE);
             launch_norm_rows(h->clip_x, c.ln2_w, c.ln2_b, h->clip_h, Rc, Hc, d.clip_ln_eps, h->op_dt, st, h->prec, 1,
-                             lo8_norm_target(h, GemmParams{h->clip_h, c.fc1_w, h->clip_ff, c.fc1_b, Rc, Mc, Hc, Hc, Hc, Mc, EPI_OUT_OP, ACT_QUICK_GELU, nullptr, 0, 0}), &h->pre_enc_hot);
+                             lo8_norm_target(h, GemmParams{h->clip_h, c.fc1_w, h->clip_ff, c.fc1_b, Rc, Mc, Hc, Hc, Hc, Mc, EPI_OUT_OP, ACT_QUICK_GELU, nullptr, 0, 0}));
             gemm(h, st, h->clip_h, c.fc1_w, h->clip_ff, c.fc1_b, Rc, Mc, Hc, Hc, Hc, Mc, EPI_OUT_OP, ACT_QUICK_GELU, nullptr, c.fc2_w, Hc);
             gemm(h, st, h->clip_ff, c.fc2_w, h->clip_x, c.fc2_b, Rc, Hc, Mc, Mc, Mc, Hc, EPI_RESADD_F32, ACT_NONE);
         }
@@ -692,7 +652,8 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
         launch_token_plan(input_ids, attention_mask, B, S, d_voff, h->img_row, h->pos_ids, h->tstat, st,
                           h->llava ? (long)d.image_token_id : -1L, h->llava ? 1 : 0);
         launch_embed(input_ids, h->img_row, h->wte, h->ev, h->x, Rl, D, d.vocab_size, st);
-        launch_rope_table(h->pos_ids, h->tstat, B, S, h->inv_s, h->inv_l, d.rope_scaling, d.orig_max_pos, h->half, h->cs, st);
+        launch_rope_table(h->pos_ids, h->tstat, B, S, h->inv_s, h->inv_l, d.rope_scaling, d.orig_max_pos, h->half, h->cs, st,
+                          S + (d.rope_flash_convention ? 1 : 0));      // seq_len the rotary module is called with (lr_model_desc.rope_flash_convention)
         const int last_pos = (flags & LR_FWD_TRAINING_LAST_TOKEN) ? 1 : 0;
         const int gather = (d.mean_hidden_state || (flags & LR_FWD_KEEP_HIDDEN_STATES)) ? 0 : 1 + last_pos;
         h->last_pruned = run_decoder_stack(h, st, attention_mask, B, S, gather);
@@ -808,14 +769,6 @@ int lr_op_gemm_bt_ext(const void* A, const void* W, const void* T, const void* B
 
 size_t lr_op_lo8_scratch_bytes(int M, int K) { return ((lo8_scale_bytes(M, K) + 255) & ~(size_t)255) + (((size_t)M * 4 + 255) & ~(size_t)255); }
 
-static thread_local HotBlocks g_op_hot{0, {0, 0, 0, 0}};
-int lr_op_set_hot_blocks(int n, const int* blocks) {
-    if (n < 0 || n > GemmParams::MAX_HOT || (n && !blocks)) return LR_EINVAL;
-    g_op_hot = HotBlocks{n, {0, 0, 0, 0}};
-    for (int j = 0; j < n; ++j) g_op_hot.blk[j] = blocks[j];
-    return LR_OK;
-}
-
 int lr_op_gemm_bt_mixed(void* A, const void* W, void* W8, void* scratch, void* C, const float* bias, int M, int N, int K, int epi, int act,
                         int operand_dtype, int flags, int* wexp, void* hip_stream) {
     return op_guard([&] {
@@ -838,15 +791,13 @@ int lr_op_gemm_bt_mixed(void* A, const void* W, void* W8, void* scratch, void* C
             }
             LR_HIP_CHECK(hipFree(word));
         }
-        const HotBlocks* hb = (!inexact && g_op_hot.n > 0) ? &g_op_hot : nullptr;
-        if (flags & 2) launch_quantize_lo_inplace(A, 2 * K, K, M, scales, dt, st, inexact ? aexp2 : nullptr, hb);   // re-encode A's residual half
+        if (flags & 2) launch_quantize_lo_inplace(A, 2 * K, K, M, scales, dt, st, inexact ? aexp2 : nullptr);   // re-encode A's residual half
         if (flags & 4) return;
         const int nout = epi == EPI_SWIGLU_OP ? N / 2 : N;
         const bool op_out = epi == EPI_OUT_OP || epi == EPI_SWIGLU_OP;
         GemmParams p{A, W, C, bias, M, N, inexact ? 2 * K : K + K / 2, 2 * K, K, op_out ? 2 * nout : nout, epi, act, nullptr, 0, 0, K, op_out ? nout : 0, W8};
         p.aexp = scales; p.wexp = wexp[0];
         if (inexact) { p.aexp2 = aexp2; p.wexp2 = wexp[1]; }
-        if (hb) { p.nhot = hb->n; for (int j = 0; j < hb->n; ++j) p.hotblk[j] = hb->blk[j]; }
         if (flags & 32) {          // operand-typed output with one-byte residuals: C's block scales behind this call's own scratch
             if (!op_out || nout % 128) throw std::runtime_error("lr_op_gemm_bt_mixed: flag 32 needs an operand-typed output with columns % 128 == 0");
             p.oexp = scales + lr_op_lo8_scratch_bytes(M, K);

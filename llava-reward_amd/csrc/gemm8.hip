@@ -988,12 +988,6 @@ static void build_segments(GemmParams& p, int f8) {
     if (f8 == 2) {
         const bool third8 = p.aexp2 != nullptr;
         add(p.kw / 64, 0, 0, 0);                                             // x_hi x W
-        if (p.nhot < 0 || p.nhot > GemmParams::MAX_HOT || (p.nhot && (third8 || 256 * p.nhot > p.kw)))
-            throw std::runtime_error("gemm_bt8_mixed: hot blocks need exact weights and at most kw / 256 (<= 4) of them");
-        for (int j = 0; j < p.nhot; ++j) {                                   // x_lo (16-bit, hot block j) x W: columns of massive activations
-            if (p.hotblk[j] < 0 || p.hotblk[j] >= p.kw / 128) throw std::runtime_error("gemm_bt8_mixed: hot block out of range");
-            add(2, 0, p.kw + p.kw / 2 + 128 * j, 128 * p.hotblk[j]);
-        }
         if (p.Wlo16) add(p.kw / 64, GemmParams::SRC_LO16, 0, 0);              // x_hi x W_lo, 16-bit
         adapter(true);
         p.nk_f16 = kt;

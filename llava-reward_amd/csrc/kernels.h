@@ -14,12 +14,7 @@ void launch_gemm_bt8(const GemmParams& p, int operand_dtype, int variant, hipStr
 // W8A8: e4m3 operands (K, lda, ldw in bytes), per-row / per-channel fp32 scales in p.ascale / p.wscale
 void launch_gemm_bt8_fp8(GemmParams p, int operand_dtype, hipStream_t st);
 void launch_gemm_bt8_mixed(const GemmParams& p, int operand_dtype, hipStream_t st, int dbg = 0);
-// hot: blocks whose 16-bit residuals are kept (moved to the second half of the residual space) instead of encoded (GemmParams::nhot)
-void launch_quantize_lo_inplace(void* a, int ld, int K, int rows, unsigned char* scales, int operand_dtype, hipStream_t st, int* aexp2 = nullptr,
-                                const HotBlocks* hot = nullptr);
-// calibration (lr_calibrate): counts[b] += rows whose 128-column block b of the hi half holds |x| >= ratio * mean |x| of the row;
-// counts[K / 128] += rows.  a: operand rows (2-byte elements, row stride ld), K % 128 == 0.
-void launch_block_outlier_stats(const void* a, int ld, int K, int rows, unsigned* counts, float ratio, int operand_dtype, hipStream_t st);
+void launch_quantize_lo_inplace(void* a, int ld, int K, int rows, unsigned char* scales, int operand_dtype, hipStream_t st, int* aexp2 = nullptr);
 void prepare_weight_e4m3_pair(const void* w, void* twin, int ldw, int K, int N, void* tmp, int operand_dtype, unsigned* scratch_word,
                               hipStream_t st, int* wexp, int* wexp2);
 int prepare_weight_e4m3(const void* w, int ldw, int K, int N, void* dst, int operand_dtype, unsigned* scratch_word, hipStream_t st);
@@ -31,8 +26,7 @@ void launch_attention(const AttnParams& p, int batch, int head_dim, bool causal,
 // y_op[r][:] = LN(x[r][:]) * w + b   (b == null -> RMSNorm: x * rsqrt(mean x^2 + eps) * w)
 // prec = 1 (every operand producer below): split-operand mode, rows are stored [hi | lo], twice as wide (common.h split2)
 void launch_norm_rows(const float* x, const float* w, const float* b, void* y, int rows, int H, float eps,
-                      int operand_dtype, hipStream_t st, int prec = 0, int group = 1, unsigned char* lo8 = nullptr,
-                      const HotBlocks* hot = nullptr);   // group g: g consecutive rows form one output row; hot (with lo8): GemmParams::nhot
+                      int operand_dtype, hipStream_t st, int prec = 0, int group = 1, unsigned char* lo8 = nullptr);   // group g: g consecutive rows form one output row
 // lo8: write the residual half as block-scaled e4m3 (common.h lo8_scale_at; lo8 = the scale array) instead of 16-bit residuals
 // pixels [B, C, 3, img, img] (fp32/bf16) -> patch matrix [ncrop*g*g, Kpad] operand dtype; crop_src[i] = b*C + c
 void launch_im2col(const void* pixels, int pix_dtype, const int* crop_src, int ncrop, int img, int patch, int Kpad,
@@ -54,7 +48,8 @@ void launch_embed(const int64_t* ids, const int* img_row, const unsigned short* 
 // cos/sin table [rows][hd/2][2] = (cos, sin) pairs from positions (su-scaled RoPE); long factors iff S > orig_max (the reference
 // passes seq_len = the padded length, modeling_phi3_v.py:673)
 void launch_rope_table(const int* pos, const int* tstat, int B, int S, const float* inv_freq_short,
-                       const float* inv_freq_long, float scaling, int orig_max_pos, int half, float* cs, hipStream_t st);
+                       const float* inv_freq_long, float scaling, int orig_max_pos, int half, float* cs, hipStream_t st,
+                       int rotary_seq_len = 0);     // the seq_len the rotary module is called with: S (eager / sdpa, default) or S + 1 (flash)
 // qkv32 [rows, 3D] fp32 -> qkv operand dtype with RoPE applied to q and k heads (pair-interleaved head dims)
 void launch_rope_split(const float* qkv32, const float* cs, void* out, int rows, int rope_cols, int v_cols, int hd,
                        int operand_dtype, hipStream_t st, int prec = 0);

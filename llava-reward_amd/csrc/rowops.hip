@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
 template <typename OT, bool LAYERNORM>
 __global__ __launch_bounds__(256) void norm_rows8_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ b, void* __restrict__ y, int rows,
-                                                         int H, float eps, int prec, unsigned char* __restrict__ lo8, HotBlocks hot) {
+                                                         int H, float eps, int prec, unsigned char* __restrict__ lo8) {
     constexpr int MAXI = NORM_MAXC / 2;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -159,19 +159,7 @@ __global__ __launch_bounds__(256) void norm_rows8_kernel(const float* __restrict
                                                 hb[4] | ((unsigned)hb[5] << 16), hb[6] | ((unsigned)hb[7] << 16));
         }
         if (lo8) {              // residual half as block-scaled e4m3 (common.h): 16 lanes = one 128-column block (H % 128 == 0)
-            int E = e8m0_of_amax(row16_max(m));
-            // hot blocks (columns of massive activations, GemmParams::nhot): 16-bit residuals into the second half of the residual
-            // space, zeros in the e4m3 bytes -- an element 1000x its row's typical magnitude needs more than e4m3's 4 bits of residual
-            int hj = -1;
-#pragma unroll
-            for (int j = 0; j < GemmParams::MAX_HOT; ++j) hj = (j < hot.n && hot.blk[j] == (c >> 4)) ? j : hj;
-            if (hj >= 0 && c < n8) {
-                *(uint4*)((unsigned char*)(dst + H) + H + 256 * hj + 16 * (c & 15)) =
-                    make_uint4(pack2<OT>(r[0], r[1]), pack2<OT>(r[2], r[3]), pack2<OT>(r[4], r[5]), pack2<OT>(r[6], r[7]));
-#pragma unroll
-                for (int j = 0; j < 8; ++j) r[j] = 0.f;
-                E = 127;
-            }
+            const int E = e8m0_of_amax(row16_max(m));
             if (c < n8) {
                 const float sc = e8m0_inv_scale(E);
                 int p0 = 0, p1 = 0;
@@ -189,13 +177,8 @@ __global__ __launch_bounds__(256) void norm_rows8_kernel(const float* __restrict
 }
 
 void launch_norm_rows(const float* x, const float* w, const float* b, void* y, int rows, int H, float eps,
-                      int operand_dtype, hipStream_t st, int prec, int group, unsigned char* lo8, const HotBlocks* hot) {
+                      int operand_dtype, hipStream_t st, int prec, int group, unsigned char* lo8) {
     if (rows <= 0) return;
-    HotBlocks hb{0, {0, 0, 0, 0}};
-    if (lo8 && hot && hot->n > 0) {
-        hb = *hot;
-        if (hb.n > GemmParams::MAX_HOT || 256 * hb.n > H) throw std::runtime_error("norm_rows: too many hot blocks for this width");
-    }
     if (group < 1 || rows % group) throw std::runtime_error("norm_rows: rows must be a multiple of group");
     if (lo8 && (!prec || group != 1 || H % 128 || (((uintptr_t)y) & 15) || (((uintptr_t)w) & 15) || (b && (((uintptr_t)b) & 15))))
         throw std::runtime_error("norm_rows: the e4m3 residual form needs split-operand rows, group 1, H % 128 == 0 and 16-byte aligned pointers");
@@ -204,11 +187,11 @@ void launch_norm_rows(const float* x, const float* w, const float* b, void* y, i
     const bool f16 = operand_dtype == DT_F16;
     if (group == 1 && H % 8 == 0 && (((uintptr_t)y) & 15) == 0 && (((uintptr_t)w) & 15) == 0 && (!b || (((uintptr_t)b) & 15) == 0)) {
         if (b) {
-            if (f16) hipLaunchKernelGGL((norm_rows8_kernel<F16, true>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, lo8, hb);
-            else hipLaunchKernelGGL((norm_rows8_kernel<BF16, true>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, lo8, hb);
+            if (f16) hipLaunchKernelGGL((norm_rows8_kernel<F16, true>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, lo8);
+            else hipLaunchKernelGGL((norm_rows8_kernel<BF16, true>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, lo8);
         } else {
-            if (f16) hipLaunchKernelGGL((norm_rows8_kernel<F16, false>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, lo8, hb);
-            else hipLaunchKernelGGL((norm_rows8_kernel<BF16, false>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, lo8, hb);
+            if (f16) hipLaunchKernelGGL((norm_rows8_kernel<F16, false>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, lo8);
+            else hipLaunchKernelGGL((norm_rows8_kernel<BF16, false>), g, t, 0, st, x, w, b, y, rows, H, eps, prec, lo8);
         }
         return;
     }
@@ -430,9 +413,10 @@ void launch_embed(const int64_t* ids, const int* img_row, const unsigned short* 
 // the switch depends on S alone, not on how many tokens of a row are valid.  This is the EAGER / SDPA convention (the oracle's and
 // the goldens' attention implementation).  Phi3FlashAttention2 (:793-794; flash-attn is absent here, so it is unpinned) passes
 // seq_len = max(kv_seq_len, max(position_ids)) + 1 and therefore switches one token earlier, at S >= original_max: at S ==
-// original_max exactly (4096 for Phi-3.5-V) a flash-attention reference uses the long factors where this engine, like eager / sdpa,
-// still uses the short ones (golden ref_small_rope_at_orig_bt_ca pins the eager side of that boundary).  cs layout: [row][half][2].
-__global__ __launch_bounds__(256) void rope_table_kernel(const int* __restrict__ pos, int S,
+// original_max exactly (4096 for Phi-3.5-V) a flash-attention reference uses the long factors where eager / sdpa still use the
+// short ones (golden ref_small_rope_at_orig_bt_ca pins the eager side of that boundary).  lr_model_desc.rope_flash_convention selects
+// the flash side: the launcher then passes rotary_seq_len = S + 1.  cs layout: [row][half][2].
+__global__ __launch_bounds__(256) void rope_table_kernel(const int* __restrict__ pos, int S,          // S = the seq_len the rotary module sees
                                                          int rows, const float* __restrict__ inv_s,
                                                          const float* __restrict__ inv_l, float scaling, int orig_max,
                                                          int half, float* __restrict__ cs) {
@@ -446,11 +430,11 @@ __global__ __launch_bounds__(256) void rope_table_kernel(const int* __restrict__
 }
 
 void launch_rope_table(const int* pos, const int* tstat, int B, int S, const float* inv_freq_short,
-                       const float* inv_freq_long, float scaling, int orig_max_pos, int half, float* cs, hipStream_t st) {
+                       const float* inv_freq_long, float scaling, int orig_max_pos, int half, float* cs, hipStream_t st, int rotary_seq_len) {
     const int rows = B * S;
     (void)tstat;
     if (rows <= 0) return;
-    hipLaunchKernelGGL(rope_table_kernel, dim3(cdiv((long)rows * half, 256)), dim3(256), 0, st, pos, S, rows,
+    hipLaunchKernelGGL(rope_table_kernel, dim3(cdiv((long)rows * half, 256)), dim3(256), 0, st, pos, rotary_seq_len > 0 ? rotary_seq_len : S, rows,
                        inv_freq_short, inv_freq_long, scaling, orig_max_pos, half, cs);
 }
 
@@ -1105,25 +1089,16 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const unsigned s
 // the second half of the residual space (behind the residual bytes), after the residual sweep has consumed it.
 template <typename OT>
 __global__ __launch_bounds__(256) void quantize_lo_inplace_kernel(unsigned short* __restrict__ a, int ld, int K, int rows, unsigned char* __restrict__ scales,
-                                                                  int* __restrict__ aexp2, HotBlocks hot) {
+                                                                  int* __restrict__ aexp2) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     unsigned short* lo = a + (size_t)row * ld + K;
     unsigned char* q = (unsigned char*)lo;
-    uint4 keep0 = make_uint4(0, 0, 0, 0), keep1 = keep0, keep2 = keep0, keep3 = keep0;      // 16-bit residuals of hot blocks (this lane's 8 columns)
-    int held = 0;
     for (int k0 = 0; k0 < K; k0 += 512) {
         const int k = k0 + lane * 8;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (k < K) v = *(const uint4*)(lo + k);
         __builtin_amdgcn_s_waitcnt(0);                       // the whole wave has its 16 bytes before anyone overwrites them
-        if (hot.n > 0 && k < K) {                            // hot blocks keep their 16-bit residuals (written out behind the sweep)
-            const int blk = k >> 7;
-            if (hot.n > 0 && hot.blk[0] == blk) { keep0 = v; held |= 1; v = make_uint4(0, 0, 0, 0); }
-            if (hot.n > 1 && hot.blk[1] == blk) { keep1 = v; held |= 2; v = make_uint4(0, 0, 0, 0); }
-            if (hot.n > 2 && hot.blk[2] == blk) { keep2 = v; held |= 4; v = make_uint4(0, 0, 0, 0); }
-            if (hot.n > 3 && hot.blk[3] == blk) { keep3 = v; held |= 8; v = make_uint4(0, 0, 0, 0); }
-        }
         const unsigned w[4] = {v.x, v.y, v.z, v.w};
         float f[8];
         float m = 0.f;
@@ -1144,14 +1119,6 @@ __global__ __launch_bounds__(256) void quantize_lo_inplace_kernel(unsigned short
             *(uint2*)(q + k) = make_uint2((unsigned)l2, (unsigned)h2);
             if ((lane & 15) == 0) scales[lo8_scale_at(row, k >> 7, rows)] = (unsigned char)E;
         }
-    }
-    if (hot.n > 0) {           // (never together with aexp2: the hi-half copy lives in the same bytes)
-        __builtin_amdgcn_s_waitcnt(0);
-        unsigned char* side = q + K + 16 * (lane & 15);
-        if (held & 1) *(uint4*)(side) = keep0;
-        if (held & 2) *(uint4*)(side + 256) = keep1;
-        if (held & 4) *(uint4*)(side + 512) = keep2;
-        if (held & 8) *(uint4*)(side + 768) = keep3;
     }
     if (aexp2) {
         __builtin_amdgcn_s_waitcnt(0);
@@ -1188,56 +1155,14 @@ __global__ __launch_bounds__(256) void quantize_lo_inplace_kernel(unsigned short
     }
 }
 
-void launch_quantize_lo_inplace(void* a, int ld, int K, int rows, unsigned char* scales, int operand_dtype, hipStream_t st, int* aexp2,
-                                const HotBlocks* hot) {
+void launch_quantize_lo_inplace(void* a, int ld, int K, int rows, unsigned char* scales, int operand_dtype, hipStream_t st, int* aexp2) {
     if (rows <= 0) return;
     if (K % 128 || ld % 8) throw std::runtime_error("quantize_lo_inplace: K must be a multiple of 128 and the row stride of 8");
-    HotBlocks hb{0, {0, 0, 0, 0}};
-    if (hot && hot->n > 0) {
-        hb = *hot;
-        if (aexp2 || hb.n > GemmParams::MAX_HOT || 256 * hb.n > K) throw std::runtime_error("quantize_lo_inplace: hot blocks need exact weights and K >= 256 per block");
-    }
     const dim3 grid((rows + 3) / 4), block(256);
-    if (operand_dtype == DT_F16) hipLaunchKernelGGL(quantize_lo_inplace_kernel<F16>, grid, block, 0, st, (unsigned short*)a, ld, K, rows, scales, aexp2, hb);
-    else hipLaunchKernelGGL(quantize_lo_inplace_kernel<BF16>, grid, block, 0, st, (unsigned short*)a, ld, K, rows, scales, aexp2, hb);
+    if (operand_dtype == DT_F16) hipLaunchKernelGGL(quantize_lo_inplace_kernel<F16>, grid, block, 0, st, (unsigned short*)a, ld, K, rows, scales, aexp2);
+    else hipLaunchKernelGGL(quantize_lo_inplace_kernel<BF16>, grid, block, 0, st, (unsigned short*)a, ld, K, rows, scales, aexp2);
 }
 
-// Calibration statistics (lr_calibrate): one wave per row of an operand's hi half.
-template <typename OT>
-__global__ __launch_bounds__(256) void block_outlier_stats_kernel(const unsigned short* __restrict__ a, int ld, int K, int rows, unsigned* __restrict__ counts,
-                                                                  float ratio) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    const unsigned short* hi = a + (size_t)row * ld;
-    float s = 0.f;
-    for (int k = lane * 8; k < K; k += 512) {
-        const uint4 v = *(const uint4*)(hi + k);
-        const unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s += fabsf(Op<OT>::to_f32((unsigned short)(w[i] & 0xFFFF))) + fabsf(Op<OT>::to_f32((unsigned short)(w[i] >> 16)));
-    }
-    const float thr = ratio * (wave_sum(s) / (float)K);
-    for (int k0 = 0; k0 < K; k0 += 512) {
-        const int k = k0 + lane * 8;
-        float m = 0.f;
-        if (k < K) {
-            const uint4 v = *(const uint4*)(hi + k);
-            const unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) m = fmaxf(m, fmaxf(fabsf(Op<OT>::to_f32((unsigned short)(w[i] & 0xFFFF))), fabsf(Op<OT>::to_f32((unsigned short)(w[i] >> 16)))));
-        }
-        m = row16_max(m);
-        if (k < K && (lane & 15) == 0 && m >= thr && thr > 0.f) atomicAdd(&counts[k >> 7], 1u);
-    }
-    if (lane == 0) atomicAdd(&counts[K >> 7], 1u);
-}
-void launch_block_outlier_stats(const void* a, int ld, int K, int rows, unsigned* counts, float ratio, int operand_dtype, hipStream_t st) {
-    if (rows <= 0) return;
-    if (K % 128 || ld % 8) throw std::runtime_error("block_outlier_stats: K must be a multiple of 128 and the row stride of 8");
-    const dim3 grid((rows + 3) / 4), block(256);
-    if (operand_dtype == DT_F16) hipLaunchKernelGGL(block_outlier_stats_kernel<F16>, grid, block, 0, st, (const unsigned short*)a, ld, K, rows, counts, ratio);
-    else hipLaunchKernelGGL(block_outlier_stats_kernel<BF16>, grid, block, 0, st, (const unsigned short*)a, ld, K, rows, counts, ratio);
-}
 
 // W8 twin of a weight matrix [N, K] (2-byte elements, row stride ldw): e4m3(W * 2^(127 - E)) into the first K bytes of the rows of
 // `dst` (same row stride, in 2-byte units), one exponent per TENSOR.  amax_bits: device word, max |w| as float bits.

@@ -14,7 +14,7 @@ LR_MAX_HALF_HEAD = 64
 LR_MAX_PINPOINTS = 8
 LR_MAX_FULLATT = 8
 LR_BACKBONE_PHI3V, LR_BACKBONE_LLAVA_NEXT, LR_BACKBONE_QWEN2_5_VL = 0, 1, 2
-LR_ABI_VERSION = 7
+LR_ABI_VERSION = 8
 EPI_OUT_OP, EPI_OUT_F32, EPI_RESADD_F32, EPI_SWIGLU_OP, EPI_ROPE_OP = 0, 1, 2, 3, 4
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2
 
@@ -49,6 +49,7 @@ class ModelDesc(C.Structure):
         ("mean_hidden_state", C.c_int32),
         ("w8a8", C.c_int32),
         ("lora_rank", C.c_int32),
+        ("rope_flash_convention", C.c_int32),
     ]
 
 
@@ -74,7 +75,7 @@ _SIGS = {
     "lr_read_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "lr_set_layer_limits": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "lr_set_precision_map": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "lr_calibrate": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int)]),
+    "lr_weights_epoch": (C.c_uint64, [C.c_void_p]),
     "lr_set_gemm_tile": (C.c_int, [C.c_void_p, C.c_int]),
     "lr_op_gemm_bt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]),
     "lr_op_gemm_bt_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),
@@ -87,7 +88,6 @@ _SIGS = {
     "lr_op_gemm_fp8": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_void_p]),
     "lr_op_gemm_bt_mixed": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7 + [C.POINTER(C.c_int), C.c_void_p]),
     "lr_op_lo8_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
-    "lr_op_set_hot_blocks": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "lr_op_norm_rows": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "lr_op_synth_fill": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_char_p, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "lr_hd_transform_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

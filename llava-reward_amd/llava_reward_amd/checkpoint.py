@@ -49,7 +49,10 @@ def config_from_hf(path: str, reward_cfg: dict) -> RewardConfig:
         is_general_preference=bool(reward_cfg["is_general_preference"]),
         add_cross_attention=bool(reward_cfg["add_cross_attention"]),
         value_head_dim=int(reward_cfg["value_head_dim"]),
-        general_preference_tau=float(reward_cfg["general_preference_tau"]))
+        general_preference_tau=float(reward_cfg["general_preference_tau"]),
+        # the checkpoint's config.json names the attention class the reference instantiates (modeling_phi3_v.py:1123-1135); the
+        # flash class switches the su-RoPE tables one token earlier (:793-794)
+        rope_flash_convention=c.get("_attn_implementation") == "flash_attention_2")
 
 
 def llava_config_from_hf(path: str, reward_cfg: dict) -> LlavaConfig:

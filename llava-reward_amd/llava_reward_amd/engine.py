@@ -91,6 +91,8 @@ def make_desc(cfg, max_batch: int, max_seq: int, max_crops: int, operand_dtype: 
     d.mean_hidden_state = 1 if mean_hidden_state else 0
     d.w8a8 = 1 if operand_dtype == "fp8" else 0
     d.lora_rank = int(getattr(cfg, "lora_rank", 0))
+    # Phi3FlashAttention2's su-RoPE switch point (modeling_phi3_v.py:793-794): what the reference's --flash_attn scripts run
+    d.rope_flash_convention = 1 if getattr(cfg, "rope_flash_convention", False) else 0
     if d.lora_rank and d.w8a8:
         raise ValueError("operand_dtype='fp8' (W8A8) runs merged weights only: load the adapter with merge=True")
     return d
@@ -246,20 +248,9 @@ class RewardEngine:
         L.check(self.lib, self.lib.lr_set_precision_map(self.h, clip_form, decoder_mid_form, decoder_first, decoder_last), self.h,
                 "lr_set_precision_map")
 
-    def calibrate_begin(self, ratio: float = 64.0) -> None:
-        L.check(self.lib, self.lib.lr_calibrate(self.h, 1, ratio, 0.0, None), self.h, "lr_calibrate(begin)")
-
-    def calibrate_end(self, row_fraction: float = 0.002) -> int:
-        """-> number of GEMM operands that got a hot-block list (lr_calibrate)."""
-        n = C.c_int(0)
-        L.check(self.lib, self.lib.lr_calibrate(self.h, 0, 0.0, row_fraction, C.byref(n)), self.h, "lr_calibrate(end)")
-        return n.value
-
-    def clear_calibration(self) -> None:
-        """Forget the hot-block lists and return every stage to the descriptor's operand form."""
-        self.calibrate_begin()
-        self.calibrate_end()
-        self.set_precision_map(-1, -1, 0, 0)
+    def weights_epoch(self) -> int:
+        """Counts the calls that changed this handle's weights (lr_weights_epoch): what was derived from them is stale once it moves."""
+        return int(self.lib.lr_weights_epoch(self.h))
 
     def set_gemm_tile(self, tile: int) -> None:
         L.check(self.lib, self.lib.lr_set_gemm_tile(self.h, tile), self.h, "lr_set_gemm_tile")

@@ -17,10 +17,25 @@ import torch
 from .synth import LlavaConfig, QwenConfig, RewardConfig, llava_geometry
 
 
+class _Outputs(dict):
+    """`outputs` of custom_forward(return_output=True).  The reference hands back the backbone's whole output object; this one
+    holds what its callers read.  A key the forward did not compute fails with the reason instead of a bare KeyError."""
+
+    def __missing__(self, key):
+        if key == "last_hidden_state":
+            raise KeyError("last_hidden_state: with layer_id != 32 the forward stops after `layer_id` decoder layers (the reward is read from "
+                           "hidden_states[layer_id], rw_model_general_preference.py:349-352), so the final norm of the full stack was never "
+                           "computed; read outputs['hidden_states_at_layer_id'], or build the model with layer_id=32")
+        if key == "hidden_states":
+            raise KeyError("hidden_states: the per-layer tuple is not materialised (33 x [B, S, hidden]); use layer_id=<k> for one of them")
+        raise KeyError(key)
+
+
 class RewardModel:
     def __init__(self, cfg, weights: Optional[Dict[str, torch.Tensor]] = None, synth_seed: Optional[int] = None,
                  max_batch: int = 32, max_seq: int = 2816, max_crops: int = 17, operand_dtype: str = "f16x2f8",
-                 layer_id: int = 32, mean_hidden_state=None, max_patches: int = 0, synth_profile: int = 0):
+                 layer_id: int = 32, mean_hidden_state=None, max_patches: int = 0, synth_profile: int = 0,
+                 calibrate: bool = True, parity_budget: float = 3e-4):
         if weights is None and synth_seed is None:
             raise ValueError("RewardModel needs weights or a synth_seed")
         # rw_model:349-352: layer_id == 32 (the literal) -> last_hidden_state, else hidden_states[layer_id] = the input of decoder
@@ -42,7 +57,15 @@ class RewardModel:
         # True: every forward keeps all hidden states through the last layer (read_tap("x") / last_hidden_state afterwards);
         # custom_forward(return_output=True) does so by itself.  Default: the last layer computes the reward rows only.
         self.keep_hidden_states = False
-        self.operand_form = "default"          # "strict" once calibrate() has found the default form outside its parity budget
+        # Operand form of the default parity mode ("f16x2f8"), locked by .to('cuda') on the loaded weights (_lock_operand_form):
+        # "default" = f16 hi + e4m3 residual passes, "strict" = 16-bit residual passes everywhere (1.33x the step time).
+        # calibrate=False (load_reward_adaptor: args.calibrate = False) skips the self-check and keeps "default".
+        self.operand_form = "default"
+        self.form_info: Optional[Dict[str, object]] = None      # {"form", "default_vs_strict", "source", "rows", "budget"} of the last check
+        self.auto_calibrate = bool(calibrate)
+        self.parity_budget = float(parity_budget)
+        self._form_epoch = None                # lr_weights_epoch the locked form belongs to
+        self._in_probe = False
         self.training = False
         self.device = torch.device("cpu")
         self.is_general_preference = cfg.is_general_preference
@@ -66,10 +89,16 @@ class RewardModel:
         else:
             eng.synth_weights(self._synth_seed, getattr(self, "synth_fp32_valued", False), self._synth_profile)
         eng.finalize()
+        moved = self.engine is not None          # same weights on another device: the locked form is a property of the weights
         if self.engine is not None:
             self.engine.close()
         self.engine = eng
         self.device = torch.device("cuda", idx)
+        if moved and self.form_info is not None:
+            self._form_epoch = eng.weights_epoch()
+            self._apply_form()
+        else:
+            self._lock_operand_form()
         return self
 
     def cuda(self, device=None):
@@ -83,49 +112,86 @@ class RewardModel:
         self.training = bool(mode)
         return self
 
-    def calibrate(self, *batches, parity_budget: float = 2.5e-4, hot_blocks: bool = True, ratio: float = 64.0,
-                  row_fraction: float = 0.002) -> Dict[str, object]:
-        """Self-check of the default parity form (f16 hi + e4m3 residual passes, ~15 bits per operand) on the caller's OWN weights and
-        data, once after loading -- no reference needed.  `batches`: a few representative dicts of custom_forward keyword arguments.
-          1. outlier channels (include/llava_reward_hip.h lr_calibrate): GEMM operands whose columns carry massive activations get
-             hot blocks (16-bit residuals there);
-          2. the batches are scored in the default form and in the strict form (16-bit residual passes everywhere, 22 bits per
-             operand, 1.33x the step time; measured <= 6e-6 from the fp32 reference on every full-size golden, outlier-bearing
-             weights included).  If any reward differs by more than `parity_budget`, the model amplifies operand rounding beyond
-             what the default form can carry (outlier-bearing weight sets do: 15-25x) and the engine STAYS in the
-             strict form from then on; else it returns to the default form.
-        Returns {"form": "default" | "strict", "default_vs_strict": max |difference|, "hot_operands": n}.  Static afterwards: a row's
-        reward stays independent of the batch it is scored in.  Under torch.distributed call it on every rank with the SAME batches
-        (the decision is all-reduced; identical batches also give identical hot-block lists).  No reference counterpart (the reference runs fp32 / bf16 operands)."""
+    # -- operand form of the default parity mode: locked on the weights, never on the data being scored --
+    def _apply_form(self) -> None:
+        if self.engine is None or self._opts["operand_dtype"] != "f16x2f8":
+            return
+        if self.operand_form == "strict":
+            self.engine.set_precision_map(1, 1, 0, 0)
+        else:
+            self.engine.set_precision_map(-1, -1, 0, 0)
+
+    def _compare_forms(self, batches, budget: float, source: str) -> Dict[str, object]:
+        """Score `batches` in the default and in the strict form, keep the strict form iff any reward differs by more than `budget`
+        (or is not finite).  Whatever happens, the engine is left in the form `self.operand_form` names."""
+        eng = self.engine
+        was_training, self.training = self.training, False
+        self._in_probe = True
+        try:
+            eng.set_precision_map(-1, -1, 0, 0)
+            default = [self.custom_forward(**b)[0].float().clone() for b in batches]
+            eng.set_precision_map(1, 1, 0, 0)
+            strict = [self.custom_forward(**b)[0].float() for b in batches]
+            d = 0.0
+            for a, st in zip(default, strict):
+                x = float((a - st).abs().max()) if a.numel() else 0.0
+                d = float("inf") if x != x else max(d, x)         # NaN anywhere: not a form to trust
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                # every rank must end in the same form (rewards are bit-identical across shardings only then): the probe rows are
+                # the same on every rank by construction; user batches should be too -- the largest distance any rank saw decides
+                t = torch.tensor([min(d, 3.0e38)], dtype=torch.float64, device=self.device if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                d = float(t.item())
+            self.operand_form = "strict" if d > budget else "default"
+            self.form_info = {"form": self.operand_form, "default_vs_strict": d, "source": source,
+                              "rows": int(sum(a.shape[0] for a in default)), "budget": budget}
+            return dict(self.form_info)
+        finally:
+            self._in_probe = False
+            self.training = was_training
+            self._apply_form()
+
+    def _lock_operand_form(self) -> None:
+        """Runs in .to('cuda') and again whenever the engine's weights have changed since (lr_weights_epoch): the default form is
+        checked against the strict form on the seeded probe rows of probe.py -- a function of the weights and the engine's capacity
+        alone, so every rank, batch and shard of a deployment locks the same form -- and the engine stays STRICT when any probe reward
+        differs by more than `parity_budget`.  Measured on the full-size synthetic weight sets (max over the 4 probe rows): benign
+        Phi-3.5-V 3e-5 .. 1.9e-4, LLaVA-7B 0.9 .. 1.5e-4, Qwen2.5-VL-7B 1.6 .. 2.3e-4 (their default-form errors against the
+        reference: <= 1e-4); outlier-bearing Phi-3.5-V 2.4e-3 .. 1.6e-2 (default-form errors 4.8e-4 .. 2.6e-3), with adapters 3.4e-3.
+        The budget, 3e-4, is the bound the golden tests hold the default form to -- a third of the 1e-3 bar."""
+        self._form_epoch = self.engine.weights_epoch()
+        if self._opts["operand_dtype"] != "f16x2f8":
+            return
+        self.operand_form, self.form_info = "default", None
+        if not self.auto_calibrate:
+            self._apply_form()
+            return
+        from .probe import probe_batches
+        batches = probe_batches(self)
+        if not batches:            # an engine too small for any probe row: nothing to measure on, stay on the safe side
+            self.operand_form = "strict"
+            self.form_info = {"form": "strict", "default_vs_strict": None, "source": "no probe row fits the engine's capacity", "rows": 0,
+                              "budget": self.parity_budget}
+            self._apply_form()
+            return
+        self._compare_forms(batches, self.parity_budget, "probe")
+
+    def calibrate(self, *batches, parity_budget: float = 2.5e-4) -> Dict[str, object]:
+        """Refinement of the automatic check of .to('cuda') on the caller's OWN data: `batches` (a few representative dicts of
+        custom_forward keyword arguments) are scored in the default and in the strict form (16-bit residual passes everywhere, 22 bits
+        per operand, 1.33x the step time; measured <= 6e-6 from the fp32 reference on every full-size golden, outlier-bearing weights
+        included); if any reward differs by more than `parity_budget` the engine STAYS in the strict form, else it runs the default
+        form -- also when the automatic probe had chosen the strict one.  Returns {"form", "default_vs_strict", "source", "rows",
+        "budget"}.  Static afterwards (until the weights change): a row's reward stays independent of the batch it is scored in.
+        Under torch.distributed call it on every rank with the SAME batches (the decision is all-reduced).  No reference
+        counterpart (the reference runs fp32 / bf16 operands)."""
         if self.engine is None:
             raise RuntimeError("calibrate: model is on CPU; call model.to('cuda') first")
         if self._opts["operand_dtype"] != "f16x2f8":
             raise ValueError("calibrate applies to the default parity form (operand_dtype='f16x2f8')")
-        eng = self.engine
-        eng.set_precision_map(-1, -1, 0, 0)
-        n = 0
-        if hot_blocks:
-            eng.calibrate_begin(ratio)
-            try:
-                for b in batches:
-                    self.custom_forward(**b)
-            finally:
-                n = eng.calibrate_end(row_fraction)
-        default = [self.custom_forward(**b)[0].float().clone() for b in batches]
-        eng.set_precision_map(1, 1, 0, 0)
-        strict = [self.custom_forward(**b)[0].float() for b in batches]
-        d = max((float((a - s).abs().max()) for a, s in zip(default, strict)), default=0.0)
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            # every rank must end in the same form (rewards are bit-identical across shardings only then): give every rank the SAME
-            # batches -- the hot-block lists are then identical too -- and take the largest distance any rank saw
-            t = torch.tensor([d], dtype=torch.float64, device=self.device if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            d = float(t.item())
-        self.operand_form = "strict" if d > parity_budget else "default"
-        if self.operand_form == "default":
-            eng.set_precision_map(-1, -1, 0, 0)
-        return {"form": self.operand_form, "default_vs_strict": d, "hot_operands": n}
+        self._form_epoch = self.engine.weights_epoch()
+        return self._compare_forms(list(batches), parity_budget, "calibrate")
 
     def custom_forward(self, input_ids=None, attention_mask=None, pixel_values=None, image_sizes=None,
                        return_output=False, inputs_batch=None):
@@ -134,6 +200,8 @@ class RewardModel:
         if self.engine is None:
             raise RuntimeError("custom_forward: model is on CPU; call model.to('cuda') first "
                                "(the scoring path has no CPU fallback)")
+        if not self._in_probe and self._form_epoch != self.engine.weights_epoch():
+            self._lock_operand_form()         # weights re-uploaded / re-synthesised since the form was locked: check it again on them
         if self.model_type == "qwen":
             return self._custom_forward_qwen(inputs_batch, return_output)
         if inputs_batch is not None and input_ids is None:
@@ -188,10 +256,10 @@ class RewardModel:
             # layer_id != 32: the reference's outputs["last_hidden_state"] would still be the final norm of the FULL stack, which this
             # forward (stopped after layer_id layers) never computed -- so the key is not offered; what the reward was read from,
             # hidden_states[layer_id] (rw_model:351-352), comes back under its own name
-            return reward, {"hidden_states_at_layer_id": self.engine.last_hidden_state(B, S, no_final_norm=True),
-                            "last_hidden_state_at_reward_token": hl}
-        return reward, {"last_hidden_state": self.engine.last_hidden_state(B, S, no_final_norm=False),
-                        "last_hidden_state_at_reward_token": hl}
+            return reward, _Outputs({"hidden_states_at_layer_id": self.engine.last_hidden_state(B, S, no_final_norm=True),
+                                     "last_hidden_state_at_reward_token": hl})
+        return reward, _Outputs({"last_hidden_state": self.engine.last_hidden_state(B, S, no_final_norm=False),
+                                 "last_hidden_state_at_reward_token": hl})
 
     def _custom_forward_qwen(self, inputs_batch, return_output):
         """rw_model_general_preference.py:354-371: the qwen branch reads everything from `inputs_batch` (the

@@ -44,6 +44,8 @@ def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=Fal
             raise FileNotFoundError(f"args.pretrain={args.pretrain!r} must be a local checkpoint directory "
                                     "(config.json + *.safetensors); hub download is not available offline")
         cfg = ckpt.config_from_hf(args.pretrain, reward_cfg)
+        if getattr(args, "flash_attn", False):         # the reference's scripts pass --flash_attn (eval/batch_inference_rm_phi.py:162)
+            cfg.rope_flash_convention = True
         names = [n for n, *_ in weight_specs(cfg)]
         head_names = {n for n in names if n.split(".")[0] in ("value_head", "W_q", "W_k", "W_v", "ca_layernorm")}
         weights = ckpt.read_base_weights(args.pretrain, [n for n in names if n not in head_names])
@@ -53,7 +55,7 @@ def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=Fal
         model = RewardModel(cfg, weights=weights,
                             max_batch=getattr(args, "max_batch", 32), max_seq=getattr(args, "max_seq", 2816),
                             max_crops=getattr(args, "max_crops", 17),
-                            operand_dtype=getattr(args, "operand_dtype", "f16x2f8"))
+                            operand_dtype=getattr(args, "operand_dtype", "f16x2f8"), calibrate=getattr(args, "calibrate", True))
         model.model_type = "phi3v"
         if load_tokenizer:
             from transformers import AutoProcessor
@@ -77,7 +79,7 @@ def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=Fal
         weights.update(ckpt.read_heads(args.pm_path, cfg, getattr(args, "ft_projector", False)))
         model = RewardModel(cfg, weights=weights, max_batch=getattr(args, "max_batch", 32),
                             max_seq=getattr(args, "max_seq", 4096), max_crops=getattr(args, "max_crops", 5),
-                            operand_dtype=getattr(args, "operand_dtype", "f16x2f8"))
+                            operand_dtype=getattr(args, "operand_dtype", "f16x2f8"), calibrate=getattr(args, "calibrate", True))
         if load_tokenizer:
             from transformers import LlavaNextProcessor
             processor = LlavaNextProcessor.from_pretrained(args.pretrain, cache_dir=getattr(args, "cache_dir", None))   # utils/utils.py:46-55
@@ -99,7 +101,7 @@ def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=Fal
         weights.update(ckpt.read_heads(args.pm_path, cfg, getattr(args, "ft_projector", False)))
         model = RewardModel(cfg, weights=weights, max_batch=getattr(args, "max_batch", 32),
                             max_seq=getattr(args, "max_seq", 2048), max_patches=getattr(args, "max_patches", 0),
-                            operand_dtype=getattr(args, "operand_dtype", "f16x2f8"))
+                            operand_dtype=getattr(args, "operand_dtype", "f16x2f8"), calibrate=getattr(args, "calibrate", True))
         if load_tokenizer:
             from transformers import AutoProcessor
             processor = AutoProcessor.from_pretrained(args.pretrain, cache_dir=getattr(args, "cache_dir", None),

@@ -65,13 +65,14 @@ class GatherHandle:
         return self._out
 
 
-def gather_rewards_async(local: torch.Tensor, n_total: Optional[int] = None) -> GatherHandle:
+def gather_rewards_async(local: torch.Tensor, n_total: Optional[int] = None, always_collective: bool = False) -> GatherHandle:
     """All-gather per-rank rewards [n_r, d] -> [n_total, d] on every rank; ragged shards are padded to the largest shard for the
     collective.  Device tensors under RCCL (backend "nccl"): the collective is enqueued on a dedicated stream behind an event of the
     compute stream, so the next forward (the rejected rows of a pair) is not ordered behind it.  Device tensors
-    under a backend without device collectives (gloo) are staged through the host; host tensors gather as they are."""
+    under a backend without device collectives (gloo) are staged through the host; host tensors gather as they are.
+    always_collective: enter the collective even in a world of one rank (tests: the RCCL / side-stream branch on a single GPU)."""
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 and not (always_collective and dist.is_available() and dist.is_initialized()):
         return GatherHandle(local)
     if local.is_cuda and dist.get_backend() != "nccl":
         return GatherHandle(_all_gather(local.cpu(), n_total, ws).to(local.device))
@@ -253,7 +254,9 @@ class PrefetchingBatcher:
     into batches of `batch_size`, or (batch_size=None) a list of ready-made chunks.  A background thread prepares batches k + 1 ..
     k + depth while batch k is scored: image files are decoded by a small thread pool (PIL releases the GIL), the uint8 pixels cross
     PCIe and go through lr_hd_transform on a SIDE stream, prompts are tokenised and left-padded; the consumer's stream only waits on
-    the event recorded behind that work.  Phi-3.5-V rows (batch_inference_process_phi3v_device)."""
+    the event recorded behind that work.  Phi-3.5-V rows (batch_inference_process_phi3v_device).
+    A consumer that stops early (an exception in custom_forward, a `break`) must call close() -- or use the object as a context
+    manager -- so that the producer thread ends and the prefetched device batches are released."""
 
     def __init__(self, items, tokenizer, batch_size: Optional[int] = 32, num_crops: int = 16, device="cuda", depth: int = 2, workers: int = 4,
                  pad_token_id: Optional[int] = None):
@@ -269,12 +272,43 @@ class PrefetchingBatcher:
         self.workers = max(1, int(workers))
         self._q = queue.Queue(maxsize=max(1, int(depth)))
         self._err = None
+        self._stop = threading.Event()
         self._stream = torch.cuda.Stream(device=self.device)
         self._thread = threading.Thread(target=self._produce, daemon=True)
         self._thread.start()
 
     def __len__(self):
         return len(self.chunks)
+
+    def _put(self, item) -> bool:
+        """queue.put that gives up when close() was called (a bounded queue nobody reads would block the producer forever)."""
+        import queue
+        while not self._stop.is_set():
+            try:
+                self._q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def close(self):
+        """Stop the producer thread and drop what it had prefetched.  Idempotent; called by __exit__ and by score_pairwise_files."""
+        import queue
+        self._stop.set()
+        for _ in range(2):               # unblock a producer waiting on the full queue, release the device batches it holds
+            while True:
+                try:
+                    self._q.get_nowait()
+                except queue.Empty:
+                    break
+            self._thread.join(timeout=30)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def _produce(self):
         from concurrent.futures import ThreadPoolExecutor
@@ -283,20 +317,23 @@ class PrefetchingBatcher:
             torch.cuda.set_device(self.device)
             with ThreadPoolExecutor(max_workers=self.workers) as pool:
                 for chunk in self.chunks:
+                    if self._stop.is_set():
+                        break
                     pixels = list(pool.map(lambda it: _load_rgb(it[0]), chunk))               # decode off the main thread
                     with torch.cuda.stream(self._stream):
                         batch = batch_inference_process_phi3v_device(None, self.tok, [(p, it[1]) for p, it in zip(pixels, chunk)],
                                                                      device=self.device, num_crops=self.num_crops, pad_token_id=self.pad)
                         ev = torch.cuda.Event()
                         ev.record(self._stream)
-                    self._q.put((batch, ev))
+                    if not self._put((batch, ev)):
+                        break
         except BaseException as e:          # surfaced on the consumer's side
             self._err = e
         finally:
-            self._q.put(None)
+            self._put(None)
 
     def __iter__(self):
-        while True:
+        while not self._stop.is_set():
             item = self._q.get()
             if item is None:
                 if self._err is not None:
@@ -331,8 +368,8 @@ def score_pairwise_files(model, args, tokenizer, pairs, batch_size: int = 32, nu
     d = int(getattr(model, "value_head_dim", 1))
     cs = [torch.empty((0, d), dtype=torch.float32, device=device)]
     rs = [torch.empty((0, d), dtype=torch.float32, device=device)]
-    batches = PrefetchingBatcher(chunks, tokenizer, batch_size=None, num_crops=num_crops, device=device, depth=depth, workers=workers,
-                                 pad_token_id=pad_token_id)
-    for i, batch in enumerate(batches):
-        (cs if i % 2 == 0 else rs).append(model.custom_forward(**batch)[0].float().reshape(-1, d))
+    with PrefetchingBatcher(chunks, tokenizer, batch_size=None, num_crops=num_crops, device=device, depth=depth, workers=workers,
+                            pad_token_id=pad_token_id) as batches:          # (closed on any exit: an exception in custom_forward included)
+        for i, batch in enumerate(batches):
+            (cs if i % 2 == 0 else rs).append(model.custom_forward(**batch)[0].float().reshape(-1, d))
     return _pairwise_stats(args, [gather_rewards(torch.cat(cs, dim=0), len(pairs))], [gather_rewards(torch.cat(rs, dim=0), len(pairs))])

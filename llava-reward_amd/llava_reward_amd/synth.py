@@ -80,6 +80,9 @@ class RewardConfig:
     ca_eps: float = 1e-5          # RMSNorm_class_eps passed by load_reward_adaptor (:32)
     # un-merged LoRA adapter on the decoder linears (eval/reward_adaptor_loader.py:44-45; scripts: --lora_rank 128 --lora_alpha 256)
     lora_rank: int = 0
+    # su-RoPE switch point: False = eager / sdpa attention (long factors iff S > orig_max_pos, modeling_phi3_v.py:673), True =
+    # Phi3FlashAttention2 (:793-794: iff S >= orig_max_pos) -- what the reference's --flash_attn scripts run
+    rope_flash_convention: bool = False
 
     def __post_init__(self):
         if not self.short_factor:

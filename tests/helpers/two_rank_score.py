@@ -49,8 +49,16 @@ def main():
     # same-sized images so that every row sees the same V_max whatever its shard (the reference's SkipCA attends over padded rows)
     pairs = [(f"caption {i}", synth.synth_image(seed, f"c.{i}", 200, 300), synth.synth_image(seed, f"r.{i}", 200, 300)) for i in range(5)]
     fr = score_pairwise_files(model, args, synth.StandInTokenizer(), pairs, batch_size=2, num_crops=1, pad_token_id=cfg.vocab_size - 1)
-    json.dump({"rank": rank, "probs": res["probs"], "proportion": res["proportion"], "candidates": cr.cpu().tolist(), "file_probs": fr["probs"]},
-              open(out_path, "w"))
+    # The operand form: .to('cuda') locked it on the probe rows (the same on every rank; the distance is all-reduced).  calibrate() on
+    # batches that DIFFER per rank must still end with one decision: every rank reports the largest distance any rank saw.
+    probe = dict(model.form_info)
+    kb = [{a: torch.from_numpy(b).cuda() for a, b in synth.synth_batch(cfg, seed + 500 + k, [4 + k, 2], (1, 1)).items()} for k in range(2)]
+    if ws > 1:
+        cal = model.calibrate(kb[rank], parity_budget=1.0)["default_vs_strict"]
+    else:
+        cal = [model.calibrate(b, parity_budget=1.0)["default_vs_strict"] for b in kb]
+    json.dump({"rank": rank, "probs": res["probs"], "proportion": res["proportion"], "candidates": cr.cpu().tolist(), "file_probs": fr["probs"],
+               "probe_form": probe["form"], "probe_distance": probe["default_vs_strict"], "calibrate_distance": cal}, open(out_path, "w"))
     if ws > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -77,16 +77,12 @@ def test_llava_reference_goldens(path, dtype):
     assert torch.equal(_fwd(m, batch).reshape(ref.shape), got)
     if dtype == "f16x2":
         assert err < (3e-4 if g.get("weight_profile", 0) & synth.PROFILE_OUTLIER else 1e-4)      # (outlier rows: fp32 summation-order noise amplified too)
-    elif dtype == "f16x2f8" and err >= 3e-4 and g.get("weight_profile", 0) & synth.PROFILE_OUTLIER:
-        # outlier-bearing weights amplify operand rounding 15-25x: outside the default form's budget at full depth.  calibrate() sees
-        # it on the loaded weights (default vs strict form, no reference needed) and keeps the engine strict
-        assert err < 5e-3
-        info = m.calibrate({"inputs_batch": {k: torch.from_numpy(v).cuda() for k, v in batch.items()}})
-        err2 = (_fwd(m, batch).reshape(ref.shape) - ref).abs().max().item()
-        print(f"[{g['name']} {dtype}] after calibrate(): {info} err={err2:.3e}")
-        assert info["form"] == "strict" and err2 < 3e-4
     elif dtype == "f16x2f8":
-        assert err < 3e-4                        # e4m3 residual pass (default parity mode): measured 1.1e-6 on the full-size row
+        # default parity mode through the bare drop-in sequence: .to('cuda') locked the operand form on these weights by itself
+        # (e4m3 residual passes where the model carries them -- measured <= 9.4e-5 on the full-size rows, outlier and e4m3-valued
+        # weights included -- or the strict form where the probe rows say it does not)
+        print(f"[{g['name']} {dtype}] form locked by .to('cuda'): {m.form_info}")
+        assert err < 3e-4
     elif "full" in g["name"]:
         # single-pass f16 is NOT a parity mode: at full depth it is noise-limited -- numerically equivalent builds of the same row
         # (tile shape = summation order) land anywhere within a few 1e-3 of the reference (sigma ~ 7e-4 for Phi-3.5-V,

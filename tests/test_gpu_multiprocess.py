@@ -36,6 +36,20 @@ def test_two_rank_processes_on_one_gpu_equal_single_process(tmp_path):
         assert got["rank"] == r and got["probs"] == ref["probs"] and got["proportion"] == ref["proportion"]      # bit-identical on every rank
         assert len(got["candidates"]) == 5 and got["candidates"] == ref["candidates"]                            # score_candidates: sharded 3 + 2
         assert len(got["file_probs"]) == 5 and got["file_probs"] == ref["file_probs"]                            # score_pairwise_files: pairs sharded 3 + 2
+        # the operand form locked by .to('cuda') is the single process's (same probe rows, same distance), and a calibrate() call fed
+        # DIFFERENT batches on the two ranks ends with one decision: the largest distance either rank measured
+        assert got["probe_form"] == ref["probe_form"] and got["probe_distance"] == ref["probe_distance"]
+        assert got["calibrate_distance"] == max(ref["calibrate_distance"])
+
+
+def test_rccl_side_stream_gather_in_a_world_of_one_rank():
+    """RCCL refuses two ranks on one device, but a world of ONE rank is a legal communicator: the device-collective branch of
+    gather_rewards_async (side stream behind the compute stream, all_gather_into_tensor and the padded ragged form, GatherHandle.wait)
+    runs on the real transport library."""
+    helper = os.path.join(ROOT, "tests", "helpers", "one_rank_rccl.py")
+    port = 29950 + os.getpid() % 40
+    r = subprocess.run([sys.executable, helper], env=_env(0, 1, port), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ONE_RANK_RCCL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
 def test_bench_two_ranks_on_one_device(tmp_path):

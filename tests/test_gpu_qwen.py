@@ -208,18 +208,10 @@ def test_qwen_reference_golden_full_size(path, dtype):
     got = _fwd(m, batch).reshape(ref.shape)
     err = (got - ref).abs().max().item()
     print(f"[{g['name']} {dtype}] reward hip={got.flatten().tolist()} ref={ref.flatten().tolist()} err={err:.3e}")
-    if dtype == "f16x2f8" and err >= 3e-4 and g.get("weight_profile", 0) & synth.PROFILE_OUTLIER:
-        # outlier-bearing weights amplify operand rounding 15-25x: outside the default form's budget at full depth.  calibrate() sees
-        # it on the loaded weights (default vs strict form, no reference needed) and keeps the engine strict
-        assert err < 5e-3
-        info = m.calibrate({"inputs_batch": {k: torch.from_numpy(v).cuda() for k, v in batch.items()}})
-        got = _fwd(m, batch).reshape(ref.shape)
-        err = (got - ref).abs().max().item()
-        print(f"[{g['name']} {dtype}] after calibrate(): {info} err={err:.3e}")
-        assert info["form"] == "strict" and err < 3e-4
-    else:
-        tol = {"f16x2": 3e-4 if g.get("weight_profile", 0) & synth.PROFILE_OUTLIER else 1e-4, "f16x2f8": 3e-4}.get(dtype, 5e-3)
-        assert err < tol      # see the module docstring / DESIGN.md §4 (f16x2f8: measured 8.1e-5; outlier rows: fp32 summation-order noise amplified too)
+    if dtype == "f16x2f8":
+        print(f"[{g['name']} {dtype}] form locked by .to('cuda'): {m.form_info}")      # (the bare drop-in sequence: no calibrate() call)
+    tol = {"f16x2": 3e-4 if g.get("weight_profile", 0) & synth.PROFILE_OUTLIER else 1e-4, "f16x2f8": 3e-4}.get(dtype, 5e-3)
+    assert err < tol      # see the module docstring / DESIGN.md §4 (f16x2f8: measured 8.1e-5; outlier rows: fp32 summation-order noise amplified too)
     dup = dict(input_ids=np.concatenate([batch["input_ids"]] * 2), attention_mask=np.concatenate([batch["attention_mask"]] * 2),
                pixel_values=np.concatenate([batch["pixel_values"]] * 2), image_grid_thw=np.concatenate([batch["image_grid_thw"]] * 2))
     r2 = _fwd(m, dup)

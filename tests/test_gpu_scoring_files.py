@@ -61,3 +61,24 @@ def test_score_pairwise_files_matches_direct_forwards(tmp_path):
         probs.extend(preference_compute(args, c, r).tolist())
     assert out["probs"] == probs and len(probs) == 7
     assert out["proportion"] == sum(p > 0.5 for p in probs) / 7 and abs(out["prob_mean"] - float(np.mean(probs))) < 1e-7
+
+
+def test_prefetching_batcher_closes_when_the_consumer_stops_early(tmp_path):
+    """A consumer that leaves the loop early (an exception in custom_forward, a `break`) must not leave the producer thread blocked
+    on its bounded queue with `depth` device batches alive: close() / the context manager end it."""
+    cfg = synth.tiny_config()
+    tok = synth.StandInTokenizer()
+    paths = _files(tmp_path, 12, 4)
+    items = [(p, "caption") for p in paths]
+    pb = PrefetchingBatcher(items, tok, batch_size=2, num_crops=4, device="cuda", depth=1, workers=2)
+    it = iter(pb)
+    first = next(it)
+    assert first["input_ids"].shape[0] == 2 and pb._thread.is_alive()          # 5 more batches to go, the queue holds one
+    pb.close()
+    assert not pb._thread.is_alive() and pb._q.empty()
+    pb.close()                                                                  # idempotent
+    with pytest.raises(ZeroDivisionError):
+        with PrefetchingBatcher(items, tok, batch_size=2, num_crops=4, device="cuda", depth=1, workers=2) as pb2:
+            for _ in pb2:
+                1 / 0
+    assert not pb2._thread.is_alive()

@@ -21,10 +21,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_header_symbols_are_exported():
     hdr = open(os.path.join(ROOT, "include", "llava_reward_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|size_t|const char\*)\s+(lr_\w+)\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|size_t|uint64_t|const char\*)\s+(lr_\w+)\(", hdr, flags=re.M))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     lib = _lib.load()                      # resolves every symbol; no compute without a GPU
-    assert lib.lr_abi_version() == _lib.LR_ABI_VERSION == 7
+    assert lib.lr_abi_version() == _lib.LR_ABI_VERSION == 8
     assert _lib.ModelDesc.struct_size.offset == 0
 
 
