@@ -234,6 +234,8 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 }
                 src = (j == 0) ? gA[0][it] + koff : (j == 1) ? gB[0][it] + koffw + wsel : (j == 2) ? gB[1][it] + koffw + wsel : gA[1][it] + koff;
             }
+            // (round 4 A/B: declaring M0 clobbered instead of saving / restoring it -- 3 instructions per piece instead of 5 -- changes
+            //  nothing here, +-0.5 % on five shapes: the partner wave's MFMAs cover this wave's issue slots)
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
@@ -1021,6 +1023,7 @@ static void launch8_variant(const GemmParams& p, int variant, hipStream_t st) {
         case 6: { GemmParams q = p; build_segments(q, 0); launch8_epi<OT, 6, 0, 2>(q, true, st); break; }   // product: persistent walk, super-phase schedule
         case 10: launch8_epi<OT, 6, 0, 1>(p, true, st); break;           // A/B: 4-phase schedule + B fragments prefetched inside COMPUTE
         case 13: { GemmParams q = p; build_segments(q, 0); launch8<OT, 6, 3, EPI_OUT_F32, 2>(q, false, st); break; }  // diagnostic only: stamps of the super-phase schedule
+        case 12: { GemmParams q = p; build_segments(q, 0); launch8<OT, 6, 2, EPI_OUT_F32, 2>(q, true, st); break; }   // diagnostic only: the product schedule without its epilogue (results not written)
         case 7: launch8<OT, 5, 1, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: cache-resident operands
         case 8: launch8<OT, 5, 2, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: no epilogue
         case 9: launch8<OT, 5, 3, EPI_OUT_F32>(p, false, st); break;     // diagnostic only: in-kernel stamps -> `bias` buffer
