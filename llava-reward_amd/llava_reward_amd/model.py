@@ -58,7 +58,8 @@ class RewardModel:
         # custom_forward(return_output=True) does so by itself.  Default: the last layer computes the reward rows only.
         self.keep_hidden_states = False
         # Operand form of the default parity mode ("f16x2f8"), locked by .to('cuda') on the loaded weights (_lock_operand_form):
-        # "default" = f16 hi + e4m3 residual passes, "strict" = 16-bit residual passes everywhere (1.33x the step time).
+        # "default" = f16 hi + e4m3 residual passes everywhere, "strict" = 16-bit residual passes everywhere (1.17x the step time),
+        # or one of the forms in between (_form_candidates: strict from the front of the model).
         # calibrate=False (load_reward_adaptor: args.calibrate = False) skips the self-check and keeps "default".
         self.operand_form = "default"
         self.form_info: Optional[Dict[str, object]] = None      # {"form", "default_vs_strict", "source", "rows", "budget"} of the last check
@@ -113,39 +114,60 @@ class RewardModel:
         return self
 
     # -- operand form of the default parity mode: locked on the weights, never on the data being scored --
+    def _form_candidates(self):
+        """(name, lr_set_precision_map arguments) in the order of their cost.  Which stages need 16-bit residual passes on a weight
+        set that amplifies operand rounding was measured on the outlier-bearing synthetic set (tools/prec_map_probe.py ... strict-stages,
+        8 full-size rows, distance to the strict form): default 2.2e-3, vision tower strict 4.4e-4, vision tower + first half of the
+        decoder strict 8.7e-5 -- noise injected early is what the depth amplifies; the LAST decoder layers never matter
+        (decoder 16..31 strict alone: 2.2e-3) -- so the candidates grow from the front of the model."""
+        L = int(self.config.layers)
+        out = [("default", (-1, -1, 0, 0)), ("strict-vision", (1, -1, 0, 0))]
+        for frac, tag in ((4, "/4"), (2, "/2")):
+            k = L // frac
+            if 0 < k < L:
+                out.append((f"strict-vision+decoder{tag}", (1, 1, 0, L - k)))
+        out.append(("strict", (1, 1, 0, 0)))
+        return out
+
     def _apply_form(self) -> None:
         if self.engine is None or self._opts["operand_dtype"] != "f16x2f8":
             return
-        if self.operand_form == "strict":
-            self.engine.set_precision_map(1, 1, 0, 0)
-        else:
-            self.engine.set_precision_map(-1, -1, 0, 0)
+        self.engine.set_precision_map(*dict(self._form_candidates())[self.operand_form])
 
     def _compare_forms(self, batches, budget: float, source: str) -> Dict[str, object]:
-        """Score `batches` in the default and in the strict form, keep the strict form iff any reward differs by more than `budget`
-        (or is not finite).  Whatever happens, the engine is left in the form `self.operand_form` names."""
+        """Score `batches` in the strict form (the yardstick: 16-bit residual passes everywhere) and in the cheaper forms of
+        _form_candidates, cheapest first; lock the first one whose rewards all sit within `budget` of the strict form's (NaN anywhere:
+        not a form to trust).  Whatever happens, the engine is left in the form `self.operand_form` names."""
         eng = self.engine
         was_training, self.training = self.training, False
         self._in_probe = True
         try:
-            eng.set_precision_map(-1, -1, 0, 0)
-            default = [self.custom_forward(**b)[0].float().clone() for b in batches]
-            eng.set_precision_map(1, 1, 0, 0)
-            strict = [self.custom_forward(**b)[0].float() for b in batches]
-            d = 0.0
-            for a, st in zip(default, strict):
-                x = float((a - st).abs().max()) if a.numel() else 0.0
-                d = float("inf") if x != x else max(d, x)         # NaN anywhere: not a form to trust
+            def score(args):
+                eng.set_precision_map(*args)
+                return [self.custom_forward(**b)[0].float().clone() for b in batches]
+            cands = self._form_candidates()
+            strict = score(cands[-1][1])
             import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                # every rank must end in the same form (rewards are bit-identical across shardings only then): the probe rows are
-                # the same on every rank by construction; user batches should be too -- the largest distance any rank saw decides
-                t = torch.tensor([min(d, 3.0e38)], dtype=torch.float64, device=self.device if dist.get_backend() == "nccl" else "cpu")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                d = float(t.item())
-            self.operand_form = "strict" if d > budget else "default"
-            self.form_info = {"form": self.operand_form, "default_vs_strict": d, "source": source,
-                              "rows": int(sum(a.shape[0] for a in default)), "budget": budget}
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            tried, chosen = {}, "strict"
+            for name, args in cands[:-1]:
+                d = 0.0
+                for a, st in zip(score(args), strict):
+                    x = float((a - st).abs().max()) if a.numel() else 0.0
+                    d = float("inf") if x != x else max(d, x)
+                if multi:
+                    # every rank must end in the same form (rewards are bit-identical across shardings only then): the probe rows are
+                    # the same on every rank by construction; user batches should be too -- the largest distance any rank saw decides
+                    t = torch.tensor([min(d, 3.0e38)], dtype=torch.float64, device=self.device if dist.get_backend() == "nccl" else "cpu")
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    d = float(t.item())
+                tried[name] = d
+                if d <= budget:
+                    chosen = name
+                    break
+            self.operand_form = chosen
+            self.form_info = {"form": chosen, "default_vs_strict": tried["default"], "distance_to_strict": tried, "source": source,
+                              "rows": int(sum(a.shape[0] for a in strict)), "budget": budget}
             return dict(self.form_info)
         finally:
             self._in_probe = False
@@ -155,8 +177,8 @@ class RewardModel:
     def _lock_operand_form(self) -> None:
         """Runs in .to('cuda') and again whenever the engine's weights have changed since (lr_weights_epoch): the default form is
         checked against the strict form on the seeded probe rows of probe.py -- a function of the weights and the engine's capacity
-        alone, so every rank, batch and shard of a deployment locks the same form -- and the engine stays STRICT when any probe reward
-        differs by more than `parity_budget`.  Measured on the full-size synthetic weight sets (max over the 4 probe rows): benign
+        alone, so every rank, batch and shard of a deployment locks the same form -- and the engine keeps the cheapest form of
+        _form_candidates whose probe rewards all sit within `parity_budget` of the strict form's (the strict form if none does).  Measured on the full-size synthetic weight sets (max over the 4 probe rows): benign
         Phi-3.5-V 3e-5 .. 1.9e-4, LLaVA-7B 0.9 .. 1.5e-4, Qwen2.5-VL-7B 1.6 .. 2.3e-4 (their default-form errors against the
         reference: <= 1e-4); outlier-bearing Phi-3.5-V 2.4e-3 .. 1.6e-2 (default-form errors 4.8e-4 .. 2.6e-3), with adapters 3.4e-3.
         The budget, 3e-4, is the bound the golden tests hold the default form to -- a third of the 1e-3 bar."""
@@ -179,11 +201,10 @@ class RewardModel:
 
     def calibrate(self, *batches, parity_budget: float = 2.5e-4) -> Dict[str, object]:
         """Refinement of the automatic check of .to('cuda') on the caller's OWN data: `batches` (a few representative dicts of
-        custom_forward keyword arguments) are scored in the default and in the strict form (16-bit residual passes everywhere, 22 bits
-        per operand, 1.33x the step time; measured <= 6e-6 from the fp32 reference on every full-size golden, outlier-bearing weights
-        included); if any reward differs by more than `parity_budget` the engine STAYS in the strict form, else it runs the default
-        form -- also when the automatic probe had chosen the strict one.  Returns {"form", "default_vs_strict", "source", "rows",
-        "budget"}.  Static afterwards (until the weights change): a row's reward stays independent of the batch it is scored in.
+        custom_forward keyword arguments) are scored in the strict form (16-bit residual passes everywhere, 22 bits per operand,
+        1.17x the step time; measured <= 6e-6 from the fp32 reference on every full-size golden, outlier-bearing weights included) and in
+        the cheaper forms, cheapest first; the first one within `parity_budget` of the strict rewards is locked -- whatever the
+        automatic probe had chosen.  Returns {"form", "default_vs_strict", "distance_to_strict", "source", "rows", "budget"}.  Static afterwards (until the weights change): a row's reward stays independent of the batch it is scored in.
         Under torch.distributed call it on every rank with the SAME batches (the decision is all-reduced).  No reference
         counterpart (the reference runs fp32 / bf16 operands)."""
         if self.engine is None:

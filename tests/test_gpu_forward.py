@@ -410,10 +410,10 @@ def test_reference_golden_full_size(path, dtype):
     elif dtype == "f16x2f8" and outlier:
         # The outlier-bearing weight set amplifies ANY operand rounding 15-25x (single-pass f16 lands 1.3e-2 from the strict form there
         # against 5e-4 on benign weights, tools/prec_map_probe.py): the default form's 15 bits would give 4.8e-4 (BT row) / 2.6e-3
-        # (GPM row).  .to('cuda') measured that on its probe rows -- no reference, no caller batches -- and locked the strict form, so
-        # the unchanged drop-in sequence stays inside the bar.
+        # (GPM row).  .to('cuda') measured that on its probe rows -- no reference, no caller batches -- and locked a form with 16-bit
+        # residual passes where this model needs them, so the unchanged drop-in sequence stays inside the bar.
         print(f"[{g['name']} {dtype}] form locked by .to('cuda'): {m.form_info}")
-        assert m.operand_form == "strict" and err < TOL_X8
+        assert m.operand_form != "default" and err < TOL_X8          # (strict, or strict from the front of the model: _form_candidates)
     elif dtype == "f16x2f8":
         # default parity mode (e4m3 residual passes): <= 7e-5 on every benign row, and the probe keeps benign weights in that form
         # (the form is printed, not asserted: a benign weight set whose probe rows land above the budget runs strict -- slower, never

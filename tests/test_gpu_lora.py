@@ -244,7 +244,7 @@ def test_loader_to_engine_llava_and_qwen(tmp_path, backbone, layout):
     err = (got.cpu() - ref).abs().max().item()
     moved = (ref - base).abs().max().item()
     print(f"[loader -> engine, {backbone}, {layout} layout] {model.form_info}; max |reward err| = {err:.2e}; adapter moves the reward by {moved:.2e}")
-    assert moved > 1e-2 and err < 1e-4 + (2e-4 if model.operand_form == "default" else 0.0)
+    assert moved > 1e-2 and err < (1e-4 if model.operand_form == "strict" else 3e-4)
     # the merge=True debug switch computes the same function (fp32-valued merged weights: the inexact-weight path of the default mode)
     args2 = types.SimpleNamespace(**{**vars(args), "merge_lora": True})
     args2, merged = load_reward_adaptor(args2, backbone, os.path.join(pm, "reward_config.yaml"))

@@ -59,7 +59,7 @@ def run_split(lib, name, B, S, H, hd, causal, reps, Hkv):
 
 
 if __name__ == "__main__":
-    lib = L.load()
+    lib = L.load(sys.argv[1]) if len(sys.argv) > 1 else L.load()       # (a library path: A/B against another build on the same box)
     run(lib, "phi", 32, 2642, 32, 96, True)
     run(lib, "clip", 544, 577, 16, 64, False)
     run(lib, "phi", 32, 2642, 32, 96, True, split=True)

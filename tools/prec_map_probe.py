@@ -15,7 +15,7 @@ cfg = synth.full_config()
 b = synth.synth_batch(cfg, 77, [128, 64, 200, 17, 96, 128, 33, 150][:rows] + [128] * max(0, rows - 8), (4, 4), with_pixels=False)
 ids, mask = torch.from_numpy(b["input_ids"]).cuda(), torch.from_numpy(b["attention_mask"]).cuda()
 pix = torch.randn(rows, 17, 3, 336, 336, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
-m = RewardModel(cfg, synth_seed=77, max_batch=rows, max_seq=ids.shape[1], max_crops=17, synth_profile=profile).to("cuda").eval()
+m = RewardModel(cfg, synth_seed=77, max_batch=rows, max_seq=ids.shape[1], max_crops=17, synth_profile=profile, calibrate=False).to("cuda").eval()
 
 
 def run(cm, mid, first, last):
@@ -33,12 +33,19 @@ ref, t_ref = run(1, 1, 0, 0)
 print(f"profile {profile}: rewards (strict) {ref.flatten().tolist()}")
 print(f"{'map':44s} {'rms':>9s} {'max':>9s} {'ms':>8s}")
 L = cfg.layers
-for name, args in [("strict everywhere (f16x2)", (1, 1, 0, 0)), ("default everywhere (f16x2f8)", (-1, -1, 0, 0)),
-                   ("CLIP single pass, decoder default", (0, -1, 0, 0)), ("CLIP strict, decoder default", (1, -1, 0, 0)),
-                   ("CLIP default, decoder single pass", (-1, 0, 0, 0)),
-                   ("decoder layers 4..27 single", (-1, 0, 4, 4)), ("decoder layers 8..23 single", (-1, 0, 8, 8)),
-                   ("decoder layers 12..19 single", (-1, 0, 12, 12)), ("decoder layers 0..15 single", (-1, 0, 0, 16)),
-                   ("decoder layers 16..31 single", (-1, 0, 16, 0)), ("everything single pass (f16)", (0, 0, 0, 0))]:
+MAPS = [("strict everywhere (f16x2)", (1, 1, 0, 0)), ("default everywhere (f16x2f8)", (-1, -1, 0, 0)),
+        ("CLIP single pass, decoder default", (0, -1, 0, 0)), ("CLIP strict, decoder default", (1, -1, 0, 0)),
+        ("CLIP default, decoder single pass", (-1, 0, 0, 0)),
+        ("decoder layers 4..27 single", (-1, 0, 4, 4)), ("decoder layers 8..23 single", (-1, 0, 8, 8)),
+        ("decoder layers 12..19 single", (-1, 0, 12, 12)), ("decoder layers 0..15 single", (-1, 0, 0, 16)),
+        ("decoder layers 16..31 single", (-1, 0, 16, 0)), ("everything single pass (f16)", (0, 0, 0, 0))]
+if len(sys.argv) > 3 and sys.argv[3] == "strict-stages":       # which stages have to be strict on this weight set (round 4)
+    MAPS = [("strict everywhere (f16x2)", (1, 1, 0, 0)), ("default everywhere (f16x2f8)", (-1, -1, 0, 0)),
+            ("CLIP strict, decoder default", (1, -1, 0, 0)), ("CLIP default, decoder strict", (-1, 1, 0, 0)),
+            ("CLIP default, decoder 0..7 strict", (-1, 1, 0, L - 8)), ("CLIP default, decoder 0..15 strict", (-1, 1, 0, L - 16)),
+            ("CLIP default, decoder 16..31 strict", (-1, 1, 16, 0)), ("CLIP default, decoder 24..31 strict", (-1, 1, 24, 0)),
+            ("CLIP strict, decoder 0..15 strict", (1, 1, 0, L - 16))]
+for name, args in MAPS:
     r, ms = run(*args)
     d = (r - ref).abs()
     print(f"{name:44s} {d.pow(2).mean().sqrt().item():9.2e} {d.max().item():9.2e} {ms:8.1f}")
