@@ -35,7 +35,7 @@ class RewardModel:
     def __init__(self, cfg, weights: Optional[Dict[str, torch.Tensor]] = None, synth_seed: Optional[int] = None,
                  max_batch: int = 32, max_seq: int = 2816, max_crops: int = 17, operand_dtype: str = "f16x2f8",
                  layer_id: int = 32, mean_hidden_state=None, max_patches: int = 0, synth_profile: int = 0,
-                 calibrate: bool = True, parity_budget: float = 3e-4):
+                 calibrate: bool = True, parity_budget: float = 1.5e-4):
         if weights is None and synth_seed is None:
             raise ValueError("RewardModel needs weights or a synth_seed")
         # rw_model:349-352: layer_id == 32 (the literal) -> last_hidden_state, else hidden_states[layer_id] = the input of decoder
@@ -178,10 +178,12 @@ class RewardModel:
         """Runs in .to('cuda') and again whenever the engine's weights have changed since (lr_weights_epoch): the default form is
         checked against the strict form on the seeded probe rows of probe.py -- a function of the weights and the engine's capacity
         alone, so every rank, batch and shard of a deployment locks the same form -- and the engine keeps the cheapest form of
-        _form_candidates whose probe rewards all sit within `parity_budget` of the strict form's (the strict form if none does).  Measured on the full-size synthetic weight sets (max over the 4 probe rows): benign
-        Phi-3.5-V 3e-5 .. 1.9e-4, LLaVA-7B 0.9 .. 1.5e-4, Qwen2.5-VL-7B 1.6 .. 2.3e-4 (their default-form errors against the
-        reference: <= 1e-4); outlier-bearing Phi-3.5-V 2.4e-3 .. 1.6e-2 (default-form errors 4.8e-4 .. 2.6e-3), with adapters 3.4e-3.
-        The budget, 3e-4, is the bound the golden tests hold the default form to -- a third of the 1e-3 bar."""
+        _form_candidates whose probe rewards all sit within `parity_budget` of the strict form's (the strict form if none does).
+        Measured on the full-size synthetic weight sets, default form, max over the 4 probe rows: benign Phi-3.5-V 3e-5 .. 1.9e-4,
+        LLaVA-7B 0.9 .. 1.5e-4, Qwen2.5-VL-7B 1.6 .. 2.3e-4 (their default-form errors against the reference on the golden rows:
+        <= 1e-4); outlier-bearing Phi-3.5-V 2.4e-3 .. 1.6e-2 (golden rows 4.8e-4 .. 2.6e-3), with adapters 3.4e-3.  The budget is HALF
+        the bound the golden tests hold the locked form to (3e-4, itself a third of the 1e-3 bar): a form whose 4 probe rows sit
+        within 1.7e-4 of the strict form still landed 3.3e-4 from the reference on a golden row (the rows are draws of one noise)."""
         self._form_epoch = self.engine.weights_epoch()
         if self._opts["operand_dtype"] != "f16x2f8":
             return
