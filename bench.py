@@ -106,7 +106,7 @@ def qwen_flop_per_row(cfg, grid, S):
     return float(lin + att + patch + merger + dec + datt)
 
 
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r3_pmc_gemm_gate_up.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r4_pmc_gemm_gate_up.json")
 KERNEL_SOURCES = ("llava-reward_amd/csrc/gemm8.hip", "llava-reward_amd/csrc/common.h")
 
 
@@ -120,7 +120,7 @@ def kernel_source_sha16():
 
 def pmc_for(form):
     """PMC figures of the dominant kernel (HBM-side bytes per launch, MFMA-pipe busy fraction, effective clock) from the committed
-    rocprofv3 summary profiles/r3_pmc_gemm_gate_up.json (tools/pmc_summary.py writes it from separate --pmc passes of
+    rocprofv3 summary profiles/r4_pmc_gemm_gate_up.json (tools/pmc_summary.py writes it from separate --pmc passes of
     tools/gemm_one.py).  They describe THIS build only if the kernel sources are the ones that were profiled: the file records
     their hash and the kernel's template signature; on any mismatch the fields are null (stale profile) instead of a stale number."""
     none = {"traffic": None, "mfma_busy": None, "clock_ghz": None, "pmc_source": None}
@@ -311,6 +311,9 @@ def main():
     ap.add_argument("--quick", action="store_true", help="main line only: no secondary legs and no golden sweep -- only the timed workload's "
                                                           "launches (plus the dominant-kernel probe's) reach a profiler")
     ap.add_argument("--no-golden", action="store_true", help="skip the live golden sweep (parity_check)")
+    ap.add_argument("--profile-run", action="store_true", help="for rocprofv3 runs (tools/profile_round.sh): --quick, and NOTHING but the timed workload's "
+                    "launches reaches the profiler -- no operand-form probe at .to('cuda') (the default form is pinned: what the probe locks on these "
+                    "weights), no dominant-kernel probe (roofline = the whole pass)")
     ap.add_argument("--profile-weights", default="", choices=["", "outlier", "e4m3"], help="synthetic weight profile of the main workload "
                     "(synth.PROFILE_*): outlier = massive channels / large norm gains, what trained checkpoints show")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the secondary single-pass f16 measurement")
@@ -326,6 +329,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests)")
     ap.add_argument("--all-ranks-on-device", type=int, default=-1, help="smoke test: put every rank on this one GPU")
     a = ap.parse_args()
+    if a.profile_run:
+        a.quick = True
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: become the launcher -- one child process per GPU under torch.distributed.run, started before
@@ -403,12 +408,12 @@ def main():
 
     def build_model(w, dtype, fp32_valued=False, profile=0):
         cfg, B, S = w["cfg"], w["B"], w["S"]
+        kw = dict(operand_dtype=dtype, synth_profile=profile, calibrate=not a.profile_run)
         if w["model"] == "qwen":
-            m = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=max(S, GOLDEN_MAX_SEQ.get("qwen", 0)), max_patches=max(B * 32 * 32, 2048),
-                            operand_dtype=dtype, synth_profile=profile)
+            m = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=max(S, GOLDEN_MAX_SEQ.get("qwen", 0)), max_patches=max(B * 32 * 32, 2048), **kw)
         else:
             m = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=max(S, GOLDEN_MAX_SEQ.get(w["model"], 0)),
-                            max_crops=max(w["ncrop"], 5 if w["model"] == "llava" else 17), operand_dtype=dtype, synth_profile=profile)
+                            max_crops=max(w["ncrop"], 5 if w["model"] == "llava" else 17), **kw)
         m.synth_fp32_valued = fp32_valued
         m = m.to(f"cuda:{local}").eval()
         if a.tile >= 0:
@@ -510,7 +515,7 @@ def main():
         if world == 1:
             full = (a.model != "phi3v" or a.num_crops == 16) and not a.lora_rank      # the golden rows: 17-crop images, no adapter
             res["parity_check"] = golden_check(model, a.model, current=(1234, main_profile)) if (full and not a.quick and not a.no_golden) else None
-            if a.model == "phi3v" and a.num_crops == 16:
+            if a.model == "phi3v" and a.num_crops == 16 and not a.profile_run:
                 dk = dominant_kernel_probe(L.LR_DT_F16 if a.dtype.startswith("f16") else L.LR_DT_BF16, a.tile, split=precise, lo8=a.dtype == "f16x2f8")
                 # the roofline object proper: the dominant kernel, algorithmic FLOPs per launch / its live HIP-event duration
                 res["roofline"].update({"achieved": dk["tflops"], "frac": dk["tflops"] / PEAK_TFLOPS, "traffic": dk["traffic"],
