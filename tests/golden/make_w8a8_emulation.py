@@ -42,5 +42,32 @@ def main():
     json.dump(out, open(os.path.join(HERE, "w8a8_llava_full_emulation.json"), "w"), indent=1)
 
 
+def clip_stage():
+    """Adds the stage-level fingerprint tests/test_gpu_llava.py::test_w8a8_full_size_batch64 holds the engine to (round 4): the CLIP tower's
+    output for the golden row's crops (little has been amplified there yet), fp32 and with the W8A8 operand quantisation, as
+    256 sampled elements each.  Only the tower runs (seconds): `python tests/golden/make_w8a8_emulation.py clip` merges into the fixture."""
+    path = os.path.join(HERE, "w8a8_llava_full_emulation.json")
+    out = json.load(open(path))
+    g = json.load(open(os.path.join(HERE, "ref_llava_full_e4m3_bt.json")))
+    cfg = synth.LlavaConfig.from_json(g["config"])
+    names = [n for n, *_ in synth.llava_weight_specs(cfg) if n.startswith(lorc.CLIP_PREFIX)]
+    specs = {n: (sh, std, off) for n, sh, std, off in synth.llava_weight_specs(cfg)}
+    W = orc.weights_to_torch({n: synth.gen_tensor(g["seed"], n, specs[n][0], specs[n][1], specs[n][2], profile=g["weight_profile"]) for n in names})
+    b = synth.llava_synth_batch(cfg, g["seed"], g["caption_lens"], [tuple(x) for x in g["image_sizes"]], max_crops=g["max_crops"])
+    geo = synth.llava_geometry(*[int(v) for v in b["image_sizes"][0]], cfg.pinpoints, cfg.clip.image, cfg.clip.grid)
+    crops = torch.from_numpy(b["pixel_values"][0, : 1 + geo[0] * geo[1]])
+    gen = torch.Generator().manual_seed(99)
+    for key, opr in (("fp32", orc.Ident), ("w8a8", orc.W8A8Round(orc.f16_round))):
+        f = orc.clip_tower(W, crops, cfg.clip, opr, prefix=lorc.CLIP_PREFIX).reshape(-1)
+        if key == "fp32":
+            idx = torch.randperm(f.numel(), generator=gen)[:256].sort().values
+            out["clip_out_shape"] = [crops.shape[0], cfg.clip.tokens - 1, cfg.clip.hidden]
+            out["clip_out_idx"] = idx.tolist()
+        out["clip_out_" + key] = f[idx].tolist()
+    d = (torch.tensor(out["clip_out_fp32"]) - torch.tensor(out["clip_out_w8a8"])).abs().max().item()
+    print(f"CLIP tower, {crops.shape[0]} crops: max |fp32 - w8a8 emulation| over the 256 samples = {d:.3e}")
+    json.dump(out, open(path, "w"), indent=1)
+
+
 if __name__ == "__main__":
-    main()
+    clip_stage() if len(sys.argv) > 1 and sys.argv[1] == "clip" else main()

@@ -136,3 +136,16 @@ def test_w8a8_full_size_batch64():
     print(f"[w8a8 LLaVA-7B B=64] row 0 hip {got:.5f}  emulation {emu:.5f}  twin emulation {twin:.5f}  fp32 reference {ref:.5f}")
     assert r.shape == (B, 1) and torch.isfinite(r).all() and torch.equal(r, r2) and torch.equal(r0[0], r[0])
     assert abs(got - emu) < 3.0 * max(abs(twin - emu), 1e-2)
+    # Stage level, where little has been amplified yet (round 4; the bound of the tiny-config test, at full size): the CLIP tower's
+    # output for the golden row's crops must reproduce the QUANTISED tower -- within a quarter of the distance between the fp32 tower
+    # and its W8A8 emulation (fixture: 256 sampled elements of both, tests/golden/make_w8a8_emulation.py clip)
+    if "clip_out_idx" in fx:
+        nc, tk, hc = fx["clip_out_shape"]
+        T = tk + 1
+        m.custom_forward(inputs_batch={k: v[:1] for k, v in kw.items()})
+        clip = torch.from_numpy(m.engine.read_tap("clip_x", nc * T * hc).reshape(nc, T, hc)[:, 1:].reshape(-1).copy())
+        idx = torch.tensor(fx["clip_out_idx"])
+        e8, e32 = torch.tensor(fx["clip_out_w8a8"]), torch.tensor(fx["clip_out_fp32"])
+        d_hip, d_q = (clip[idx] - e8).abs().max().item(), (e32 - e8).abs().max().item()
+        print(f"[w8a8 LLaVA-7B] CLIP tower ({nc} crops): |hip - emulation| = {d_hip:.2e}   |fp32 - emulation| = {d_q:.2e}")
+        assert d_hip < 0.25 * d_q
