@@ -57,7 +57,7 @@ def clip_stage():
     geo = synth.llava_geometry(*[int(v) for v in b["image_sizes"][0]], cfg.pinpoints, cfg.clip.image, cfg.clip.grid)
     crops = torch.from_numpy(b["pixel_values"][0, : 1 + geo[0] * geo[1]])
     gen = torch.Generator().manual_seed(99)
-    for key, opr in (("fp32", orc.Ident), ("w8a8", orc.W8A8Round(orc.f16_round))):
+    for key, opr in (("fp32", orc.Ident), ("w8a8", orc.W8A8Round(orc.f16_round)), ("w8a8_twin", orc.W8A8Round(orc.Ident))):
         f = orc.clip_tower(W, crops, cfg.clip, opr, prefix=lorc.CLIP_PREFIX).reshape(-1)
         if key == "fp32":
             idx = torch.randperm(f.numel(), generator=gen)[:256].sort().values
@@ -65,7 +65,8 @@ def clip_stage():
             out["clip_out_idx"] = idx.tolist()
         out["clip_out_" + key] = f[idx].tolist()
     d = (torch.tensor(out["clip_out_fp32"]) - torch.tensor(out["clip_out_w8a8"])).abs().max().item()
-    print(f"CLIP tower, {crops.shape[0]} crops: max |fp32 - w8a8 emulation| over the 256 samples = {d:.3e}")
+    dt = (torch.tensor(out["clip_out_w8a8_twin"]) - torch.tensor(out["clip_out_w8a8"])).abs().max().item()
+    print(f"CLIP tower, {crops.shape[0]} crops: over the 256 samples max |fp32 - w8a8 emulation| = {d:.3e}, max |twin emulation - w8a8 emulation| = {dt:.3e}")
     json.dump(out, open(path, "w"), indent=1)
 
 

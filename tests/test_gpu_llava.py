@@ -136,16 +136,21 @@ def test_w8a8_full_size_batch64():
     print(f"[w8a8 LLaVA-7B B=64] row 0 hip {got:.5f}  emulation {emu:.5f}  twin emulation {twin:.5f}  fp32 reference {ref:.5f}")
     assert r.shape == (B, 1) and torch.isfinite(r).all() and torch.equal(r, r2) and torch.equal(r0[0], r[0])
     assert abs(got - emu) < 3.0 * max(abs(twin - emu), 1e-2)
-    # Stage level, where little has been amplified yet (round 4; the bound of the tiny-config test, at full size): the CLIP tower's
-    # output for the golden row's crops must reproduce the QUANTISED tower -- within a quarter of the distance between the fp32 tower
-    # and its W8A8 emulation (fixture: 256 sampled elements of both, tests/golden/make_w8a8_emulation.py clip)
+    # Stage level (round 4): the CLIP tower's output for the golden row's crops against the fixture's fingerprints (256 sampled elements
+    # of the fp32 tower, of its W8A8 emulation and of the TWIN emulation without the f16 storage rounding; make_w8a8_emulation.py clip).
+    # The tiny-config test holds the engine to a quarter of the quantisation noise at this stage (2 layers: measured 22x inside).  At
+    # full depth that bound is not attainable by ANY implementation: 23 layers of e4m3 operands amplify the 2^-11 storage rounding
+    # alone to 0.45 (twin vs emulation) of the 0.72 the quantisation itself moves the tower (fp32 vs emulation).  So, as for the
+    # reward: the engine must sit as close to the emulation as such a twin does.
     if "clip_out_idx" in fx:
         nc, tk, hc = fx["clip_out_shape"]
         T = tk + 1
         m.custom_forward(inputs_batch={k: v[:1] for k, v in kw.items()})
         clip = torch.from_numpy(m.engine.read_tap("clip_x", nc * T * hc).reshape(nc, T, hc)[:, 1:].reshape(-1).copy())
         idx = torch.tensor(fx["clip_out_idx"])
-        e8, e32 = torch.tensor(fx["clip_out_w8a8"]), torch.tensor(fx["clip_out_fp32"])
-        d_hip, d_q = (clip[idx] - e8).abs().max().item(), (e32 - e8).abs().max().item()
-        print(f"[w8a8 LLaVA-7B] CLIP tower ({nc} crops): |hip - emulation| = {d_hip:.2e}   |fp32 - emulation| = {d_q:.2e}")
-        assert d_hip < 0.25 * d_q
+        e8, e32, e8t = torch.tensor(fx["clip_out_w8a8"]), torch.tensor(fx["clip_out_fp32"]), torch.tensor(fx["clip_out_w8a8_twin"])
+        d_hip, d_q, d_twin = (clip[idx] - e8).abs().max().item(), (e32 - e8).abs().max().item(), (e8t - e8).abs().max().item()
+        print(f"[w8a8 LLaVA-7B] CLIP tower ({nc} crops): |hip - emulation| = {d_hip:.2e}   |twin - emulation| = {d_twin:.2e}   |fp32 - emulation| = {d_q:.2e}")
+        assert d_hip < 1.5 * d_twin and d_hip < d_q
+        rms = lambda t: t.pow(2).mean().sqrt().item()
+        assert rms(clip[idx] - e8) < 1.5 * rms(e8t - e8)
