@@ -177,12 +177,27 @@ def dominant_kernel_probe(dtype_code, tile, steps=5, split=False, lo8=False):
     e1.record(st)
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
+    # A yardstick for the nominal peak, NOT a product path: the vendor library's plain GEMM (torch.matmul -> hipBLASLt, f16 in, fp32
+    # accumulate, no epilogue, one MFMA pass) on the same shape, timed the same way on the same box.
+    del out
+    Ah = A[:, :K].contiguous() if split else A
+    torch.matmul(Ah, W.t())
+    e0.record(st)
+    for _ in range(steps):
+        torch.matmul(Ah, W.t())
+    e1.record(st)
+    torch.cuda.synchronize()
+    vms = e0.elapsed_time(e1) / steps
+    vendor = {"what": "vendor library (hipBLASLt through torch.matmul), plain single-pass GEMM of the same shape, no epilogue: measurement only",
+              "avg_ms": vms, "tflops": 2.0 * M * N * K / (vms * 1e-3) / 1e12, "frac_of_peak": 2.0 * M * N * K / (vms * 1e-3) / 1e12 / PEAK_TFLOPS}
     form = "mixed" if lo8 else "split" if split else "single"
     pmc = pmc_for(form)
     label = ", split-operand form, e4m3 residual pass" if lo8 else ", split-operand form" if split else ""
     return dict({"kernel": "gemm_bt8_kernel<SwiGLU> decoder gate_up" + label, "shape": [M, N, K],
                  "avg_ms": ms, "tflops": 2.0 * M * N * K / (ms * 1e-3) / 1e12, "mfma_work_factor": 1.5 if lo8 else w,
-                 "algorithmic_bytes": 2.0 * ((1.5 if lo8 else w) * M * K + (1.5 if lo8 else 1) * N * K + (1.5 if lo8 else w) * M * N // 2)}, **pmc)
+                 "algorithmic_bytes": 2.0 * ((1.5 if lo8 else w) * M * K + (1.5 if lo8 else 1) * N * K + (1.5 if lo8 else w) * M * N // 2),
+                 "vendor_library_same_shape": vendor,
+                 "mfma_rate_vs_vendor": (1.5 if lo8 else w) * vms / ms}, **pmc)
 
 
 GOLDEN_GLOBS = {"phi3v": "ref_full_*.json", "llava": "ref_llava_full*.json", "qwen": "ref_qwen_full*.json"}

@@ -72,13 +72,22 @@ template <typename F> __device__ __forceinline__ void for4(F&& f) { f(IC<0>{}); 
 // runs kw / 64 f16 K-tiles against W and then kw / 128 e4m3 K-tiles against W8 (the e4m3 twin of W, in the rows of p.Wlo), with
 // the power-of-two scales of the residuals (p.aexp, one E8M0 byte per row and K-tile) and of W8 (p.wexp, one per tensor) applied by
 // the matrix instruction itself, so both passes meet in the same accumulators and every epilogue is the one of the 16-bit form.
-template <typename OT, int PF, int NS, int DBG, int EPI, int PB, int F8 = 0>
+// NW: narrow tiles for problems that do not fill the chip with 256 x 256 ones (round 4).  1 = 128 x 256: the A1 half of every K-tile
+// is not multiplied (quadrants (1,*) do not exist), 2 = 256 x 128: the B1 half is not (quadrants (*,1)); the ring, the DMA stream and
+// the barriers are the full tile's -- the unused half-tile is fetched from rows the tile reads anyway (cache hits) -- so a narrow tile
+// costs ~85 % of a full one for half its flops (the K loop's skeleton, not its MFMAs, sets the pace), and twice as many of them fill
+// twice the CUs when the full tiles leave half the chip idle.  An output element's K order, MFMA
+// kinds and scales are exactly the full tile's: results are bit-identical whichever tile shape computed them, so the launcher may
+// choose by M (it does: narrow_choice).  NW == 2 exists for the operand-out epilogue only (the adapters' t = x A^T, N = rank).
+template <typename OT, int PF, int NS, int DBG, int EPI, int PB, int F8 = 0, int NW = 0>
 __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
     static_assert(!F8 || PB == 2, "the fp8 operand path exists in the super-phase schedule only");
+    static_assert(NW == 0 || PB == 2, "narrow tiles exist in the super-phase schedule only");
+    static_assert(NW != 2 || (EPI & 15) == EPI_OUT_OP, "256 x 128 tiles: operand-out epilogue only");
     constexpr int E_ = EPI & 15;          // epilogue selector; bit 4 = bias present (SwiGLU / RoPE epilogues)
     constexpr bool BIAS_ = (EPI & 16) != 0;
 
-    constexpr int BM = 256, BN = 256, BK = 64;
+    constexpr int BM = NW == 1 ? 128 : 256, BN = NW == 2 ? 128 : 256, BK = 64;
     constexpr int HT = 16384;                      // bytes per half-tile slot
     static_assert(PB == 2 || (NS - PF >= 4 && PF >= 3), "ring hazard distances");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -189,9 +198,9 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 const int row = 2 * R + (C >> 3), c = C & 7;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int ga = min(m0 + h * 128 + row, p.M - 1);
+                    const int ga = min(m0 + (NW == 1 ? 0 : h * 128) + row, p.M - 1);
                     gA[h][it] = Ab + (size_t)ga * la + c * 8 + sg.a_col;
-                    const int wrow = (row >> 5) * 64 + h * 32 + (row & 31);
+                    const int wrow = NW == 2 ? row : (row >> 5) * 64 + h * 32 + (row & 31);     // 256 x 128: image row = tile column
                     const int gb = min(n0 + wrow, p.N - 1);
                     gB[h][it] = Wb + (size_t)gb * lw + c * 8 + sg.w_col;
                 }
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int e1 = p.aexp2[min(m0 + h2 * 128 + wr * 64 + i * 16 + l15, p.M - 1)] & 255;
+                        const int e1 = p.aexp2[min(m0 + (NW == 1 ? 0 : h2 * 128) + wr * 64 + i * 16 + l15, p.M - 1)] & 255;
                         ea2[h2] = i == 0 ? e1 : (ea2[h2] | (e1 << (8 * i)));
                     }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -291,8 +300,9 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         // and K-tile.  (Issued inside the K loop, a scale group is a cold line at the head of the in-order queue: ~0.6 us per group.)
         constexpr int SC_GROUPS = 32;
         const unsigned sc_voff = (unsigned)((wr * 16 + l15) * 8);
-        const unsigned char* sc_tile = p.aexp + (size_t)mi * 1024;
-        const size_t sc_plane = (size_t)Mt * 1024;
+        // (128-row tiles: the slices are laid out per 256 rows, tile mi is A half (mi & 1) of slice row mi >> 1)
+        const unsigned char* sc_tile = p.aexp + (size_t)(NW == 1 ? mi >> 1 : mi) * 1024;
+        const size_t sc_plane = (size_t)((p.M + 255) >> 8) * 1024;
         const int nsl = nk_lo - nk_hi, nsg = (nsl + 3) >> 2;
         auto issue_scales = [&](int g) {
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + NS * HT + (g & (SC_GROUPS - 1)) * 1024);
@@ -367,9 +377,11 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 // ---------------- LOAD ----------------
                 const bool more = gi < Gtot;
                 if constexpr (DBG != 4) {
-                    const char* sa = sp == 0 ? sA0 : sA1;
+                    if (NW != 1 || sp == 0) {
+                        const char* sa = sp == 0 ? sA0 : sA1;
 #pragma unroll
-                    for (int f = 0; f < 8; ++f) af[f] = *(const uint4*)(sa + aoff[f]);
+                        for (int f = 0; f < 8; ++f) af[f] = *(const uint4*)(sa + aoff[f]);
+                    }
                 }
                 // the scales of this residual K-tile's rows (both A halves) from LDS; a late scale group (K > 16384) into the slot of
                 // the one it replaces
@@ -379,7 +391,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                         typedef int v2i_t __attribute__((ext_vector_type(2)));
                         typedef __attribute__((address_space(3))) const volatile v2i_t lds_scale_t;       // an LDS read, never a flat one
                         const v2i_t e2 = *(lds_scale_t*)(lds_base + NS * HT + (((j >> 2) & (SC_GROUPS - 1)) << 10) + ((j & 3) << 8) + sc_voff);
-                        ea[0] = e2.x; ea[1] = e2.y;
+                        ea[0] = (NW == 1 && (mi & 1)) ? e2.y : e2.x; ea[1] = e2.y;
                         const int g = (j >> 2) - 1 + SC_GROUPS;        // its slot was last read in the K-tile before this one
                         if ((j & 3) == 0 && j >= 4 && g < nsg && wave == (g & 7)) { issue_scales(g); scl = true; }
                     }
@@ -406,13 +418,15 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 // ---------------- COMPUTE ----------------
                 __builtin_amdgcn_s_setprio(1);
                 if constexpr (DBG != 4) {
-                    if (sp == 0) {
+                    if (sp == 0 && NW != 2) {
 #pragma unroll
                         for (int f = 0; f < 4; ++f) bg[f] = *(const uint4*)(sB1 + boff[f]);
                     }
                     constexpr int q0 = 0, q1 = 1, q3 = 3, q2 = 2;
                     const int qa = sp == 0 ? q0 : q3, qb = sp == 0 ? q1 : q2;      // first block uses bf (B0), second bg (B1)
-                    if constexpr (F8 == 1 || (F8 == 2 && LO)) {
+                    const bool do_a = NW != 1 || sp == 0, do_b = do_a && NW != 2;        // (compile-time constants after unrolling)
+                    if (!do_a) {
+                    } else if constexpr (F8 == 1 || (F8 == 2 && LO)) {
                         for4([&](auto ic) {
                             constexpr int i = decltype(ic)::value;
 #pragma unroll
@@ -432,7 +446,8 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 #pragma unroll
                         for (int f = 0; f < 4; ++f) bf[f] = *(const uint4*)(sB0n + boff[f]);
                     }
-                    if constexpr (F8 == 1 || (F8 == 2 && LO)) {
+                    if (!do_b) {
+                    } else if constexpr (F8 == 1 || (F8 == 2 && LO)) {
                         for4([&](auto ic) {
                             constexpr int i = decltype(ic)::value;
 #pragma unroll
@@ -454,7 +469,10 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
-                            for (int j = 0; j < 2; ++j) { asm volatile("" : "+v"(acc[qa][i][j])); asm volatile("" : "+v"(acc[qb][i][j])); }
+                            for (int j = 0; j < 2; ++j) {
+                                if (do_a) asm volatile("" : "+v"(acc[qa][i][j]));
+                                if (do_b) asm volatile("" : "+v"(acc[qb][i][j]));
+                            }
                     }
                 }
                 __builtin_amdgcn_s_setprio(0);
@@ -635,7 +653,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int col = n0 + wc * 64 + qb * 32 + j * 16 + l15;
+                    const int col = n0 + (NW == 2 ? wc * 32 : wc * 64 + qb * 32) + j * 16 + l15;
                     sw[qb][j] = col < p.N ? wsc[col] : 0.f;
                 }
 #pragma unroll
@@ -687,7 +705,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         constexpr int SLD = 260;
         float* stg = (float*)smem;
 #pragma unroll
-        for (int qa = 0; qa < 2; ++qa) {
+        for (int qa = 0; qa < (NW == 1 ? 1 : 2); ++qa) {
             const int rowq = m0 + qa * 128;
             // residual rows are fetched around the staging pass so their latency hides behind it: 8 rows
             // before it, 8 right after the staging writes (when 64 accumulator registers have been freed)
@@ -718,7 +736,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
             __syncthreads();
             tstamp(4 + 3 * qa);
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
+            for (int qb = 0; qb < (NW == 2 ? 1 : 2); ++qb) {
                 const int q = qa == 0 ? qb : 3 - qb;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -726,7 +744,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            stg[(wr * 64 + i * 16 + 4 * l4 + r) * SLD + wc * 64 + qb * 32 + j * 16 + l15] = acc[q][i][j][r];
+                            stg[(wr * 64 + i * 16 + 4 * l4 + r) * SLD + (NW == 2 ? wc * 32 : wc * 64 + qb * 32) + j * 16 + l15] = acc[q][i][j][r];
             }
             if constexpr (E_ == EPI_RESADD_F32) {
 #pragma unroll
@@ -811,14 +829,15 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) body(4 + it, ca[2 * it], ca[2 * it + 1]);
             } else if constexpr (E_ == EPI_OUT_OP) {
-                // 256 columns = 32 chunks of 8: 32 lanes per row, 2 rows per wave-iteration
-                const int c8 = lane & 31;
+                // 256 columns = 32 chunks of 8: 32 lanes per row, 2 rows per wave-iteration (256 x 128 tiles: 16 lanes, 4 rows)
+                constexpr int LPR = NW == 2 ? 16 : 32, RPW = 64 / LPR;
+                const int c8 = lane & (LPR - 1);
                 const int col = n0 + c8 * 8;
                 float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
                 if (p.bias && col < p.N) { b0 = *(const float4*)(p.bias + col); b1 = *(const float4*)(p.bias + col + 4); }
 #pragma unroll 2
-                for (int it = 0; it < 8; ++it) {
-                    const int rl = it * 16 + wave * 2 + (lane >> 5);
+                for (int it = 0; it < 128 / (8 * RPW); ++it) {
+                    const int rl = it * 8 * RPW + wave * RPW + lane / LPR;
                     const int row = rowq + rl;
                     const float* sp = stg + rl * SLD + c8 * 8;
                     float4 v0 = *(const float4*)sp, v1 = *(const float4*)(sp + 4);
@@ -929,17 +948,18 @@ static int* sched_words(hipStream_t st) {
     return w;
 }
 
-template <typename OT, int PF, int DBG, int EPI, int PB = 0, int F8 = 0>
+template <typename OT, int PF, int DBG, int EPI, int PB = 0, int F8 = 0, int NW = 0>
 static void launch8(const GemmParams& p, bool persistent, hipStream_t st) {
     constexpr int NS = PB == 2 ? 8 : 10;      // ring slots; the product schedule keeps the rest of the 160 KB for scale slices
     constexpr int smem = 10 * 16384;
     static bool attr_set = false;
-    auto kfn = gemm_bt8_kernel<OT, PF, NS, DBG, EPI, PB, F8>;
+    auto kfn = gemm_bt8_kernel<OT, PF, NS, DBG, EPI, PB, F8, NW>;
     if (!attr_set) {
         LR_HIP_CHECK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    const int Mt = (p.M + 255) / 256, Nt = (p.N + 255) / 256;
+    constexpr int BM = NW == 1 ? 128 : 256, BN = NW == 2 ? 128 : 256;
+    const int Mt = (p.M + BM - 1) / BM, Nt = (p.N + BN - 1) / BN;
     // persistent: one resident workgroup per CU (160 KB LDS each) walking its tiles; else one workgroup per tile
     const int grid = persistent ? std::min(Mt * Nt, num_cus()) : Mt * Nt;
     GemmParams q = p;
@@ -948,8 +968,59 @@ static void launch8(const GemmParams& p, bool persistent, hipStream_t st) {
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), smem, st, q);
 }
 
+#ifdef LR_GEMM8_NARROW_TU
+// The narrow-tile instantiations live in a translation unit of their own (gemm8_narrow.hip includes this file) so that the two
+// halves compile side by side.  F16 operands, 16-bit (F8 = 0) and mixed (F8 = 2) forms; other modes keep 256 x 256 tiles.
+template <int F8>
+static void launch8_narrow_f8(const GemmParams& p, int nw, hipStream_t st) {
+    if (nw == 2) { launch8<F16, 6, 0, EPI_OUT_OP, 2, F8, 2>(p, true, st); return; }
+    switch (p.epi) {
+        case EPI_OUT_OP: launch8<F16, 6, 0, EPI_OUT_OP, 2, F8, 1>(p, true, st); break;
+        case EPI_OUT_F32: launch8<F16, 6, 0, EPI_OUT_F32, 2, F8, 1>(p, true, st); break;
+        case EPI_RESADD_F32: launch8<F16, 6, 0, EPI_RESADD_F32, 2, F8, 1>(p, true, st); break;
+        case EPI_SWIGLU_OP:
+            if (p.bias) launch8<F16, 6, 0, EPI_SWIGLU_OP | 16, 2, F8, 1>(p, true, st);
+            else launch8<F16, 6, 0, EPI_SWIGLU_OP, 2, F8, 1>(p, true, st);
+            break;
+        case EPI_ROPE_OP:
+            if (p.bias) launch8<F16, 6, 0, EPI_ROPE_OP | 16, 2, F8, 1>(p, true, st);
+            else launch8<F16, 6, 0, EPI_ROPE_OP, 2, F8, 1>(p, true, st);
+            break;
+        default: throw std::runtime_error("gemm_bt8: unknown epilogue");
+    }
+}
+void launch8_narrow(const GemmParams& p, int f8, int nw, hipStream_t st) {
+    if (f8 == 2) launch8_narrow_f8<2>(p, nw, st);
+    else launch8_narrow_f8<0>(p, nw, st);
+}
+#else
+void launch8_narrow(const GemmParams& p, int f8, int nw, hipStream_t st);
+
+// Tile shape for one problem (product schedule): 0 = 256 x 256, 1 = 128 x 256, 2 = 256 x 128 (see the kernel's NW).  Free to look
+// at M: every shape gives the same bits.  Measured (tools/narrow_bench.py): a 128-row tile costs 0.85 of a full one -- the K loop's
+// DMA / LDS / barrier skeleton is the full tile's, only the MFMAs halve -- so it pays exactly when it does not add a round of tiles
+// over the CUs: B = 1 o_proj / down (132 -> 264 tiles: -15 %), the gathered last layer (M = B rows: -16 %); a 256 x 128 tile for
+// the adapters' t = x A^T costs 0.94 (-6 %).
+int narrow_choice(const GemmParams& p) {
+    const char* fe = getenv("LR_GEMM_NARROW");          // A/B and test switch, read per launch: 0 = never, 1 = 128-row tiles always
+    const int force = fe ? atoi(fe) : -1;
+    if (force == 0) return 0;
+    const int E = p.epi;
+    if (E == EPI_OUT_OP && p.N <= 128) return 2;
+    const int cus = num_cus();
+    const long Nt = (p.N + 255) / 256;
+    const long full = (p.M + 255) / 256 * Nt, half = (p.M + 127) / 128 * Nt;
+    const double t_full = (double)((full + cus - 1) / cus), t_half = 0.85 * (double)((half + cus - 1) / cus);
+    return (force == 1 || t_half < 0.9 * t_full) ? 1 : 0;
+}
+
+
 template <typename OT, int PF, int DBG, int PB = 0, int F8 = 0>
 static void launch8_epi(const GemmParams& p, bool persistent, hipStream_t st) {
+    if constexpr (std::is_same<OT, F16>::value && PB == 2 && DBG == 0 && (F8 == 0 || F8 == 2)) {
+        const int nw = narrow_choice(p);
+        if (nw) { launch8_narrow(p, F8, nw, st); return; }
+    }
     switch (p.epi) {
         case EPI_OUT_OP: launch8<OT, PF, DBG, EPI_OUT_OP, PB, F8>(p, persistent, st); break;
         case EPI_OUT_F32: launch8<OT, PF, DBG, EPI_OUT_F32, PB, F8>(p, persistent, st); break;
@@ -1098,5 +1169,7 @@ void launch_gemm_bt8(const GemmParams& p, int operand_dtype, int variant, hipStr
     if (operand_dtype == DT_F16) launch8_variant<F16>(p, variant, st);
     else launch8_variant<BF16>(p, variant, st);
 }
+
+#endif  // LR_GEMM8_NARROW_TU
 
 }  // namespace lr

@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(PKG_DIR), "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libllava_reward_hip.so")
-SOURCES = ["gemm.hip", "gemm8.hip", "attention.hip", "gemm_f32.hip", "rowops.hip", "rowops_qwen.hip", "engine.hip", "qwen.hip", "preprocess.hip"]
+SOURCES = ["gemm.hip", "gemm8.hip", "gemm8_narrow.hip", "attention.hip", "gemm_f32.hip", "rowops.hip", "rowops_qwen.hip", "engine.hip", "qwen.hip", "preprocess.hip"]
 HEADERS = ["common.h", "kernels.h", "engine.h", os.path.join("..", "..", "include", "llava_reward_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
@@ -29,7 +29,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
-        if force or _newer([src] + hdrs, obj):
+        deps = [src] + hdrs + ([os.path.join(CSRC, "gemm8.hip")] if s == "gemm8_narrow.hip" else [])     # (it includes gemm8.hip)
+        if force or _newer(deps, obj):
             jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
 
     def run(cmd):

@@ -626,3 +626,107 @@ def test_gemm_e4m3_residual_pass_with_inexact_weights(lib):
         torch.cuda.synchronize()
         e_nolo = (exact_w - ref).abs().max().item()
         assert err < 3e-5 * scale and err < e_nolo / 4, (M, N, K, err / scale, e_nolo / scale)
+
+
+def test_gemm_narrow_tiles_give_the_full_tile_bits(lib, monkeypatch):
+    """Round 4: problems that do not fill the chip with 256 x 256 tiles run 128 x 256 ones, the adapters' t = x A^T (N = rank <= 128)
+    256 x 128 ones (csrc/gemm8.hip NW).  An element's K order, matrix instructions and scales are the full tile's, so the bits are:
+    every epilogue, 16-bit / split / e4m3-residual forms, ragged M, against LR_GEMM_NARROW=0 (256 x 256 only)."""
+    code, tdt = L.LR_DT_F16, torch.float16
+
+    def both(fn):
+        outs = []
+        for env in ("0", "1"):
+            monkeypatch.setenv("LR_GEMM_NARROW", env)
+            outs.append(fn())
+            torch.cuda.synchronize()
+        monkeypatch.delenv("LR_GEMM_NARROW")
+        outs.append(fn())                       # the launcher's own choice
+        torch.cuda.synchronize()
+        return outs
+
+    def same(outs, what):
+        for o in outs[1:]:
+            for a, b in zip(outs[0], o):
+                assert torch.equal(a, b), what
+
+    for (M, N, K) in [(300, 512, 384), (2642, 3072, 1024), (130, 256, 256), (1, 768, 128)]:
+        A32 = rnd((M, K), 301, 0.7) * torch.exp2(torch.randint(-4, 5, (M, 1), generator=torch.Generator().manual_seed(9)).float()).cuda()
+        W = rnd((N, K), 302, 0.05).to(torch.bfloat16).to(tdt)
+        bias = rnd((N,), 303)
+        hi, lo = _split(A32, tdt)
+        A2 = torch.cat([hi, lo], dim=1).contiguous()
+        res = rnd((M, N), 304)
+
+        def plain():
+            o1 = torch.empty(M, N, device="cuda", dtype=torch.float32)
+            assert lib.lr_op_gemm_bt(P(hi), P(W), P(o1), P(bias), M, N, K, K, K, N, L.EPI_OUT_F32, 0, code, 6, stream()) == 0
+            o2 = res.clone()
+            assert lib.lr_op_gemm_bt(P(hi), P(W), P(o2), P(None), M, N, K, K, K, N, L.EPI_RESADD_F32, 0, code, 6, stream()) == 0
+            o3 = torch.zeros(M, N, device="cuda", dtype=tdt)
+            assert lib.lr_op_gemm_bt(P(hi), P(W), P(o3), P(bias), M, N, K, K, K, N, L.EPI_OUT_OP, L.ACT_QUICK_GELU, code, 6, stream()) == 0
+            o4 = torch.zeros(M, N // 2, device="cuda", dtype=tdt)
+            assert lib.lr_op_gemm_bt(P(hi), P(W), P(o4), P(None), M, N, K, K, K, N // 2, L.EPI_SWIGLU_OP, 0, code, 6, stream()) == 0
+            return o1, o2, o3, o4
+        same(both(plain), ("16-bit", M, N, K))
+
+        def split():
+            o1 = torch.empty(M, N, device="cuda", dtype=torch.float32)
+            assert lib.lr_op_gemm_bt_split(P(A2), P(W), P(o1), P(bias), M, N, K, L.EPI_OUT_F32, 0, code, 6, stream()) == 0
+            o2 = torch.zeros(M, 2 * N, device="cuda", dtype=tdt)
+            assert lib.lr_op_gemm_bt_split(P(A2), P(W), P(o2), P(bias), M, N, K, L.EPI_OUT_OP, L.ACT_GELU_ERF, code, 6, stream()) == 0
+            return o1, o2
+        same(both(split), ("split", M, N, K))
+
+        if K % 128 == 0:
+            def mixed():
+                outs = []
+                for epi, act, fl in ((L.EPI_OUT_F32, 0, 3), (L.EPI_RESADD_F32, 0, 3), (L.EPI_OUT_OP, L.ACT_GELU_ERF, 3 | 32), (L.EPI_SWIGLU_OP, 0, 3 | 32)):
+                    if (epi == L.EPI_SWIGLU_OP and N % 256) or (fl & 32 and (N // (2 if epi == L.EPI_SWIGLU_OP else 1)) % 128):
+                        continue
+                    Aw = A2.clone()
+                    No = N // 2 if epi == L.EPI_SWIGLU_OP else N
+                    sc = torch.full((lib.lr_op_lo8_scratch_bytes(M, K) + lib.lr_op_lo8_scratch_bytes(M, No),), 127, dtype=torch.uint8, device="cuda")
+                    W8 = torch.zeros_like(W)
+                    we = C.c_int(0)
+                    o = res.clone() if epi in (L.EPI_OUT_F32, L.EPI_RESADD_F32) else torch.zeros(M, 2 * No, device="cuda", dtype=tdt)
+                    assert lib.lr_op_gemm_bt_mixed(P(Aw), P(W), P(W8), P(sc), P(o), P(bias) if epi != L.EPI_SWIGLU_OP else None, M, N, K, epi, act, code, fl,
+                                                   C.byref(we), stream()) == 0
+                    outs += [o, sc]
+                return outs
+            same(both(mixed), ("e4m3 residual pass", M, N, K))
+
+    # fused RoPE epilogue
+    M, D, hd, K = 333, 256, 64, 256
+    N = 3 * D
+    A = rnd((M, K), 311).to(tdt)
+    W = rnd((N, K), 312, 0.05).to(tdt)
+    ang = rnd((M, hd // 2), 313, 3.0)
+    cs = torch.stack([ang.cos(), ang.sin()], dim=-1).contiguous()
+
+    def rope():
+        o = torch.zeros(M, N, device="cuda", dtype=tdt)
+        assert lib.lr_op_gemm_rope(P(A), P(W), P(o), P(None), P(cs), M, N, K, 2 * D, hd, code, 5, stream()) == 0
+        return (o,)
+    same(both(rope), "rope")
+
+    # the adapters' skinny GEMM in the default form: N = rank (256 x 128 tiles unless switched off), many row tiles, ragged M
+    for (M, N, K) in [(5000, 128, 1024), (70000, 128, 3072), (700, 64, 384)]:
+        A32 = rnd((M, K), 321, 0.7)
+        W = rnd((N, K), 322, 0.05).to(torch.bfloat16).to(tdt)
+        hi, lo = _split(A32, tdt)
+        A2 = torch.cat([hi, lo], dim=1).contiguous()
+
+        def skinny():
+            Aw = A2.clone()
+            sc = torch.full((lib.lr_op_lo8_scratch_bytes(M, K) + lib.lr_op_lo8_scratch_bytes(M, 128),), 127, dtype=torch.uint8, device="cuda")
+            W8 = torch.zeros_like(W)
+            we = C.c_int(0)
+            o = torch.zeros(M, 2 * N, device="cuda", dtype=tdt)
+            assert lib.lr_op_gemm_bt_mixed(P(Aw), P(W), P(W8), P(sc), P(o), None, M, N, K, L.EPI_OUT_OP, 0, code, 3, C.byref(we), stream()) == 0
+            return (o,)
+        outs = both(skinny)
+        same(outs, ("skinny", M, N, K))
+        ref = (A32.double() @ W.double().t()).float()
+        got = outs[0][0][:, :N].float() + outs[0][0][:, N:].float()
+        assert (got - ref).abs().max().item() < 4e-5 * ref.abs().max().item()
