@@ -48,8 +48,6 @@ class RewardModel:
         self._synth_seed = synth_seed
         self._synth_profile = int(synth_profile)      # synth.PROFILE_* (outlier-bearing / e4m3-valued synthetic weights)
         self.mean_hidden_state = bool(mean_hidden_state)      # rw_model:398-406: masked mean of the (SkipCA'd) hidden states
-        if self.mean_hidden_state and layer_id != 32 and layer_id < cfg.layers:
-            raise NotImplementedError("mean_hidden_state together with an inner layer_id is not implemented")
         self._opts = dict(max_batch=max_batch, max_seq=max_seq, max_crops=max_crops, operand_dtype=operand_dtype,
                           max_patches=max_patches, mean_hidden_state=self.mean_hidden_state)
         self.layer_id = layer_id

@@ -369,6 +369,8 @@ def main():
     elif which == "layer_id":
         # rw_model:349-352 with layer_id != 32: hidden_states[1] = the residual stream entering decoder layer 1 (no final norm)
         run_case(ref, "ref_small_layer1_bt_ca", synth.ref_small_config(), 77, [4, 7], (1, 1), None, layer_id=1)
+        # ... together with mean_hidden_state (rw_model:398-406 pools whatever :349-352 selected): SkipCA + masked mean over hidden_states[1]
+        run_case(ref, "ref_small_mean_layer1_bt_ca", synth.ref_small_config(), 81, [5, 9], [(1, 1), (1, 2)], 3, taps=False, layer_id=1, mean_hidden_state=True)
     elif which == "qwen":
         C, Q = synth.qwen_tiny_config, synth.qwen_quirk_config
         run_qwen_case("ref_qwen_tiny_bt", C(), 21, [6, 3], [(16, 16), (16, 16)])

@@ -308,8 +308,9 @@ def test_reference_goldens_small(path, dtype, tol):
     if g.get("layer_id", 32) != 32:      # the same engine gives the last-layer reward again once layer_id is the literal 32
         m.layer_id = 32
         W = orc.weights_to_torch(synth.make_weights(cfg, g["seed"], g.get("weight_profile", 0)))
-        full = orc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"])
-        assert (_fwd(m, batch) - full).abs().max().item() < tol
+        full = orc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"],
+                                  mean_hidden_state=bool(g.get("mean_hidden_state", False)))
+        assert (_fwd(m, batch).reshape(full.shape) - full).abs().max().item() < tol
 
 
 TAP_CASES = [p for p in CASES if json.load(open(p)).get("taps")]
