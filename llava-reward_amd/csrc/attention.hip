@@ -87,11 +87,20 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lc = lane & 31, lh = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    int S = p.S, qt, qsel = -1;
+    int head = blockIdx.y, b = blockIdx.z, bx = blockIdx.x;
+    if (p.lin_nqt > 0) {                           // XCD-aware order (AttnParams::lin_nqt): id = ((kvpair / 8) * (G nqt) + (g nqt + rank)) * 8 + kvpair % 8
+        const int id = blockIdx.x, G = p.kv_group, per = G * p.lin_nqt;
+        const int k = id >> 3, kvpair = (k / per) * 8 + (id & 7), r = k % per;
+        const int kvheads = p.heads / G;
+        if (kvpair >= kvheads * p.lin_batch) return;          // (the grid is padded to whole groups of 8 pairs)
+        b = kvpair / kvheads;
+        head = (kvpair % kvheads) * G + r / p.lin_nqt;
+        bx = r % p.lin_nqt;
+    }
+    int S = p.S, qt, qsel = -1, qshift = 0;
     size_t rowbase;
     if (!CAUSAL && p.items) {                      // ragged mode: one segment per workgroup
-        const int4 it = p.items[blockIdx.x];
+        const int4 it = p.items[bx];
         rowbase = (size_t)it.x; S = it.y; qt = it.z;
     } else if (CAUSAL && p.qsel) {                 // gathered mode: the query tile that holds the wanted query of sequence b
         qsel = __builtin_amdgcn_readfirstlane(p.qsel_last ? S - 1 : min(max(p.qsel[b * p.qsel_stride], 0), S - 1));
@@ -99,10 +108,20 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
         rowbase = (size_t)b * S;
     } else {
         const int nqt = (S + NW * 32 - 1) / (NW * 32);
-        qt = nqt - 1 - (int)blockIdx.x;            // heavy (late) causal tiles first
+        qt = nqt - 1 - bx;                         // heavy (late) causal tiles first
         rowbase = (size_t)b * S;
+        // Causal: the query tiles are shifted towards the END of the sequence (by whole key tiles, so that a wave's diagonal stays
+        // inside one key tile), which makes the partial workgroup the FIRST one (a few key tiles of work) instead of the last (all of
+        // them): at S = 2642 with 256-query workgroups 242 instead of 262 tile periods per (sequence, head), and the heaviest
+        // workgroup no longer runs with 5 of its 8 waves past the sequence.  Queries below 0 are dead lanes / waves.  A query's
+        // arithmetic does not depend on the lane or tile that holds it (key tiles stay aligned to kbeg; rescales by alpha = 1 and
+        // fully masked tiles are exact no-ops), so the outputs are bit-identical to the front-aligned tiling (tools/dbg/attn_equal.py).
+        // Ping-pong kernels only (S >= 1024: one workgroup per CU, lock-stepped tile periods: -10 % at S = 2642 together with the
+        // XCD-aware order, tools/dbg/attn_equal.py); the shorter-sequence forms, whose waves are not lock-stepped in pairs, measured
+        // level to worse with it (S = 800 .. 960: +1 .. +9 %) and keep the front-aligned tiles.
+        if (CAUSAL && PP && p.q_end_aligned) qshift = (nqt * (NW * 32) - S) / KT * KT;
     }
-    const int q0 = qt * (NW * 32) + wave * 32;
+    const int q0 = qt * (NW * 32) - qshift + wave * 32;
 
     const unsigned short* Qp = (const unsigned short*)p.Q + p.qoff + head * HD;
     const int kvh = head / p.kv_group;                 // GQA: several query heads share one key/value head
@@ -112,7 +131,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
     // ---- key range of this workgroup ----
     int kbeg = 0, kend = S;
     if (CAUSAL) {
-        kend = min(S, qt * (NW * 32) + NW * 32);
+        kend = min(S, qt * (NW * 32) - qshift + NW * 32);
         if (p.kmin) kbeg = (min(p.kmin[b * p.kmin_stride], S) / KT) * KT;
     }
     const int ntiles = kbeg < kend ? (kend - kbeg + KT - 1) / KT : 0;
@@ -169,14 +188,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
     }
     uint4 qf[KSTEPS];       // lane (c,h) holds Q[q0+c][16*ks + 8h .. +7]
     {
-        const int qrow = min(q0 + lc, S - 1);
+        const int qrow = max(min(q0 + lc, S - 1), 0);
         const unsigned short* src = Qp + (rowbase + qrow) * p.ldq + 8 * lh;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = *(const uint4*)(src + 16 * ks);
     }
     uint4 qfl[PREC ? KSTEPS : 1];       // residuals of the same Q elements
     if constexpr (PREC) {
-        const int qrow = min(q0 + lc, S - 1);
+        const int qrow = max(min(q0 + lc, S - 1), 0);
         const unsigned short* src = Qp + (rowbase + qrow) * p.ldq + p.lo_off + 8 * lh;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) qfl[ks] = *(const uint4*)(src + 16 * ks);
@@ -229,7 +248,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
         const int grp = wave >> 2;
         f32x16 s[2];
         uint4 pf[4], pl[PREC ? 4 : 1];
-        auto act = [&](int t) { return !CAUSAL || (kbeg + t * KT <= q0 + 31); };
+        auto act = [&](int t) { return (!CAUSAL || (kbeg + t * KT <= q0 + 31)) && q0 < S; };       // (waves wholly outside the sequence idle)
         auto qk = [&](int t) {
             const char* sK = smem + (t % NSLOT) * NOPS * TILE;
 #pragma unroll
@@ -407,8 +426,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
         const char* sK = smem + (t % NSLOT) * NOPS * TILE;
         const char* sV = sK + TILE;
 
-        // waves whose 32 queries all precede this tile have nothing to do (diagonal workgroup tiles)
-        const bool active = !CAUSAL || (k0 <= q0 + 31);
+        // waves whose 32 queries all precede this tile have nothing to do (diagonal workgroup tiles); nor have waves whose queries
+        // all lie beyond the sequence (577 tokens = 4.5 x 128 queries: the last workgroup's fourth wave).
+        // (Skipping the 32-key score halves / 16-key PV steps of a last key tile that holds no key -- 577 = 9 x 64 + 1 -- was built
+        //  and measured level: the branches cost what the skipped MFMAs save.)
+        const bool active = (!CAUSAL || (k0 <= q0 + 31)) && q0 < S;
         if (active) {
             // ---- S^T tiles: keys kt*32 + [(r&3) + 8(r>>2) + 4h], query lc ----
             f32x16 s[2];
@@ -517,7 +539,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
     }
 
     // ---- epilogue: O[q][d], d = dt*32 + (r&3) + 8(r>>2) + 4h : 4 consecutive d per register quad ----
-    if (qsel >= 0 ? qpos == qsel : qpos < S) {
+    if (qsel >= 0 ? qpos == qsel : (qpos < S && qpos >= 0)) {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
         unsigned short* dst = (unsigned short*)p.O + (qsel >= 0 ? (size_t)b : rowbase + qpos) * p.ldo + head * HD + 4 * lh;
 #pragma unroll
@@ -534,26 +556,45 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
 }
 
 template <typename OT, int HD, bool CAUSAL>
-static void launch_one(const AttnParams& p, int batch, hipStream_t st) {
+static void launch_one(const AttnParams& p0, int batch, hipStream_t st) {
+    AttnParams p = p0;
     const int nqt = p.items ? p.n_items : p.qsel ? 1 : (p.S + 127) / 128;
     const int nq8 = p.qsel ? 1 : (p.S + 255) / 256;        // gathered mode: one query tile per (sequence, head)
+    // dense launches: 1-D grid in the XCD-aware order (AttnParams::lin_nqt), padded to whole groups of 8 (sequence, kv head) pairs
+    const char* xe = getenv("LR_ATT_XCD_ORDER");            // A/B switch, read per launch: 0 = the 3-D grid
+    const bool xcd_order = !xe || atoi(xe) != 0;
+    const char* qe = getenv("LR_ATT_QSHIFT");                // A/B switch: 0 = query tiles aligned to the start of the sequence
+    p.q_end_aligned = (!qe || atoi(qe) != 0) ? 1 : 0;
+    auto grid = [&](int nq) {
+        if (p.items || !xcd_order) { p.lin_nqt = 0; p.lin_batch = 0; return dim3(nq, p.heads, batch); }
+        p.lin_nqt = nq; p.lin_batch = batch;
+        const int kvpairs = p.heads / p.kv_group * batch;
+        return dim3((unsigned)((kvpairs + 7) / 8 * 8 * p.kv_group * nq), 1, 1);
+    };
     // Long sequences: 256-query workgroups on the ping-pong schedule (measured at B=32: HD 128 1.47x, where the 4-wave form
     // fits one workgroup per CU; HD 96 1.03-1.07x; split operands 1.01-1.03x; below ~1k keys the 128-query grid fills better).
     if (p.lo_off == 0 && !p.items && p.S >= 1024) {
-        hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, false, 8, true>), dim3(nq8, p.heads, batch), dim3(512), 0, st, p);
+        const dim3 g = grid(nq8);
+        hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, false, 8, true>), g, dim3(512), 0, st, p);
     } else if (p.lo_off > 0 && !p.items && p.S >= 1024 && HD != 128) {
-        if constexpr (HD != 128)
-            hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true, 8, true>), dim3(nq8, p.heads, batch), dim3(512), 0, st, p);
+        if constexpr (HD != 128) {
+            const dim3 g = grid(nq8);
+            hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true, 8, true>), g, dim3(512), 0, st, p);
+        }
     } else if (p.lo_off > 0 && !p.items && HD == 64 && p.S > 128) {
         // head_dim 64 (CLIP, 577 tokens): a 2-slot ring lets two 4-wave workgroups share a CU, and 128-query workgroups waste 10 % of
         // their query slots on 577 tokens where 256-query ones waste 25 %: 4.23 -> 3.53 ms at 544 x 577 x 16 heads, bit-identical
-        hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true, 4>), dim3(nqt, p.heads, batch), dim3(256), 0, st, p);
+        const dim3 g = grid(nqt);
+        hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true, 4>), g, dim3(256), 0, st, p);
     } else if (p.lo_off > 0 && !p.items && p.S > 128) {      // split-operand mode: 8 waves per workgroup (the ring fills the LDS)
-        hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true, 8>), dim3(nq8, p.heads, batch), dim3(512), 0, st, p);
+        const dim3 g = grid(nq8);
+        hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true, 8>), g, dim3(512), 0, st, p);
     } else if (p.lo_off > 0) {
-        hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true, 4>), dim3(nqt, p.heads, batch), dim3(256), 0, st, p);
+        const dim3 g = grid(nqt);
+        hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true, 4>), g, dim3(256), 0, st, p);
     } else {
-        hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, false, 4>), dim3(nqt, p.heads, batch), dim3(256), 0, st, p);
+        const dim3 g = grid(nqt);
+        hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, false, 4>), g, dim3(256), 0, st, p);
     }
 }
 

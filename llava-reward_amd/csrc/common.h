@@ -222,6 +222,13 @@ struct AttnParams {
     // query tile that holds it, with the arithmetic of the full launch (bit-identical), and stores that query's row to O[b].
     const int* qsel;
     int qsel_stride, qsel_last;
+    // ---- filled by launch_attention, not by callers ----
+    // XCD-aware workgroup order of the dense launches (1-D grid): workgroup ids go round-robin over the 8 XCDs, so id & 7 names
+    // the XCD; all query tiles of a (sequence, key/value head) -- its kv_group query heads included -- run on ONE XCD, back to
+    // back, heaviest first, and that XCD's L2 holds their K / V rows.  nqt = query tiles per (sequence, head), batch = sequences;
+    // 0 = the 3-D grid (ragged mode).
+    int lin_nqt, lin_batch;
+    int q_end_aligned;      // causal: query tiles shifted towards the end of the sequence by whole key tiles (see attn_kernel)
 };
 
 }  // namespace lr

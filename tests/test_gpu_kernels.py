@@ -730,3 +730,44 @@ def test_gemm_narrow_tiles_give_the_full_tile_bits(lib, monkeypatch):
         ref = (A32.double() @ W.double().t()).float()
         got = outs[0][0][:, :N].float() + outs[0][0][:, N:].float()
         assert (got - ref).abs().max().item() < 4e-5 * ref.abs().max().item()
+
+
+def test_attention_workgroup_order_and_query_tiling_are_bit_neutral(lib, monkeypatch):
+    """Round 4: dense attention launches walk their workgroups in an XCD-aware order (all query tiles of a (sequence, kv head) on one
+    XCD, heaviest first) and the long-sequence causal kernel shifts its query tiles towards the end of the sequence.  Neither may
+    change a bit: a query's arithmetic does not depend on the workgroup, wave or lane that holds it."""
+    def run(B, S, H, hd, causal, Hkv, pads):
+        Wd = (H + 2 * Hkv) * hd
+        g = torch.Generator(device="cuda").manual_seed(S + hd)
+        qkv = torch.cat([torch.randn(B * S, Wd, device="cuda", generator=g).half(),
+                         (torch.randn(B * S, Wd, device="cuda", generator=g) * 2.0 ** -12).half()], dim=1).contiguous()
+        mask = kmin = None
+        if causal:
+            mask = torch.ones(B, S, dtype=torch.int64, device="cuda")
+            kmin = torch.zeros(B, dtype=torch.int32, device="cuda")
+            for b, p_ in enumerate(pads):
+                mask[b, :p_] = 0
+                kmin[b] = p_
+        outs = []
+        for env in ({}, {"LR_ATT_XCD_ORDER": "0"}, {"LR_ATT_QSHIFT": "0"}, {"LR_ATT_XCD_ORDER": "0", "LR_ATT_QSHIFT": "0"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            out = torch.zeros(B * S, 2 * H * hd, device="cuda", dtype=torch.float16)
+            assert lib.lr_op_attention_split(P(qkv), P(qkv), P(qkv), P(out), P(mask), P(kmin), 2 * Wd, 2 * H * hd, 0, H * hd, (H + Hkv) * hd, Wd, H * hd,
+                                             B, S, H, hd, int(causal), H // Hkv, 1.0 / math.sqrt(hd), L.LR_DT_F16, stream()) == 0
+            torch.cuda.synchronize()
+            for k in env:
+                monkeypatch.delenv(k)
+            valid = torch.ones(B * S, dtype=torch.bool, device="cuda")
+            for b, p_ in enumerate(pads if causal else []):
+                valid[b * S: b * S + p_] = False
+            outs.append(out[valid])
+        assert all(torch.equal(outs[0], o) for o in outs[1:]), (B, S, H, hd, causal)
+        assert outs[0].float().abs().sum().item() > 0
+
+    run(3, 1100, 8, 96, True, 8, [0, 77, 640])          # ping-pong kernel, shifted query tiles, 3 x 8 pairs = 3 groups of 8
+    run(5, 1031, 4, 96, True, 4, [5, 0, 300, 64, 1000])  # 20 pairs: the grid is padded to 24
+    run(2, 700, 8, 96, True, 8, [0, 33])
+    run(9, 577, 16, 64, False, 16, [])                   # CLIP's shape
+    run(3, 1313, 8, 128, True, 2, [0, 100, 1])           # GQA: 4 query heads per kv head on one XCD
+    run(2, 70, 28, 128, True, 4, [0, 3])
