@@ -194,6 +194,8 @@ struct GemmParams {
     // ---- caller-provided storage for `sched`: 16 ints of DEVICE memory on the launch device, zero, used by one launch at a time
     // (an engine passes its own; null = the launcher keeps one set per (device, stream)) ----
     int* sched_mem;
+    // rows of tiles per band of the tile walk (launch8; 0 = 8): an XCD's 32 concurrent tiles form a gm x (32 / gm) patch
+    int gm;
 };
 
 struct AttnParams {

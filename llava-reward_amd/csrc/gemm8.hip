@@ -162,7 +162,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         int L;
         if (Ldyn >= 0) L = Ldyn;
         else L = chunk0(vb & 7) + (vb >> 3);
-        constexpr int GM = 8;
+        const int GM = p.gm;
         const int band = L / (GM * Nt);
         const int within = L - band * (GM * Nt);
         const int rows_in_band = min(GM, Mt - band * GM);
@@ -963,6 +963,12 @@ static void launch8(const GemmParams& p, bool persistent, hipStream_t st) {
     // persistent: one resident workgroup per CU (160 KB LDS each) walking its tiles; else one workgroup per tile
     const int grid = persistent ? std::min(Mt * Nt, num_cus()) : Mt * Nt;
     GemmParams q = p;
+    // Band height of the tile walk (an XCD's 32 concurrent tiles form a gm x 32/gm patch).  At the L2, 8 x 4 and 4 x 8 are the same
+    // optimum; what differs is the Infinity Cache: W plus the A bands of the 8 XCDs in flight (8 gm x 256 rows x K) must fit its
+    // 256 MB, or both are re-read from HBM at every patch step.  gate_up: W 151 MB + 151 MB of A at gm = 8 (thrashing) / 75 MB at
+    // gm = 4.  Measured (tools/gm_bench.py, profiles/r4_gemm_band_height.log): gm = 4 -2.2 % over the step's GEMMs against gm = 8
+    // (qkv -4 %), gm = 16 +6 %; deep K (down, fc2: K >= 4096, where even 4 rows of A are 100-200 MB) is best with gm = 1.
+    { const char* ge = getenv("LR_GEMM_GM"); q.gm = ge ? atoi(ge) : 0; if (q.gm < 1 || q.gm > 32) q.gm = (p.kw > 0 ? p.kw : p.K) >= 4096 ? 1 : 4; }
     static const bool dynamic = [] { const char* e = getenv("LR_GEMM_DYNAMIC"); return !e || atoi(e) != 0; }();
     q.sched = (persistent && PB == 2 && DBG != 2 && dynamic && grid % 8 == 0 && Mt * Nt >= 4 * grid) ? (p.sched_mem ? p.sched_mem : sched_words(st)) : nullptr;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), smem, st, q);

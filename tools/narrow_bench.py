@@ -42,32 +42,37 @@ def mixed_case(M, N, K, epi):
     return lambda: lib.lr_op_gemm_bt_mixed(P(A), P(W), P(W8), P(sc), P(out), None, M, N, K, epi, 0, L.LR_DT_F16, fused, C.byref(we), st())
 
 
-CASES = [("decoder o_proj      B=1", 2642, 3072, 3072, L.EPI_RESADD_F32), ("decoder down        B=1", 2642, 3072, 8192, L.EPI_RESADD_F32),
-         ("decoder qkv         B=1", 2642, 9216, 3072, L.EPI_OUT_OP), ("decoder gate_up     B=1", 2642, 16384, 3072, L.EPI_SWIGLU_OP),
-         ("CLIP out-proj       B=1", 9809, 1024, 1024, L.EPI_RESADD_F32), ("CLIP fc2            B=1", 9809, 1024, 4096, L.EPI_RESADD_F32),
-         ("CLIP qkv            B=1", 9809, 3072, 1024, L.EPI_OUT_OP), ("CLIP fc1            B=1", 9809, 4096, 1024, L.EPI_OUT_OP),
-         ("decoder o_proj      B=2", 5284, 3072, 3072, L.EPI_RESADD_F32), ("decoder o_proj      B=4", 10568, 3072, 3072, L.EPI_RESADD_F32),
-         ("gathered gate_up    M=32", 32, 16384, 3072, L.EPI_SWIGLU_OP), ("gathered down       M=32", 32, 3072, 8192, L.EPI_RESADD_F32),
-         ("adapter t = x A^T   B=32", 84544, 128, 3072, L.EPI_OUT_OP), ("adapter t (down)    B=32", 84544, 128, 8192, L.EPI_OUT_OP),
-         ("adapter t = x A^T   B=1", 2642, 128, 3072, L.EPI_OUT_OP)]
-print(f"{'GEMM':28s} {'M':>6s} {'N':>6s} {'K':>6s} {'256x256 us':>11s} {'128-row us':>11s} {'launcher us':>12s}")
-for name, M, N, K, epi in CASES:
-    fn = mixed_case(M, N, K, epi)
-    t = {}
-    for env in ("0", "1", None):
-        if env is None:
-            os.environ.pop("LR_GEMM_NARROW", None)
-        else:
-            os.environ["LR_GEMM_NARROW"] = env
-        t[env] = timed(fn)
-    print(f"{name:28s} {M:6d} {N:6d} {K:6d} {t['0']:11.1f} {t['1']:11.1f} {t[None]:12.1f}")
+def main():
+    CASES = [("decoder o_proj      B=1", 2642, 3072, 3072, L.EPI_RESADD_F32), ("decoder down        B=1", 2642, 3072, 8192, L.EPI_RESADD_F32),
+             ("decoder qkv         B=1", 2642, 9216, 3072, L.EPI_OUT_OP), ("decoder gate_up     B=1", 2642, 16384, 3072, L.EPI_SWIGLU_OP),
+             ("CLIP out-proj       B=1", 9809, 1024, 1024, L.EPI_RESADD_F32), ("CLIP fc2            B=1", 9809, 1024, 4096, L.EPI_RESADD_F32),
+             ("CLIP qkv            B=1", 9809, 3072, 1024, L.EPI_OUT_OP), ("CLIP fc1            B=1", 9809, 4096, 1024, L.EPI_OUT_OP),
+             ("decoder o_proj      B=2", 5284, 3072, 3072, L.EPI_RESADD_F32), ("decoder o_proj      B=4", 10568, 3072, 3072, L.EPI_RESADD_F32),
+             ("gathered gate_up    M=32", 32, 16384, 3072, L.EPI_SWIGLU_OP), ("gathered down       M=32", 32, 3072, 8192, L.EPI_RESADD_F32),
+             ("adapter t = x A^T   B=32", 84544, 128, 3072, L.EPI_OUT_OP), ("adapter t (down)    B=32", 84544, 128, 8192, L.EPI_OUT_OP),
+             ("adapter t = x A^T   B=1", 2642, 128, 3072, L.EPI_OUT_OP)]
+    print(f"{'GEMM':28s} {'M':>6s} {'N':>6s} {'K':>6s} {'256x256 us':>11s} {'128-row us':>11s} {'launcher us':>12s}")
+    for name, M, N, K, epi in CASES:
+        fn = mixed_case(M, N, K, epi)
+        t = {}
+        for env in ("0", "1", None):
+            if env is None:
+                os.environ.pop("LR_GEMM_NARROW", None)
+            else:
+                os.environ["LR_GEMM_NARROW"] = env
+            t[env] = timed(fn)
+        print(f"{name:28s} {M:6d} {N:6d} {K:6d} {t['0']:11.1f} {t['1']:11.1f} {t[None]:12.1f}")
 
-# vendor reference point: plain f16 GEMM of the dominant shape through torch.matmul (hipBLASLt), fp32 accumulate, f16 out
-M, N, K = 84544, 16384, 3072
-A = torch.randn(M, K, device="cuda").to(torch.float16)
-W = (torch.randn(N, K, device="cuda") * 0.02).to(torch.float16)
-us = timed(lambda: torch.matmul(A, W.t()))
-print(f"vendor library, plain f16 {M} x {N} x {K}: {us / 1e3:.2f} ms = {2.0 * M * N * K / us / 1e6:.0f} TFLOP/s")
-out = torch.zeros(M, N // 2, device="cuda", dtype=torch.float16)
-us2 = timed(lambda: lib.lr_op_gemm_bt(P(A), P(W), P(out), None, M, N, K, K, K, N // 2, L.EPI_SWIGLU_OP, 0, L.LR_DT_F16, 6, st()))
-print(f"this kernel, single-pass f16 + SwiGLU, same shape: {us2 / 1e3:.2f} ms = {2.0 * M * N * K / us2 / 1e6:.0f} TFLOP/s")
+    # vendor reference point: plain f16 GEMM of the dominant shape through torch.matmul (hipBLASLt), fp32 accumulate, f16 out
+    M, N, K = 84544, 16384, 3072
+    A = torch.randn(M, K, device="cuda").to(torch.float16)
+    W = (torch.randn(N, K, device="cuda") * 0.02).to(torch.float16)
+    us = timed(lambda: torch.matmul(A, W.t()))
+    print(f"vendor library, plain f16 {M} x {N} x {K}: {us / 1e3:.2f} ms = {2.0 * M * N * K / us / 1e6:.0f} TFLOP/s")
+    out = torch.zeros(M, N // 2, device="cuda", dtype=torch.float16)
+    us2 = timed(lambda: lib.lr_op_gemm_bt(P(A), P(W), P(out), None, M, N, K, K, K, N // 2, L.EPI_SWIGLU_OP, 0, L.LR_DT_F16, 6, st()))
+    print(f"this kernel, single-pass f16 + SwiGLU, same shape: {us2 / 1e3:.2f} ms = {2.0 * M * N * K / us2 / 1e6:.0f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
