@@ -196,6 +196,7 @@ struct GemmParams {
     int* sched_mem;
     // rows of tiles per band of the tile walk (launch8; 0 = 8): an XCD's 32 concurrent tiles form a gm x (32 / gm) patch
     int gm;
+    int band_chunks;      // dynamic walk: the XCDs' chunks are cut at band boundaries (launch8)
 };
 
 struct AttnParams {

@@ -151,9 +151,15 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
     // Static walk: workgroup slot i of the XCD takes i, i + 32, ...  Dynamic (p.sched, launch8): the first tile is the static one,
     // every further tile is claimed from the XCD's counter while the previous tile's epilogue runs; an XCD that runs ahead of the
     // others -- they differ by several per cent in sustained speed -- then takes tiles from the chunk with the most left.
+    // Dynamic walk over many bands (p.band_chunks, launch8): the chunks are cut at band boundaries, so every XCD starts a band at
+    // its first column tile and the eight of them move along N together -- the W tiles one XCD fetches are still in the Infinity
+    // Cache when the other seven ask for them, whatever the size of W (the chunks differ by up to one band; the XCDs that finish
+    // first take tiles from the longest one, as before).
     const int chq = nwg >> 3, chr = nwg & 7;
-    auto chunk0 = [&](int x) { return x < chr ? x * (chq + 1) : chr * (chq + 1) + (x - chr) * chq; };
-    auto chunk_n = [&](int x) { return chq + (x < chr ? 1 : 0); };
+    const int nbands = (Mt + p.gm - 1) / p.gm, band_tiles = p.gm * Nt;
+    const bool bandc = PB == 2 && p.sched != nullptr && p.band_chunks;
+    auto chunk0 = [&](int x) { return bandc ? min(nwg, (x * nbands >> 3) * band_tiles) : x < chr ? x * (chq + 1) : chr * (chq + 1) + (x - chr) * chq; };
+    auto chunk_n = [&](int x) { return bandc ? min(nwg, ((x + 1) * nbands >> 3) * band_tiles) - min(nwg, (x * nbands >> 3) * band_tiles) : chq + (x < chr ? 1 : 0); };
     const int my_xcd = (int)blockIdx.x & 7, per_xcd = (int)gridDim.x >> 3;
     const bool dyn = PB == 2 && p.sched != nullptr;
     int Ldyn = -1;
@@ -967,10 +973,13 @@ static void launch8(const GemmParams& p, bool persistent, hipStream_t st) {
     // optimum; what differs is the Infinity Cache: W plus the A bands of the 8 XCDs in flight (8 gm x 256 rows x K) must fit its
     // 256 MB, or both are re-read from HBM at every patch step.  gate_up: W 151 MB + 151 MB of A at gm = 8 (thrashing) / 75 MB at
     // gm = 4.  Measured (tools/gm_bench.py, profiles/r4_gemm_band_height.log): gm = 4 -2.2 % over the step's GEMMs against gm = 8
-    // (qkv -4 %), gm = 16 +6 %; deep K (down, fc2: K >= 4096, where even 4 rows of A are 100-200 MB) is best with gm = 1.
-    { const char* ge = getenv("LR_GEMM_GM"); q.gm = ge ? atoi(ge) : 0; if (q.gm < 1 || q.gm > 32) q.gm = (p.kw > 0 ? p.kw : p.K) >= 4096 ? 1 : 4; }
+    // (qkv -4 %), gm = 16 +6 %; with the XCDs' chunks cut at band boundaries (band_chunks below: -0.8 % more, LLaVA-7B's gate_up /
+    // down, whose W alone exceeds the cache, -2.2 / -2.5 %) gm = 4 is best or level on every shape, deep K included.
+    { const char* ge = getenv("LR_GEMM_GM"); q.gm = ge ? atoi(ge) : 0; if (q.gm < 1 || q.gm > 32) q.gm = 4; }
     static const bool dynamic = [] { const char* e = getenv("LR_GEMM_DYNAMIC"); return !e || atoi(e) != 0; }();
     q.sched = (persistent && PB == 2 && DBG != 2 && dynamic && grid % 8 == 0 && Mt * Nt >= 4 * grid) ? (p.sched_mem ? p.sched_mem : sched_words(st)) : nullptr;
+    { const char* be = getenv("LR_GEMM_BANDCHUNK"); const int nb = (Mt + q.gm - 1) / q.gm;
+      q.band_chunks = (q.sched && ((nb >> 3) - 1) * q.gm * Nt >= grid / 8 && (!be || atoi(be) != 0)) ? 1 : 0; }      // (every chunk holds its XCD's first tiles)
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), smem, st, q);
 }
 
