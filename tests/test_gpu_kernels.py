@@ -771,3 +771,44 @@ def test_attention_workgroup_order_and_query_tiling_are_bit_neutral(lib, monkeyp
     run(9, 577, 16, 64, False, 16, [])                   # CLIP's shape
     run(3, 1313, 8, 128, True, 2, [0, 100, 1])           # GQA: 4 query heads per kv head on one XCD
     run(2, 70, 28, 128, True, 4, [0, 3])
+
+
+def test_gemm_tile_walk_order_is_bit_neutral(lib, monkeypatch):
+    """Round 4: the persistent kernel walks its tiles in bands of 4 tile rows, the XCDs' chunks cut at band boundaries (so that W and the
+    A bands in flight fit the Infinity Cache, csrc/gemm8.hip launch8).  A tile's arithmetic does not depend on when or where it runs:
+    band heights 8 / 4 / 1, equal chunks, the static walk -- the same bits, on a problem large enough for the band-aligned chunks
+    (157 tile rows x 8 tile columns), ragged M, every operand form."""
+    code, tdt = L.LR_DT_F16, torch.float16
+    M, N, K = 40100, 2048, 512
+    A32 = rnd((M, K), 401, 0.7)
+    W = rnd((N, K), 402, 0.05).to(torch.bfloat16).to(tdt)
+    bias = rnd((N,), 403)
+    hi, lo = _split(A32, tdt)
+    A2 = torch.cat([hi, lo], dim=1).contiguous()
+    res = rnd((M, N), 404)
+
+    def run():
+        o1 = res.clone()
+        assert lib.lr_op_gemm_bt(P(hi), P(W), P(o1), P(None), M, N, K, K, K, N, L.EPI_RESADD_F32, 0, code, 6, stream()) == 0
+        o2 = torch.zeros(M, 2 * N, device="cuda", dtype=tdt)
+        assert lib.lr_op_gemm_bt_split(P(A2), P(W), P(o2), P(bias), M, N, K, L.EPI_OUT_OP, L.ACT_QUICK_GELU, code, 6, stream()) == 0
+        Aw = A2.clone()
+        sc = torch.full((lib.lr_op_lo8_scratch_bytes(M, K) + lib.lr_op_lo8_scratch_bytes(M, N // 2),), 127, dtype=torch.uint8, device="cuda")
+        W8 = torch.zeros_like(W)
+        we = C.c_int(0)
+        o3 = torch.zeros(M, N, device="cuda", dtype=tdt)
+        assert lib.lr_op_gemm_bt_mixed(P(Aw), P(W), P(W8), P(sc), P(o3), None, M, N, K, L.EPI_SWIGLU_OP, 0, code, 3 | 32, C.byref(we), stream()) == 0
+        torch.cuda.synchronize()
+        return o1, o2, o3, sc
+
+    base = run()
+    ref = (A32.double() @ W.double().t()).float() + res
+    assert (base[0] - ref).abs().max().item() < 2e-3 * ref.abs().max().item()         # (single-pass operands: sanity of the walk itself)
+    for env in ({"LR_GEMM_GM": "8"}, {"LR_GEMM_GM": "1"}, {"LR_GEMM_BANDCHUNK": "0"}, {"LR_GEMM_GM": "8", "LR_GEMM_BANDCHUNK": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = run()
+        for k in env:
+            monkeypatch.delenv(k)
+        for a, b in zip(base, got):
+            assert torch.equal(a, b), env
