@@ -257,7 +257,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
                 for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks) {
-#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 2)      // diagnostic build: no LDS fragment reads
+#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & (2 | 32))      // diagnostic build: no LDS fragment reads
                     const uint4 kf = qf[(ks + 1) % KSTEPS];
 #else
                     const uint4 kf = *(const uint4*)(sK + koff[kt][ks]);
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
                     s[kt] = Op<OT>::mfma32(kf, qf[ks], s[kt]);
                     if constexpr (PREC) {
                         s[kt] = Op<OT>::mfma32(kf, qfl[ks], s[kt]);
-#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 2)
+#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & (2 | 32))
                         const uint4 kl = qfl[(ks + 1) % KSTEPS];
 #else
                         const uint4 kl = *(const uint4*)(sK + 2 * TILE + koff[kt][ks]);
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
 #pragma unroll
                     for (int d = 0; d < DT; ++d) {
                         const char* vb = sV + (kt * 32 + 16 * st) * ROW + voff[d];
-#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 2)
+#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & (2 | 64))
                         (void)vb;
                         const uint4 vf = qf[d], vl_diag = qfl[d];
 #else
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
                         o[d] = Op<OT>::mfma32(vf, pf[2 * kt + st], o[d]);
                         if constexpr (PREC) {
                             o[d] = Op<OT>::mfma32(vf, pl[2 * kt + st], o[d]);
-#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 2)
+#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & (2 | 64))
                             const uint4 vl = vl_diag;
 #else
                             const s16x4 w0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 2 * TILE));
@@ -383,11 +383,26 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
                         }
                     }
         };
+#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 16)           // diagnostic 16 (tools/dbg/attn_stamps.py): cycles per segment of the ping-pong loop, summed
+        unsigned long long sg[5] = {0, 0, 0, 0, 0};        // over the tiles: vector, barrier 1, matrix, barrier 2, tiles; workgroup 0, behind O
+        auto stamp = [&]() -> unsigned long long {
+            unsigned long long tt;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            return tt;
+        };
+#define LR_ATT_STAMP(i, a, b) sg[i] += (b) - (a)
+#else
+#define LR_ATT_STAMP(i, a, b)
+        auto stamp = [&]() -> unsigned long long { return 0ull; };
+#endif
         if (ntiles > 0) {
             __syncthreads();                              // tiles 0 and 1 landed (the wait above retired them), sBits written
             if (grp) __syncthreads();                     // the late group starts one interval behind
             if (act(0)) qk(0);
             for (int t = 0; t < ntiles; ++t) {
+                const unsigned long long ts0 = stamp();
                 // ---- vector segment ----
 #if !(defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 8))          // diagnostic 8: no DMA in the loop (tiles 0, 1 only), results invalid
                 if (t + 2 < ntiles) issue(t + 2);         // (the issuing group only)
@@ -397,20 +412,33 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
                     if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPT) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
+                const unsigned long long ts1 = stamp();
 #if !(defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 4))          // diagnostic 4: no barriers in the loop, results invalid
                 __syncthreads();
 #endif
+                const unsigned long long ts2 = stamp();
                 // ---- matrix segment ----
                 __builtin_amdgcn_s_setprio(1);            // the wave in its matrix segment goes first (2-4 % on every shape)
                 if (act(t)) pv(t);
                 if (t + 1 < ntiles && act(t + 1)) qk(t + 1);
                 __builtin_amdgcn_s_setprio(0);
                 if (PREC && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned long long ts3 = stamp();
 #if !(defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 4))
                 if (t + 1 < ntiles || grp == 0) __syncthreads();
 #endif
+                const unsigned long long ts4 = stamp();
+                LR_ATT_STAMP(0, ts0, ts1); LR_ATT_STAMP(1, ts1, ts2); LR_ATT_STAMP(2, ts2, ts3); LR_ATT_STAMP(3, ts3, ts4);
+                (void)ts0; (void)ts1; (void)ts2; (void)ts3; (void)ts4;
             }
         }
+#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 16)
+        if (blockIdx.x == 0 && lane == 0 && p.lin_nqt > 0) {
+            unsigned long long* dbg = (unsigned long long*)((unsigned short*)p.O + (size_t)p.lin_batch * S * p.ldo) + wave * 8;
+            sg[4] = (unsigned long long)ntiles;
+            for (int i = 0; i < 5; ++i) dbg[i] = sg[i];
+        }
+#endif
     } else {
     for (int t = 0; t < ntiles; ++t) {
         const int k0 = kbeg + t * KT;

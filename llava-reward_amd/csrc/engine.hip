@@ -193,6 +193,15 @@ void alloc_gather_ws(lr_engine* h) {
     h->ffg = h->dalloc(R * d.intermediate * ob, false);
 }
 
+// DIAGNOSTIC ONLY (LR_ATT_EMU_LO8=1; tools/dbg/attn_lo8_probe.py): round the K / V residuals the attention kernel is about to read to
+// e4m3 with one scale per (token, head) -- see launch_emulate_lo8.  No effect unless the variable is set; default form only.
+static void emulate_attention_lo8(lr_engine* h, const AttnParams& ap, size_t rows, int kv_heads, int hd, hipStream_t st) {
+    static const bool on = [] { const char* e = getenv("LR_ATT_EMU_LO8"); return e && atoi(e) != 0; }();
+    if (!on || !ap.lo_off || !h->lo8) return;          // (stages in the default form only: lo8 = the e4m3-residual form is in force)
+    launch_emulate_lo8((void*)ap.K, rows, ap.ldq, ap.lo_off + ap.koff, kv_heads, hd, h->op_dt, st);
+    launch_emulate_lo8((void*)ap.V, rows, ap.ldq, ap.lo_off + ap.voff, kv_heads, hd, h->op_dt, st);
+}
+
 bool run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_mask, int B, int S, int gather) {
     const lr_model_desc& d = h->d;
     const int D = d.hidden, I = d.intermediate, Rl = B * S;
@@ -228,6 +237,7 @@ bool run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_ma
             ap.O = h->attg;
             ap.qsel = h->tstat; ap.qsel_stride = 4; ap.qsel_last = gather == 2 ? 1 : 0;
             apply_prec(h, ap);
+            emulate_attention_lo8(h, ap, Rl, d.kv_heads, h->hd, st);
             launch_attention(ap, B, h->hd, true, h->op_dt, st);
             launch_gather_norm_rows(h->x, h->tstat, S, gather == 2 ? 1 : 0, nullptr, 0.f, h->xg, B, D, st);      // (no weight: a plain row gather)
             gemm(h, st, h->attg, L.o_w, h->xg, nullptr, B, D, Hq, Hq, Hq, D, EPI_RESADD_F32, ACT_NONE, &L.lo);
@@ -239,6 +249,7 @@ bool run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_ma
             break;
         }
         apply_prec(h, ap);
+        emulate_attention_lo8(h, ap, Rl, d.kv_heads, h->hd, st);
         launch_attention(ap, B, h->hd, true, h->op_dt, st);
         gemm(h, st, h->att, L.o_w, h->x, nullptr, Rl, D, Hq, Hq, Hq, D, EPI_RESADD_F32, ACT_NONE, &L.lo);
         launch_norm_rows(h->x, L.ln2, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st, h->prec, 1,
@@ -627,6 +638,7 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
             gemm(h, st, h->clip_h, c.qkv_w, h->clip_qkv, c.qkv_b, Rc, 3 * Hc, Hc, Hc, Hc, 3 * Hc, EPI_OUT_OP, ACT_NONE);
             AttnParams ap{h->clip_qkv, h->clip_qkv, h->clip_qkv, h->clip_att, nullptr, nullptr, 0, 3 * Hc, Hc, 0, Hc, 2 * Hc, T, d.clip_heads, 0.125f, 1};
             apply_prec(h, ap);
+            emulate_attention_lo8(h, ap, Rc, d.clip_heads, 64, st);
             launch_attention(ap, NC, 64, false, h->op_dt, st);
             gemm(h, st, h->clip_att, c.out_w, h->clip_x, c.out_b, Rc, Hc, Hc, Hc, Hc, Hc, EPI_RESADD_F32, ACT_NONE);
             launch_norm_rows(h->clip_x, c.ln2_w, c.ln2_b, h->clip_h, Rc, Hc, d.clip_ln_eps, h->op_dt, st, h->prec, 1,

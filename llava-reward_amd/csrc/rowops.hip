@@ -1242,4 +1242,30 @@ void launch_quantize_rows_fp8(const void* x, int ldx, int K, int rows, void* q, 
     else hipLaunchKernelGGL(quantize_rows_fp8_kernel<BF16>, grid, block, 0, st, (const unsigned short*)x, ldx, K, rows, (unsigned char*)q, ldq, scale);
 }
 
+
+// DIAGNOSTIC ONLY (LR_ATT_EMU_LO8=1, tools/dbg/attn_lo8_probe.py): what the rewards would lose if attention's K_lo / V_lo residuals
+// were carried as e4m3 with one power-of-two scale per (token, head) -- the operand format of an e4m3 cross-term attention kernel
+// that does not exist yet.  Rounds the 16-bit residuals of the given column range to that grid IN PLACE (they stay 16-bit values).
+template <typename OT>
+__global__ void emulate_lo8_kernel(unsigned short* qkv, size_t rows, int ld, int col0, int heads, int hd) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * (size_t)heads) return;
+    unsigned short* p = qkv + (i / heads) * (size_t)ld + col0 + (int)(i % heads) * hd;
+    float m = 0.f;
+    for (int d = 0; d < hd; ++d) m = fmaxf(m, fabsf(Op<OT>::to_f32(p[d])));
+    const int E = e8m0_of_amax(m);
+    const float inv = e8m0_inv_scale(E), sc = __builtin_bit_cast(float, (unsigned)E << 23);
+    for (int d = 0; d < hd; d += 2) {
+        const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(Op<OT>::to_f32(p[d]) * inv, Op<OT>::to_f32(p[d + 1]) * inv, 0, false);
+        p[d] = Op<OT>::from_f32(__builtin_amdgcn_cvt_f32_fp8(pk, 0) * sc);
+        p[d + 1] = Op<OT>::from_f32(__builtin_amdgcn_cvt_f32_fp8(pk, 1) * sc);
+    }
+}
+void launch_emulate_lo8(void* qkv, size_t rows, int ld, int col0, int heads, int hd, int operand_dtype, hipStream_t st) {
+    const size_t n = rows * (size_t)heads;
+    if (!n) return;
+    if (operand_dtype == DT_F16) hipLaunchKernelGGL(emulate_lo8_kernel<F16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (unsigned short*)qkv, rows, ld, col0, heads, hd);
+    else hipLaunchKernelGGL(emulate_lo8_kernel<BF16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (unsigned short*)qkv, rows, ld, col0, heads, hd);
+}
+
 }  // namespace lr
