@@ -309,6 +309,112 @@ def golden_check(model, model_name, name=None, current=(1234, 0)):
                     "per_golden_if_default_form_were_forced = the same rows with the default form pinned (reported only)"}
 
 
+LINE_BUDGET = 4096                # bytes: the driver keeps an 8 KB stdout tail and parses the LAST line of it
+
+
+def _r(x, nd=6):
+    return None if x is None else (round(float(x), nd) if isinstance(x, (int, float)) and not isinstance(x, bool) else x)
+
+
+def _form(fi):
+    return None if not fi else fi.get("form")
+
+
+def compact_line(res):
+    """The ONE line the driver parses (rank 0's last stdout line): BASELINE.json's metric with `roofline` and `cpu_baseline`, every
+    field a number or a short string, <= LINE_BUDGET bytes whatever legs ran.  Everything else the run measured -- the legs'
+    full dicts, per-golden errors, notes -- goes to gpurun_out/bench_legs.json and to earlier '#leg' stdout lines (emit())."""
+    rf, dk = res.get("roofline") or {}, (res.get("roofline") or {}).get("dominant_kernel") or {}
+    wp = rf.get("whole_pass") or {}
+    out = {k: res.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                   "vs_baseline", "dtype", "data")}
+    out["value"], out["ms_per_step"] = _r(out["value"], 4), _r(out["ms_per_step"], 3)
+    fi = res.get("operand_form") or {}
+    out["operand_form"] = {"mode": res.get("operand_mode"), "form": fi.get("form"), "default_vs_strict": _r(fi.get("default_vs_strict"), 8),
+                           "budget": fi.get("budget"), "probe_rows": fi.get("rows"), "probe_seconds": _r(res.get("probe_seconds"), 3)}
+    out["config"] = {k: v for k, v in (res.get("config") or {}).items() if k in ("workload", "rows_per_gpu", "global_batch", "seq_len",
+                                                                                   "parallelism", "collective", "step", "input_check")}
+    out["roofline"] = {"bound": rf.get("bound"), "achieved": _r(rf.get("achieved"), 2), "peak": rf.get("peak"), "unit": rf.get("unit"),
+                       "frac": _r(rf.get("frac"), 4), "traffic": rf.get("traffic"), "kernel": rf.get("kernel"),
+                       "kernel_ms": _r(dk.get("avg_ms"), 4), "algorithmic_flop_per_launch": (2.0 * dk["shape"][0] * dk["shape"][1] * dk["shape"][2]) if dk.get("shape") else None,
+                       "mfma_busy": _r(dk.get("mfma_busy"), 4), "clock_ghz": _r(dk.get("clock_ghz"), 3), "pmc_source": dk.get("pmc_source") or dk.get("pmc_note"),
+                       "whole_pass_frac": _r(wp.get("frac", rf.get("frac")), 4), "vendor_frac": _r(dk.get("mfma_rate_vs_vendor"), 4),
+                       "vendor_plain_gemm_ms": _r((dk.get("vendor_library_same_shape") or {}).get("avg_ms"), 4)}
+    cb = res.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {"value": _r(cb["value"], 6), "unit": cb["unit"], "cores": cb["cores"], "host_cpus": cb.get("host_cpus"),
+                               "kind": cb["kind"], "seconds_per_row": _r(cb.get("seconds_per_row"), 2),
+                               "sample": "1 row, full shapes, full depth, fp32 torch oracle"}
+    pc = res.get("parity_check")
+    if pc:
+        out["parity_check"] = {"abs_err": _r(pc["abs_err"], 8), "worst": pc["worst"], "n_goldens": len(pc.get("per_golden") or {}),
+                               "tolerance": pc["tolerance"], "against": "reference fp32 CPU custom_forward goldens"}
+    if res.get("multi_gpu"):
+        out["multi_gpu"] = res["multi_gpu"]
+    legs = {}
+    for name, leg in res.items():
+        if not isinstance(leg, dict) or "value" not in leg or name in ("cpu_baseline",):
+            continue
+        e = {"value": _r(leg["value"], 3)}
+        if leg.get("ms_per_step") is not None:
+            e["ms"] = _r(leg["ms_per_step"], 2)
+        if _form(leg.get("operand_form")):
+            e["form"] = _form(leg["operand_form"])
+        for k in ("vs_headline", "vs_plain", "vs_resident_inputs"):
+            if leg.get(k) is not None:
+                e[k] = _r(leg[k], 4)
+        if isinstance(leg.get("parity_check"), dict):
+            e["abs_err"] = _r(leg["parity_check"]["abs_err"], 8)
+        if leg.get("parity") is not None:
+            e["parity"] = leg["parity"]
+        legs[name] = e
+        for sub, sl in leg.items():
+            if isinstance(sl, dict) and "value" in sl and sub != "parity_check":
+                se = {"value": _r(sl["value"], 3)}
+                if sl.get("vs_plain") is not None:
+                    se["vs_plain"] = _r(sl["vs_plain"], 4)
+                if _form(sl.get("operand_form")):
+                    se["form"] = _form(sl["operand_form"])
+                if sl.get("abs_err_vs_reference") is not None:
+                    se["abs_err_vs_reference"] = _r(sl["abs_err_vs_reference"], 4)
+                if sl.get("parity") is not None:
+                    se["parity"] = sl["parity"]
+                legs[f"{name}.{sub}"] = se
+    if res.get("latency_b1"):
+        legs["latency_b1"] = {"ms": _r(res["latency_b1"]["ms_per_forward"], 2), "ms_back_to_back": _r(res["latency_b1"]["ms_per_forward_enqueued_back_to_back"], 2)}
+    if legs:
+        out["legs"] = legs
+    out["legs_file"] = res.get("legs_file")
+    line = json.dumps(out, separators=(",", ":"))
+    for k in ("legs", "multi_gpu"):        # never outgrow the driver: drop the optional parts (they are in legs_file)
+        if len(line) > LINE_BUDGET and k in out:
+            out[k] = {"dropped": "line budget; see legs_file"}
+            line = json.dumps(out, separators=(",", ":"))
+    assert len(line) <= LINE_BUDGET, len(line)
+    return line
+
+
+def emit(res, legs_dir=None):
+    """stdout: one '#leg <name> <json>' line per secondary leg (greppable, each short enough to survive a tail), then -- LAST -- the
+    compact headline line.  The full object goes to <legs_dir>/bench_legs.json (default gpurun_out/, which gpurun merges back)."""
+    legs_dir = legs_dir or os.path.join(ROOT, "gpurun_out")
+    path = None
+    try:
+        os.makedirs(legs_dir, exist_ok=True)
+        path = os.path.join(legs_dir, "bench_legs.json")
+        with open(path, "w") as f:
+            json.dump(res, f, indent=1)
+        res["legs_file"] = os.path.relpath(path, ROOT)
+    except OSError:
+        res["legs_file"] = None
+    headline_keys = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"}
+    for k, v in res.items():
+        if k in headline_keys or not isinstance(v, dict):
+            continue
+        print("#leg " + k + " " + json.dumps(v, separators=(",", ":")), flush=True)
+    print(compact_line(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -333,6 +439,9 @@ def main():
                     "(synth.PROFILE_*): outlier = massive channels / large norm gains, what trained checkpoints show")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the secondary single-pass f16 measurement")
     ap.add_argument("--no-other-backbones", action="store_true", help="skip the Qwen2.5-VL-7B / LLaVA-1.6-7B sub-lines of the default run")
+    ap.add_argument("--check-inputs", default="deferred", choices=["eager", "deferred"],
+                    help="RewardModel(check_inputs=...): eager = the reference's exceptions raised by the forward itself (a stream drain per "
+                         "forward when input_ids live on the device, as they do here); deferred = the engine marks such rows NaN")
     ap.add_argument("--tile", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="phi3v", choices=["phi3v", "llava", "qwen"],
@@ -423,14 +532,20 @@ def main():
 
     def build_model(w, dtype, fp32_valued=False, profile=0):
         cfg, B, S = w["cfg"], w["B"], w["S"]
-        kw = dict(operand_dtype=dtype, synth_profile=profile, calibrate=not a.profile_run)
+        # check_inputs="deferred": ids are device-resident here, and the eager host check would drain the stream once per forward; the
+        # engine's own slot check (NaN rewards for a row whose image-slot count mismatches) stays, and every leg asserts finite rewards
+        kw = dict(operand_dtype=dtype, synth_profile=profile, calibrate=not a.profile_run, check_inputs=a.check_inputs)
         if w["model"] == "qwen":
             m = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=max(S, GOLDEN_MAX_SEQ.get("qwen", 0)), max_patches=max(B * 32 * 32, 2048), **kw)
         else:
             m = RewardModel(cfg, synth_seed=1234, max_batch=B, max_seq=max(S, GOLDEN_MAX_SEQ.get(w["model"], 0)),
                             max_crops=max(w["ncrop"], 5 if w["model"] == "llava" else 17), **kw)
         m.synth_fp32_valued = fp32_valued
+        torch.cuda.synchronize()
+        t_to = time.perf_counter()
         m = m.to(f"cuda:{local}").eval()
+        torch.cuda.synchronize()
+        m.to_cuda_seconds = time.perf_counter() - t_to        # engine build + weight synthesis + the operand-form probe
         if a.tile >= 0:
             m.engine.set_gemm_tile(a.tile)
         return m
@@ -495,10 +610,33 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    multi = None
     if world > 1:
-        t = torch.tensor([dt], device="cuda" if a.backend == "nccl" else "cpu", dtype=torch.float64)
+        cdev = "cuda" if a.backend == "nccl" else "cpu"
+        dt_own = dt
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # what lets a SCALE record confirm the collective saw N ranks on N devices: every rank's step time and device identity
+        # all-gathered, and the reward all-gather itself timed (events on the stream it runs on; host clock under gloo)
+        per = [torch.zeros(1, device=cdev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(per, torch.tensor([1e3 * dt_own / a.steps], device=cdev, dtype=torch.float64))
+        prop = torch.cuda.get_device_properties(local)
+        uid = str(getattr(prop, "uuid", "")) or f"{prop.name}:{local}"
+        ident = [None] * world
+        dist.all_gather_object(ident, (local, uid))
+        probe_r = torch.zeros(B, cfg.value_head_dim, device="cuda")
+        gather_rewards(probe_r if a.backend == "nccl" else probe_r.cpu())
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            gather_rewards(probe_r if a.backend == "nccl" else probe_r.cpu())
+        torch.cuda.synchronize()
+        multi = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "devices": [i[0] for i in ident],
+                 "distinct_devices": len({i[1] + ":" + str(i[0]) for i in ident}) if a.all_ranks_on_device < 0 else 1,
+                 "per_rank_ms": [round(float(p.item()), 3) for p in per],
+                 "collective_us": round(1e6 * (time.perf_counter() - t1) / 20, 1), "gathered_rows": int(out.shape[0]) if out.dim() else None}
     assert torch.isfinite(out).all(), "non-finite rewards"
 
     if rank == 0:
@@ -509,14 +647,17 @@ def main():
             "metric": "reward-pairs/sec (336px img, 128-tok caption) " + {"phi3v": "Phi-3.5-V", "llava": "LLaVA-v1.6-Mistral-7B", "qwen": "Qwen2.5-VL-7B"}[a.model], "value": value, "unit": "reward-pairs/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": f"{a.dtype} MFMA operands (bf16-valued weights), f32 accumulate/residual/softmax",
+            "dtype": "f16" if a.dtype.startswith("f16") else "fp8" if a.dtype == "fp8" else "bf16", "operand_mode": a.dtype,
+            "dtype_note": f"{a.dtype} MFMA operands (bf16-valued weights), f32 accumulate/residual/softmax",
             "operand_form": dict(model.form_info) if model.form_info else None,
+            "probe_seconds": getattr(model, "to_cuda_seconds", None), "multi_gpu": multi,
             "data": "synthetic (seeded weights and inputs; no checkpoint offline)",
             "hbm_bytes": {"workspace": model.engine.workspace_bytes(), "note": "activation workspace sized for (rows_per_gpu, seq_len) at lr_finalize; weights "
                           "(operand copies + residual / e4m3 twins in the split-operand modes) are extra"},
             "config": {"workload": w["name"] + ", S=%d" % S + (", un-merged LoRA adapter r=%d on the decoder linears" % a.lora_rank if a.lora_rank else ""),
                        "rows_per_gpu": B, "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
-                       "collective": "all_gather rewards [B,%d] fp32" % cfg.value_head_dim if world > 1 else "none"},
+                       "collective": "all_gather rewards [B,%d] fp32" % cfg.value_head_dim if world > 1 else "none",
+                       "input_check": a.check_inputs},
             "roofline": {"bound": "mfma", "achieved": tf_per_gpu, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf_per_gpu / PEAK_TFLOPS, "traffic": None,
                          "note": "whole pass: pairs/s x %.2f TFLOP ALGORITHMIC per pair, per GPU%s" % (
@@ -706,7 +847,7 @@ def main():
                 res["fast_mode"] = fm
             if headline and not a.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(res), flush=True)
+        emit(res)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

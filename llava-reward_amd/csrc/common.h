@@ -194,7 +194,7 @@ struct GemmParams {
     // ---- caller-provided storage for `sched`: 16 ints of DEVICE memory on the launch device, zero, used by one launch at a time
     // (an engine passes its own; null = the launcher keeps one set per (device, stream)) ----
     int* sched_mem;
-    // rows of tiles per band of the tile walk (launch8; 0 = 8): an XCD's 32 concurrent tiles form a gm x (32 / gm) patch
+    // rows of tiles per band of the tile walk (launch8 sets it: 4 unless LR_GEMM_GM says otherwise): an XCD's 32 concurrent tiles form a gm x (32 / gm) patch
     int gm;
     int band_chunks;      // dynamic walk: the XCDs' chunks are cut at band boundaries (launch8)
 };

@@ -180,6 +180,22 @@ struct lr_engine {
         (weight ? weight_bytes : ws_bytes) += bytes;
         return p;
     }
+    // pair8 rows ([e4m3(W) | e4m3(W_lo)], +1x the weight's bytes) of weight buffers that are exact in the operand type AGAIN (a
+    // re-upload / re-synthesis replaced merged-adapter or fp32-valued weights): nothing reads them any more -- give the HBM back.
+    // Called where `inexact` has just been read back, behind a device synchronisation.
+    void release_stale_pair8() {
+        for (auto it = pair8.begin(); it != pair8.end();) {
+            auto wb = wbuf_of.find(it->first);
+            const bool still = wb != wbuf_of.end() && !inexact.empty() && inexact[wb->second];
+            if (still || !it->second) { ++it; continue; }
+            const size_t bytes = (wbufs[wb->second].bytes + 255) & ~(size_t)255;
+            for (auto a = allocs.begin(); a != allocs.end(); ++a) if (*a == it->second) { allocs.erase(a); break; }
+            (void)hipFree(it->second);
+            weight_bytes -= bytes < weight_bytes ? bytes : weight_bytes;
+            w8exp.erase(it->first); w8exp2.erase(it->first);
+            it = pair8.erase(it);
+        }
+    }
     size_t opsz() const { return 2; }
 };
 

@@ -420,12 +420,15 @@ int lr_upload_weight(lr_handle h, const char* name, const void* data, const int6
                 h->w8exp.erase(wb.hi); h->w8exp2.erase(wb.hi);
             }
         }
+        if (s.wid >= 0 && s.lo_dst && h->inexact_dev && (size_t)s.rows * s.ld_dst * 2 == h->wbufs[s.wid].bytes && s.dst == h->wbufs[s.wid].hi)
+            LR_HIP_CHECK(hipMemset(h->inexact_dev + s.wid, 0, sizeof(int)));      // the whole buffer is replaced: it may be exact again
         pack_slot(h, s, f32);
         ++h->weights_epoch;
         h->w8.clear();             // W8A8 twins are separate buffers, rebuilt from the packed weights at the next launch
         LR_HIP_CHECK(hipStreamSynchronize(0));
         if (h->finalized && h->inexact_dev)      // a re-upload after lr_finalize may have made a buffer inexact
             LR_HIP_CHECK(hipMemcpy(h->inexact.data(), h->inexact_dev, h->wbufs.size() * sizeof(int), hipMemcpyDeviceToHost));
+        h->release_stale_pair8();
     });
 }
 
@@ -434,6 +437,7 @@ int lr_synth_weights(lr_handle h, uint64_t seed) { return lr_synth_weights_ex(h,
 int lr_synth_weights_ex(lr_handle h, uint64_t seed, int flags) {
     if (!h) return LR_EINVAL;
     return guarded(h, [&] {
+        if (h->inexact_dev) LR_HIP_CHECK(hipMemset(h->inexact_dev, 0, h->wbufs.size() * sizeof(int)));   // every buffer is rewritten below
         for (Slot& s : h->slots) {
             const size_t n = (size_t)s.rows * s.cols;
             ensure_stage(h, 0, n);
@@ -452,6 +456,7 @@ int lr_synth_weights_ex(lr_handle h, uint64_t seed, int flags) {
             h->inexact.resize(h->wbufs.size(), 0);
             LR_HIP_CHECK(hipMemcpy(h->inexact.data(), h->inexact_dev, h->wbufs.size() * sizeof(int), hipMemcpyDeviceToHost));
         }
+        h->release_stale_pair8();
     });
 }
 

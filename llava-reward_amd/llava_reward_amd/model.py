@@ -17,6 +17,14 @@ import torch
 from .synth import LlavaConfig, QwenConfig, RewardConfig, llava_geometry
 
 
+def _now(device) -> float:
+    """Host clock behind a drained stream (the probe's wall time, reported by bench.py)."""
+    import time
+    if getattr(device, "type", "cpu") == "cuda":
+        torch.cuda.synchronize(device)
+    return time.perf_counter()
+
+
 class _Outputs(dict):
     """`outputs` of custom_forward(return_output=True).  The reference hands back the backbone's whole output object; this one
     holds what its callers read.  A key the forward did not compute fails with the reason instead of a bare KeyError."""
@@ -35,7 +43,8 @@ class RewardModel:
     def __init__(self, cfg, weights: Optional[Dict[str, torch.Tensor]] = None, synth_seed: Optional[int] = None,
                  max_batch: int = 32, max_seq: int = 2816, max_crops: int = 17, operand_dtype: str = "f16x2f8",
                  layer_id: int = 32, mean_hidden_state=None, max_patches: int = 0, synth_profile: int = 0,
-                 calibrate: bool = True, parity_budget: float = 1.5e-4):
+                 calibrate: bool = True, parity_budget: float = 1.5e-4, operand_form: Optional[str] = None,
+                 check_inputs: str = "eager"):
         if weights is None and synth_seed is None:
             raise ValueError("RewardModel needs weights or a synth_seed")
         # rw_model:349-352: layer_id == 32 (the literal) -> last_hidden_state, else hidden_states[layer_id] = the input of decoder
@@ -64,6 +73,18 @@ class RewardModel:
         self.auto_calibrate = bool(calibrate)
         self.parity_budget = float(parity_budget)
         self._form_epoch = None                # lr_weights_epoch the locked form belongs to
+        # operand_form="<name of a _form_candidates entry>" (load_reward_adaptor: args.operand_form) PINS the form: no probe, the same
+        # form on every deployment of the checkpoint whatever the engine's capacity (the probe rows depend on max_crops / max_seq).
+        self.pinned_form = operand_form
+        if operand_form is not None and operand_form not in dict(self._form_candidates()):
+            raise ValueError(f"operand_form={operand_form!r}: not one of {[n for n, _ in self._form_candidates()]}")
+        # "eager": the reference's exceptions for rows whose image-slot count does not match their image_sizes, raised by this call
+        # (host tensors are counted on the host; DEVICE input_ids cost a stream drain per forward).  "deferred": no host-side check
+        # and no synchronisation -- the engine itself marks such a row's reward NaN (slot_check_kernel), visible at the caller's next
+        # read of the rewards.
+        if check_inputs not in ("eager", "deferred"):
+            raise ValueError("check_inputs must be 'eager' or 'deferred'")
+        self.check_inputs = check_inputs
         self._in_probe = False
         self.training = False
         self.device = torch.device("cpu")
@@ -120,9 +141,11 @@ class RewardModel:
         (decoder 16..31 strict alone: 2.2e-3) -- so the candidates grow from the front of the model."""
         L = int(self.config.layers)
         out = [("default", (-1, -1, 0, 0)), ("strict-vision", (1, -1, 0, 0))]
-        for frac, tag in ((4, "/4"), (2, "/2")):
-            k = L // frac
-            if 0 < k < L:
+        seen = set()
+        for num, den, tag in ((1, 8, "/8"), (1, 4, "/4"), (3, 8, "*3/8"), (1, 2, "/2")):
+            k = (L * num) // den
+            if 0 < k < L and k not in seen:
+                seen.add(k)
                 out.append((f"strict-vision+decoder{tag}", (1, 1, 0, L - k)))
         out.append(("strict", (1, 1, 0, 0)))
         return out
@@ -146,7 +169,12 @@ class RewardModel:
             cands = self._form_candidates()
             strict = score(cands[-1][1])
             import torch.distributed as dist
-            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            # Collective ONLY in the explicit calibrate() on user batches (documented as collective).  The probe of .to('cuda') / of
+            # a forward after a weight upload must not be one: the reference's .to() and forward have no collectives (rank-0-only
+            # evaluation, ranks loading at different times, one rank re-uploading a weight would deadlock or mis-pair with
+            # gather_rewards), and it would be redundant -- probe rows and weights are identical on every rank, so are the distances.
+            multi = source != "probe" and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            t_start = _now(self.device)
             tried, chosen = {}, "strict"
             for name, args in cands[:-1]:
                 d = 0.0
@@ -165,7 +193,7 @@ class RewardModel:
                     break
             self.operand_form = chosen
             self.form_info = {"form": chosen, "default_vs_strict": tried["default"], "distance_to_strict": tried, "source": source,
-                              "rows": int(sum(a.shape[0] for a in strict)), "budget": budget}
+                              "rows": int(sum(a.shape[0] for a in strict)), "budget": budget, "seconds": _now(self.device) - t_start}
             return dict(self.form_info)
         finally:
             self._in_probe = False
@@ -182,22 +210,40 @@ class RewardModel:
         <= 1e-4); outlier-bearing Phi-3.5-V 2.4e-3 .. 1.6e-2 (golden rows 4.8e-4 .. 2.6e-3), with adapters 3.4e-3.  The budget is HALF
         the bound the golden tests hold the locked form to (3e-4, itself a third of the 1e-3 bar): a form whose 4 probe rows sit
         within 1.7e-4 of the strict form still landed 3.3e-4 from the reference on a golden row (the rows are draws of one noise)."""
-        self._form_epoch = self.engine.weights_epoch()
+        epoch = self.engine.weights_epoch()
         if self._opts["operand_dtype"] != "f16x2f8":
+            self._form_epoch = epoch
+            return
+        if self.pinned_form is not None:
+            self.operand_form = self.pinned_form
+            self.form_info = {"form": self.pinned_form, "default_vs_strict": None, "source": "pinned (operand_form=...)", "rows": 0,
+                              "budget": self.parity_budget}
+            self._apply_form()
+            self._form_epoch = epoch
             return
         self.operand_form, self.form_info = "default", None
         if not self.auto_calibrate:
             self._apply_form()
+            self._form_epoch = epoch
             return
-        from .probe import probe_batches
-        batches = probe_batches(self)
-        if not batches:            # an engine too small for any probe row: nothing to measure on, stay on the safe side
+        try:
+            from .probe import probe_batches
+            batches = probe_batches(self)
+            if not batches:            # an engine too small for any probe row: nothing to measure on, stay on the safe side
+                self.operand_form = "strict"
+                self.form_info = {"form": "strict", "default_vs_strict": None, "source": "no probe row fits the engine's capacity", "rows": 0,
+                                  "budget": self.parity_budget}
+                self._apply_form()
+            else:
+                self._compare_forms(batches, self.parity_budget, "probe")
+        except BaseException:
+            # a probe forward failed (OOM, a rejected batch): the form was NOT checked on these weights.  Run the safe form, and leave
+            # _form_epoch behind so that the next forward tries the probe again instead of scoring un-checked in the cheapest form.
             self.operand_form = "strict"
-            self.form_info = {"form": "strict", "default_vs_strict": None, "source": "no probe row fits the engine's capacity", "rows": 0,
-                              "budget": self.parity_budget}
+            self.form_info = {"form": "strict", "default_vs_strict": None, "source": "probe failed", "rows": 0, "budget": self.parity_budget}
             self._apply_form()
-            return
-        self._compare_forms(batches, self.parity_budget, "probe")
+            raise
+        self._form_epoch = epoch
 
     def calibrate(self, *batches, parity_budget: float = 2.5e-4) -> Dict[str, object]:
         """Refinement of the automatic check of .to('cuda') on the caller's OWN data: `batches` (a few representative dicts of
@@ -235,23 +281,26 @@ class RewardModel:
             raise UnboundLocalError("img_token_batch_embedding: every row must carry an image")
         if input_ids.dim() == 3:
             input_ids = input_ids.squeeze(1)
-        sz = torch.as_tensor(image_sizes).cpu().long()
-        if self.model_type == "llava":
-            # rw_model:372-375 -> LlavaNext forward: image_sizes are the ORIGINAL (h, w); slots are image_token_id
-            n_slots = (input_ids == self.config.image_token_id).sum(dim=1).cpu()
-            expect = torch.tensor([llava_geometry(int(h), int(w), self.config.pinpoints, self.config.clip.image,
-                                                  self.config.clip.grid)[6] for h, w in sz.tolist()])
-            if not torch.equal(n_slots.long(), expect):
-                raise ValueError(f"Image features and image tokens do not match, tokens: {n_slots.tolist()}, "
-                                 f"features: {expect.tolist()}")          # modeling_llava_next.py get_placeholder_mask
-        else:
-            n_slots = (input_ids < 0).sum(dim=1).cpu()
-            g2 = self.config.clip.grid // 2
-            img = self.config.clip.image
-            expect = (sz[:, 0] // img) * g2 * ((sz[:, 1] // img) * g2 + 1) + 1 + g2 * (g2 + 1)
-            if not torch.equal(n_slots.long(), expect):
-                raise RuntimeError(f"shape mismatch: image slots per row {n_slots.tolist()} != projected image tokens "
-                                   f"{expect.tolist()} (modeling_phi3_v.py:247 index_put)")
+        sz = torch.as_tensor(image_sizes).cpu().long()        # the processors return host tensors: no copy, no stream drain
+        if self.check_inputs == "eager" or not input_ids.is_cuda:
+            # host tensors are counted on the host, BEFORE the H2D copy; device tensors drain the stream here (check_inputs="deferred"
+            # leaves the check to the engine: NaN rewards for such rows)
+            if self.model_type == "llava":
+                # rw_model:372-375 -> LlavaNext forward: image_sizes are the ORIGINAL (h, w); slots are image_token_id
+                n_slots = (input_ids == self.config.image_token_id).sum(dim=1).cpu()
+                expect = torch.tensor([llava_geometry(int(h), int(w), self.config.pinpoints, self.config.clip.image,
+                                                      self.config.clip.grid)[6] for h, w in sz.tolist()])
+                if not torch.equal(n_slots.long(), expect):
+                    raise ValueError(f"Image features and image tokens do not match, tokens: {n_slots.tolist()}, "
+                                     f"features: {expect.tolist()}")          # modeling_llava_next.py get_placeholder_mask
+            else:
+                n_slots = (input_ids < 0).sum(dim=1).cpu()
+                g2 = self.config.clip.grid // 2
+                img = self.config.clip.image
+                expect = (sz[:, 0] // img) * g2 * ((sz[:, 1] // img) * g2 + 1) + 1 + g2 * (g2 + 1)
+                if not torch.equal(n_slots.long(), expect):
+                    raise RuntimeError(f"shape mismatch: image slots per row {n_slots.tolist()} != projected image tokens "
+                                       f"{expect.tolist()} (modeling_phi3_v.py:247 index_put)")
         inner = self.model_type == "phi3v" and self.layer_id != 32 and self.layer_id < self.config.layers
         self.engine.set_layer_limits(-1, self.layer_id if inner else -1)
         reward = self.engine.forward(input_ids, attention_mask, pixel_values, sz, training=self.training, no_final_norm=inner,
@@ -292,10 +341,11 @@ class RewardModel:
         pix = inputs_batch["pixel_values"]
         grid = torch.as_tensor(inputs_batch["image_grid_thw"]).cpu().long()
         unit = self.config.vision.merge_unit
-        n_slots = int((ids == self.config.image_token_id).sum())
-        n_feat = int(grid.prod(dim=1).sum()) // unit
-        if n_slots != n_feat:
-            raise ValueError(f"Image features and image tokens do not match, tokens: {n_slots}, features: {n_feat}")
+        if self.check_inputs == "eager" or not ids.is_cuda:
+            n_slots = int((ids == self.config.image_token_id).sum())
+            n_feat = int(grid.prod(dim=1).sum()) // unit
+            if n_slots != n_feat:
+                raise ValueError(f"Image features and image tokens do not match, tokens: {n_slots}, features: {n_feat}")
         reward = self.engine.forward_qwen(ids, mask, pix, grid, training=self.training,
                                           keep_hidden_states=return_output or self.keep_hidden_states)
         return self._finish(reward, ids.shape, return_output)

@@ -7,8 +7,8 @@ passes, 22 bits) -- so the engine measures the distance between the two forms on
 function of (model geometry, engine capacity) ALONE: every rank, every shard and every batch size of one deployment sees the same
 rows and therefore locks the same form.
 
-Rows: `PROBE_ROWS` full-length rows (the largest crop grid / image that fits the engine's capacity, captions of 128 / 96 / 64 / 33
-tokens: left padding and the long-sequence regime are both inside), token ids from the counter hash of synth.py, pixels filled in
+Rows: `PROBE_ROWS` full-length rows in chunks of `PROBE_CHUNK` (the largest crop grid / image that fits the engine's capacity,
+captions of 128 / 96 / 64 / 33 and 112 / 80 / 48 / 17 tokens: left padding and the long-sequence regime are both inside), token ids from the counter hash of synth.py, pixels filled in
 HBM by the same hash (lr_op_synth_fill), std 1 like CLIP-normalised images."""
 from __future__ import annotations
 
@@ -22,8 +22,9 @@ from . import _lib as L
 from . import synth
 
 PROBE_SEED = 0x5EED0F0A
-PROBE_ROWS = 4
-PROBE_CAPTIONS = (128, 96, 64, 33)
+PROBE_ROWS = 8                   # round 5: 8 rows (4 until then): the decision is the MAX over the rows, and rows are draws of one noise
+PROBE_CHUNK = 4                  # scored 4 at a time: the rows (their left padding) do not depend on max_batch once it is >= 4
+PROBE_CAPTIONS = (128, 96, 64, 33, 112, 80, 48, 17)
 
 
 def _fill(lib, t: torch.Tensor, name: str) -> None:
@@ -63,7 +64,7 @@ def probe_batches(model, rows: int = PROBE_ROWS) -> List[Dict[str, object]]:
         caps = _captions(room, rows)
         b = synth.synth_batch(cfg, PROBE_SEED, caps, grid, with_pixels=False)
         ncr = grid[0] * grid[1] + 1
-        for lo, hi in _chunks(rows, mb):
+        for lo, hi in _chunks(rows, min(mb, PROBE_CHUNK)):
             pix = torch.empty(hi - lo, ncr, 3, cfg.clip.image, cfg.clip.image, device=dev, dtype=torch.float32)
             for r in range(lo, hi):
                 _fill(lib, pix[r - lo], f"probe.pixel_values.{r}")
@@ -83,7 +84,7 @@ def probe_batches(model, rows: int = PROBE_ROWS) -> List[Dict[str, object]]:
         ncr = 1 + g[0] * g[1]
         caps = _captions(ms - (g[6] + 5), rows)
         b = synth.llava_synth_batch(cfg, PROBE_SEED, caps, [size] * rows, with_pixels=False)
-        for lo, hi in _chunks(rows, mb):
+        for lo, hi in _chunks(rows, min(mb, PROBE_CHUNK)):
             pix = torch.empty(hi - lo, ncr, 3, cfg.clip.image, cfg.clip.image, device=dev, dtype=torch.float32)
             for r in range(lo, hi):
                 _fill(lib, pix[r - lo], f"probe.pixel_values.{r}")
@@ -97,7 +98,7 @@ def probe_batches(model, rows: int = PROBE_ROWS) -> List[Dict[str, object]]:
     grid = None
     for gsz in (32, 24, 16, 12, 8, 4):
         per_row = gsz * gsz
-        chunk = max(1, min(rows, mb))
+        chunk = max(1, min(rows, mb, PROBE_CHUNK))
         if per_row * chunk <= mp and per_row // v.merge_unit + 5 + 1 <= ms:
             grid = (gsz, gsz)
             break
@@ -106,7 +107,7 @@ def probe_batches(model, rows: int = PROBE_ROWS) -> List[Dict[str, object]]:
     caps = _captions(ms - (grid[0] * grid[1] // v.merge_unit + 5), rows)
     b = synth.qwen_synth_batch(cfg, PROBE_SEED, caps, grid, with_pixels=False)
     per_row = grid[0] * grid[1]
-    for lo, hi in _chunks(rows, mb):
+    for lo, hi in _chunks(rows, min(mb, PROBE_CHUNK)):
         pix = torch.empty((hi - lo) * per_row, v.patch_dim, device=dev, dtype=torch.float32)
         for r in range(lo, hi):
             _fill(lib, pix[(r - lo) * per_row:(r - lo + 1) * per_row], f"probe.pixel_values.{r}")

@@ -32,6 +32,13 @@ def _attach_adapter(args, cfg, weights, spec_fn, canon=None):
     return stats
 
 
+def _form_args(args):
+    """Knobs the reference does not have: args.operand_form = "<name>" pins the operand form of the default parity
+    mode across deployments (no probe); args.check_inputs = "deferred" drops the per-forward host check of device-resident inputs."""
+    return dict(operand_form=getattr(args, "operand_form", None), check_inputs=getattr(args, "check_inputs", "eager"),
+                parity_budget=getattr(args, "parity_budget", 1.5e-4))
+
+
 def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=False):
     with open(reward_config_path) as f:
         reward_cfg = yaml.safe_load(f)
@@ -44,8 +51,8 @@ def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=Fal
             raise FileNotFoundError(f"args.pretrain={args.pretrain!r} must be a local checkpoint directory "
                                     "(config.json + *.safetensors); hub download is not available offline")
         cfg = ckpt.config_from_hf(args.pretrain, reward_cfg)
-        if getattr(args, "flash_attn", False):         # the reference's scripts pass --flash_attn (eval/batch_inference_rm_phi.py:162)
-            cfg.rope_flash_convention = True
+        # su-RoPE switch convention: the eval loader of the reference never reads args.flash_attn (:24-60) -- the attention class, hence
+        # the convention, comes from the checkpoint's config.json alone, which config_from_hf has already read (_attn_implementation)
         names = [n for n, *_ in weight_specs(cfg)]
         head_names = {n for n in names if n.split(".")[0] in ("value_head", "W_q", "W_k", "W_v", "ca_layernorm")}
         weights = ckpt.read_base_weights(args.pretrain, [n for n in names if n not in head_names])
@@ -55,7 +62,7 @@ def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=Fal
         model = RewardModel(cfg, weights=weights,
                             max_batch=getattr(args, "max_batch", 32), max_seq=getattr(args, "max_seq", 2816),
                             max_crops=getattr(args, "max_crops", 17),
-                            operand_dtype=getattr(args, "operand_dtype", "f16x2f8"), calibrate=getattr(args, "calibrate", True))
+                            operand_dtype=getattr(args, "operand_dtype", "f16x2f8"), calibrate=getattr(args, "calibrate", True), **_form_args(args))
         model.model_type = "phi3v"
         if load_tokenizer:
             from transformers import AutoProcessor
@@ -79,7 +86,7 @@ def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=Fal
         weights.update(ckpt.read_heads(args.pm_path, cfg, getattr(args, "ft_projector", False)))
         model = RewardModel(cfg, weights=weights, max_batch=getattr(args, "max_batch", 32),
                             max_seq=getattr(args, "max_seq", 4096), max_crops=getattr(args, "max_crops", 5),
-                            operand_dtype=getattr(args, "operand_dtype", "f16x2f8"), calibrate=getattr(args, "calibrate", True))
+                            operand_dtype=getattr(args, "operand_dtype", "f16x2f8"), calibrate=getattr(args, "calibrate", True), **_form_args(args))
         if load_tokenizer:
             from transformers import LlavaNextProcessor
             processor = LlavaNextProcessor.from_pretrained(args.pretrain, cache_dir=getattr(args, "cache_dir", None))   # utils/utils.py:46-55
@@ -101,7 +108,7 @@ def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=Fal
         weights.update(ckpt.read_heads(args.pm_path, cfg, getattr(args, "ft_projector", False)))
         model = RewardModel(cfg, weights=weights, max_batch=getattr(args, "max_batch", 32),
                             max_seq=getattr(args, "max_seq", 2048), max_patches=getattr(args, "max_patches", 0),
-                            operand_dtype=getattr(args, "operand_dtype", "f16x2f8"), calibrate=getattr(args, "calibrate", True))
+                            operand_dtype=getattr(args, "operand_dtype", "f16x2f8"), calibrate=getattr(args, "calibrate", True), **_form_args(args))
         if load_tokenizer:
             from transformers import AutoProcessor
             processor = AutoProcessor.from_pretrained(args.pretrain, cache_dir=getattr(args, "cache_dir", None),

@@ -16,10 +16,12 @@ import os
 
 import numpy as np
 import pytest
+from conftest import record_locked_form
 import torch
 
 from llava_reward_amd import synth
 from llava_reward_amd.model import RewardModel
+from llava_reward_amd import probe as probe_mod
 from llava_reward_amd.reward_adaptor_loader import preference_compute
 from oracle import phi3v_reward_oracle as orc
 
@@ -124,7 +126,7 @@ def test_operand_form_is_locked_on_the_weights_by_to_cuda():
         info = m.form_info
         got = _fwd(m, batch)
         print(f"[form probe, profile {profile}] {info}; err {(got - ref).abs().max().item():.2e}")
-        assert info["source"] == "probe" and info["rows"] == 4 and info["form"] == m.operand_form and info["default_vs_strict"] < 1.0
+        assert info["source"] == "probe" and info["rows"] == probe_mod.PROBE_ROWS == 8 and info["seconds"] > 0 and info["form"] == m.operand_form and info["default_vs_strict"] < 1.0
         assert (got - ref).abs().max().item() < TOL_X8
         if profile == 0:
             assert m.operand_form == "default" and info["default_vs_strict"] < m.parity_budget
@@ -159,6 +161,83 @@ def test_operand_form_is_locked_on_the_weights_by_to_cuda():
             assert torch.equal(again, got)
     off = _model(cfg, seed, "f16x2f8", upload=False, calibrate=False)
     assert off.form_info is None and off.operand_form == "default"
+
+
+def test_operand_form_pin_failed_probe_and_deferred_input_check(monkeypatch):
+    """Round 5: (1) operand_form="<name>" pins the form (no probe runs; the same form on any engine capacity), bit-equal to the form
+    a probe would have had to lock; an unknown name is refused at construction.  (2) A probe that FAILS (advisor, round 4: OOM or a
+    rejected batch inside the re-lock path) must not leave the engine un-checked in the cheapest form: the model falls back to the
+    strict form, re-raises, and tries the probe again on the next forward.  (3) The probe is not a collective: with a process group
+    initialised, .to('cuda') issues no all_reduce (the reference's .to() and forward have none).  (4) check_inputs="deferred": no host
+    check; a row whose slot count mismatches comes back NaN from the engine, the other rows are untouched."""
+    cfg = synth.tiny_config(hidden=1024, intermediate=2048, heads=16, layers=4)
+    seed = 23
+    batch = synth.synth_batch(cfg, seed, [7, 3, 5], (1, 1))
+    names = [n for n, _ in RewardModel(cfg, synth_seed=seed)._form_candidates()]
+    assert names[0] == "default" and names[1] == "strict-vision" and names[-1] == "strict" and len(set(names)) == len(names) >= 5
+    with pytest.raises(ValueError):
+        RewardModel(cfg, synth_seed=seed, operand_form="nope")
+    strict = _fwd(_model(cfg, seed, "f16x2", upload=False), batch)
+    for name in (names[2], "strict"):
+        m = _model(cfg, seed, "f16x2f8", upload=False, operand_form=name)
+        assert m.operand_form == name and m.form_info["source"].startswith("pinned") and m.form_info["rows"] == 0
+        got = _fwd(m, batch)
+        assert torch.equal(got, strict) == (name == "strict")
+        m.engine.synth_weights(seed)               # new weights behind the handle: the pin survives the re-lock
+        assert torch.equal(_fwd(m, batch), got) and m.operand_form == name
+    # (2) failing probe
+    m = _model(cfg, seed, "f16x2f8", upload=False)
+    assert m.form_info["source"] == "probe"
+    calls = {"n": 0}
+    real = probe_mod.probe_batches
+
+    def boom(model, rows=probe_mod.PROBE_ROWS):
+        calls["n"] += 1
+        if calls["n"] == 1:
+            raise RuntimeError("probe blew up")
+        return real(model, rows)
+    monkeypatch.setattr(probe_mod, "probe_batches", boom)
+    m.engine.synth_weights(seed)
+    with pytest.raises(RuntimeError, match="probe blew up"):
+        _fwd(m, batch)
+    assert m.operand_form == "strict" and m.form_info["source"] == "probe failed" and m._form_epoch != m.engine.weights_epoch()
+    again = _fwd(m, batch)                          # the next forward retries the probe (second call succeeds)
+    assert calls["n"] == 2 and m.form_info["source"] == "probe" and m._form_epoch == m.engine.weights_epoch()
+    assert torch.equal(again, _fwd(_model(cfg, seed, "f16x2f8", upload=False), batch))
+    monkeypatch.undo()
+    # (3) no collective in the probe
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % (29800 + os.getpid() % 100), rank=0, world_size=1)
+        made = True
+    else:
+        made = False
+    try:
+        def no_collective(*a, **k):
+            raise AssertionError("collective inside .to('cuda') / the probe")
+        monkeypatch.setattr(dist, "all_reduce", no_collective)
+        monkeypatch.setattr(dist, "get_world_size", lambda *a, **k: 2)
+        mp = _model(cfg, seed, "f16x2f8", upload=False)
+        assert mp.form_info["source"] == "probe"
+    finally:
+        monkeypatch.undo()
+        if made:
+            dist.destroy_process_group()
+    # (4) deferred input check
+    md = _model(cfg, seed, "f16x2f8", upload=False, check_inputs="deferred", calibrate=False)
+    me = _model(cfg, seed, "f16x2f8", upload=False, calibrate=False)
+    good = _fwd(me, batch)
+    assert torch.equal(_fwd(md, batch), good)
+    bad = {k: v.copy() for k, v in batch.items()}
+    bad["input_ids"][1, int(np.nonzero(bad["input_ids"][1] < 0)[0][0])] = 7          # row 1: one image slot fewer than its image needs
+    with pytest.raises(RuntimeError):
+        _fwd(me, bad)
+    r = _fwd(md, bad)
+    assert torch.isnan(r[1]).all() and torch.equal(r[0], good[0]) and torch.equal(r[2], good[2])
+    # host-resident inputs are counted on the host even in deferred mode (free: no stream drain)
+    tb = {k: torch.from_numpy(v) for k, v in bad.items()}
+    with pytest.raises(RuntimeError):
+        md.custom_forward(tb["input_ids"], tb["attention_mask"], tb["pixel_values"], tb["image_sizes"])
 
 
 def test_stage_taps_tiny():
@@ -414,12 +493,14 @@ def test_reference_golden_full_size(path, dtype):
         # (GPM row).  .to('cuda') measured that on its probe rows -- no reference, no caller batches -- and locked a form with 16-bit
         # residual passes where this model needs them, so the unchanged drop-in sequence stays inside the bar.
         print(f"[{g['name']} {dtype}] form locked by .to('cuda'): {m.form_info}")
+        record_locked_form(g['name'], dtype, m, err)
         assert m.operand_form != "default" and err < TOL_X8          # (strict, or strict from the front of the model: _form_candidates)
     elif dtype == "f16x2f8":
         # default parity mode (e4m3 residual passes): <= 7e-5 on every benign row, and the probe keeps benign weights in that form
         # (the form is printed, not asserted: a benign weight set whose probe rows land above the budget runs strict -- slower, never
         #  less exact; bench.py prints the form its timed engine locked)
         print(f"[{g['name']} {dtype}] form locked by .to('cuda'): {m.form_info}")
+        record_locked_form(g['name'], dtype, m, err)
         assert err < TOL_X8
     else:
         # single-pass f16: 1e-3 in the assert_close sense (atol = rtol = 1e-3).  At full depth (23 + 32 layers) numerically

@@ -8,6 +8,7 @@ import os
 
 import numpy as np
 import pytest
+from conftest import record_locked_form
 import torch
 
 from llava_reward_amd import synth
@@ -82,6 +83,7 @@ def test_llava_reference_goldens(path, dtype):
         # (e4m3 residual passes where the model carries them -- measured <= 9.4e-5 on the full-size rows, outlier and e4m3-valued
         # weights included -- or the strict form where the probe rows say it does not)
         print(f"[{g['name']} {dtype}] form locked by .to('cuda'): {m.form_info}")
+        record_locked_form(g['name'], dtype, m, err)
         assert err < 3e-4
     elif "full" in g["name"]:
         # single-pass f16 is NOT a parity mode: at full depth it is noise-limited -- numerically equivalent builds of the same row

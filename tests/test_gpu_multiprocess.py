@@ -60,10 +60,16 @@ def test_bench_two_ranks_on_one_device(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    lines = r.stdout.splitlines()
+    line = [l for l in lines if l.startswith("{")][-1]
+    assert line == [l for l in lines if l.strip()][-1] and len(line) < 4096        # the driver parses the LAST line of an 8 KB tail
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 4 and res["scaling"] == "weak" and res["value"] > 0
     assert res["config"]["collective"].startswith("all_gather")
+    # what a SCALE record can check the collective by: ranks seen, every rank's own step time, the timed all-gather
+    mg = res["multi_gpu"]
+    assert mg["ranks_seen"] == 2 and len(mg["per_rank_ms"]) == 2 and all(t > 0 for t in mg["per_rank_ms"]) and mg["collective_us"] > 0
+    assert mg["devices"] == [0, 0] and mg["gathered_rows"] == 4 and max(mg["per_rank_ms"]) <= res["ms_per_step"] * 1.001
     # a failing child is this command's failure
     bad = subprocess.run(cmd + ["--model", "qwen", "--config", "gpm_pairwise"], capture_output=True, text=True, timeout=600, env=env)   # rejected by the ranks
     assert bad.returncode != 0

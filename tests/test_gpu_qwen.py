@@ -12,6 +12,7 @@ import os
 
 import numpy as np
 import pytest
+from conftest import record_locked_form
 import torch
 
 from llava_reward_amd import synth
@@ -210,6 +211,7 @@ def test_qwen_reference_golden_full_size(path, dtype):
     print(f"[{g['name']} {dtype}] reward hip={got.flatten().tolist()} ref={ref.flatten().tolist()} err={err:.3e}")
     if dtype == "f16x2f8":
         print(f"[{g['name']} {dtype}] form locked by .to('cuda'): {m.form_info}")      # (the bare drop-in sequence: no calibrate() call)
+        record_locked_form(g['name'], dtype, m, err)
     tol = {"f16x2": 3e-4 if g.get("weight_profile", 0) & synth.PROFILE_OUTLIER else 1e-4, "f16x2f8": 3e-4}.get(dtype, 5e-3)
     assert err < tol      # see the module docstring / DESIGN.md §4 (f16x2f8: measured 8.1e-5; outlier rows: fp32 summation-order noise amplified too)
     dup = dict(input_ids=np.concatenate([batch["input_ids"]] * 2), attention_mask=np.concatenate([batch["attention_mask"]] * 2),

@@ -392,3 +392,40 @@ def test_zero_pad_sequences_and_collate_rows_follow_the_reference_rules():
     assert b["pixel_values"].shape == (3, 2, 3, 4, 4) and b["pixel_values"][2].eq(2.0).all() and b["image_sizes"].tolist() == [[336, 336], [336, 672], [336, 1008]]
     raw = collate_rows(rows, pad_token_id=7, squeeze=False)          # the reference's own layout: singleton dim kept (:82-90 squeeze it)
     assert raw["input_ids"].shape == (3, 1, 6) and raw["pixel_values"].shape == (3, 1, 2, 3, 4, 4)
+
+
+def test_bench_final_line_is_compact_and_last(tmp_path, capsys):
+    """The driver keeps an 8 KB tail of bench.py's stdout and parses its last line: round 4's single 22 KB line came back `parsed: null`.
+    bench.emit() on the FULL result object of that very run (profiles/r4_bench.json, every leg present) must end with one '{' line of
+    <= 4 KB that carries the metric, `roofline` and `cpu_baseline`; the legs go to '#leg' lines in front of it and to bench_legs.json."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    res = json.load(open(os.path.join(ROOT, "profiles", "r4_bench.json")))
+    assert len(json.dumps(res)) > 20000                      # the object that broke the driver
+    res["multi_gpu"] = {"ranks_seen": 8, "backend": "nccl", "devices": list(range(8)), "distinct_devices": 8,
+                        "per_rank_ms": [1300.123] * 8, "collective_us": 55.5, "gathered_rows": 256}
+    bench.emit(res, legs_dir=str(tmp_path))
+    out = capsys.readouterr().out.splitlines()
+    assert out[-1].startswith("{") and all(not l.startswith("{") for l in out[:-1])
+    assert len(out[-1]) <= bench.LINE_BUDGET <= 4096
+    line = json.loads(out[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["value"] == pytest.approx(res["value"], rel=1e-4) and line["vs_baseline"] is None
+    rf = line["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-2)
+    assert rf["kernel_ms"] > 0 and "traffic" in rf and rf["whole_pass_frac"] > 0
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "reward-pairs/sec"
+    assert line["config"]["workload"].startswith("BASELINE configs[1]") and "model" not in line["config"]
+    assert line["multi_gpu"]["ranks_seen"] == 8
+    assert line["legs"]["llava"]["value"] > 0 and "qwen.lora_unmerged" in line["legs"]
+    full = json.load(open(tmp_path / "bench_legs.json"))
+    assert full["llava"]["parity_check"]["per_golden"]        # nothing was lost: the per-golden detail lives in the file
+    # a result with many more legs still fits: the optional parts are dropped, never the headline
+    for i in range(200):
+        res[f"extra_leg_{i}"] = {"value": 1.0, "ms_per_step": 2.0, "operand_form": {"form": "strict-vision+decoder/2"}}
+    assert len(bench.compact_line(res)) <= bench.LINE_BUDGET

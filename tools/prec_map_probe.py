@@ -45,6 +45,11 @@ if len(sys.argv) > 3 and sys.argv[3] == "strict-stages":       # which stages ha
             ("CLIP default, decoder 0..7 strict", (-1, 1, 0, L - 8)), ("CLIP default, decoder 0..15 strict", (-1, 1, 0, L - 16)),
             ("CLIP default, decoder 16..31 strict", (-1, 1, 16, 0)), ("CLIP default, decoder 24..31 strict", (-1, 1, 24, 0)),
             ("CLIP strict, decoder 0..15 strict", (1, 1, 0, L - 16))]
+if len(sys.argv) > 3 and sys.argv[3] == "ladder":       # round 5: the finer candidate ladder + cheaper-than-default tails
+    MAPS = [("strict everywhere (f16x2)", (1, 1, 0, 0)), ("default everywhere (f16x2f8)", (-1, -1, 0, 0)),
+            ("strict-vision", (1, -1, 0, 0))] + \
+           [(f"strict-vision+decoder 0..{k - 1} strict", (1, 1, 0, L - k)) for k in (2, 4, 6, 8, 10, 12, 16)] + \
+           [(f"default, decoder last {k} single pass", (-1, 0, L - k, 0)) for k in (1, 2, 4, 8)]
 for name, args in MAPS:
     r, ms = run(*args)
     d = (r - ref).abs()

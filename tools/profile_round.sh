@@ -4,7 +4,7 @@
 #      plus the dominant-kernel probe's -- no golden sweep, no legs), 
 #   2. PMC passes over the real Phi step (every kernel instantiation: traffic, MFMA busy, clock) -> <tag>_pmc_step.{md,json},
 #   3. PMC passes of the dominant GEMM alone (-> <tag>_pmc_gemm_gate_up.json, which bench.py reads from profiles/) and of the attention kernels,
-#   4. the full bench line.
+#   4. the full bench run (every leg; the compact driver line + gpurun_out/bench_legs.json) -> <tag>_bench.json / <tag>_bench_legs.json.
 #   gpurun -- 'bash tools/profile_round.sh r4'        then copy gpurun_out/<tag>/<tag>_* into profiles/
 set -u
 TAG=${1:-rX}
@@ -22,3 +22,4 @@ bash tools/pmc_step.sh $TAG/pmc_step > $O/${TAG}_pmc_step.md 2>&1; python3 tools
 bash tools/pmc_run.sh $TAG/pmc "mixed" 2>&1 | tail -3; cp $O/pmc/pmc_gemm_gate_up.json $O/${TAG}_pmc_gemm_gate_up.json
 bash tools/pmc_attn.sh $TAG/pmc_attn 2>&1 | tail -12 | tee $O/${TAG}_pmc_attention.md
 rm -rf $O/kstats_* $O/pmc/mixed/*/ $O/pmc_attn/*/ $O/pmc_step/*/
+(cd $R && python3 bench.py --steps 8 --warmup 2 > $O/bench.log 2>&1); grep '^{' $O/bench.log | tail -1 > $O/${TAG}_bench.json; cp gpurun_out/bench_legs.json $O/${TAG}_bench_legs.json; cut -c1-600 $O/${TAG}_bench.json
