@@ -139,15 +139,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
     // ---- LDS-DMA: per-thread (row, swizzled chunk) of each piece; destination is lane-linear ----
     typedef __attribute__((address_space(3))) char lds_char;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_char*)smem;
-    int drow[NPO], dkc[NPO], dvc[NPO];
-#pragma unroll
-    for (int it = 0; it < NPO; ++it) {
-        const int q = it * 256 + (tid & 255);
-        const int r = q / CH, c = q - r * CH;
-        drow[it] = r;
-        dkc[it] = (HD == 96 ? (c ^ ((r >> 2) & 3)) : HD == 64 ? (c ^ ((r >> 1) & 7)) : (c ^ (r & 15))) * 8;
-        dvc[it] = (HD == 96 ? c : HD == 64 ? (c ^ (((r >> 1) & 1) << 2)) : (c ^ ((r & 3) << 2))) * 8;
-    }
+    // (the (row, swizzled chunk) of a thread's pieces are recomputed at every issue from its laundered id: kept across the loop they
+    //  cost 3 NPO registers in a kernel whose split-operand form sits at the 256-register limit)
     auto dma = [&](const unsigned short* src, unsigned dst) {
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -158,11 +151,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
         const int slot = t % NSLOT;
         const int k0 = kbeg + t * KT;
         const unsigned dstK = __builtin_amdgcn_readfirstlane(lds_base + slot * NOPS * TILE + (wave & 3) * 1024);
+        int t256 = tid & 255;
+        asm volatile("" : "+v"(t256));
 #pragma unroll
         for (int it = 0; it < NPO; ++it) {
-            const size_t key = rowbase + min(k0 + drow[it], S - 1);
-            const unsigned short* sk = Kp + key * p.ldq + dkc[it];
-            const unsigned short* sv = Vp + key * p.ldq + dvc[it];
+            const int q = it * 256 + t256;
+            const int r = q / CH, c = q - r * CH;
+            const int dkc = (HD == 96 ? (c ^ ((r >> 2) & 3)) : HD == 64 ? (c ^ ((r >> 1) & 7)) : (c ^ (r & 15))) * 8;
+            const int dvc = (HD == 96 ? c : HD == 64 ? (c ^ (((r >> 1) & 1) << 2)) : (c ^ ((r & 3) << 2))) * 8;
+            const size_t key = rowbase + min(k0 + r, S - 1);
+            const unsigned short* sk = Kp + key * p.ldq + dkc;
+            const unsigned short* sv = Vp + key * p.ldq + dvc;
             const unsigned dk = dstK + it * 4096;
             dma(sk, dk);
             dma(sv, dk + TILE);
@@ -215,15 +214,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
     const int qpos = q0 + lc;
 
     // fragment read offsets (bytes inside an operand tile)
-    int koff[2][KSTEPS];
+    // K row of a lane = 32 kt + lc, 16-byte chunk 2 ks + lh, swizzled by XOR with m(row) (see the header): m does not depend on kt,
+    // so the offsets of a lane are kt * 32 ROW + per-lane values that depend on the swizzled low bits of the chunk only.  HD 96: m
+    // has 2 bits -> the chunk's bits above them (ks >> 1) are a compile-time 64-byte step and TWO per-lane values (ks even / odd)
+    // serve all 12 reads (a 12-register table otherwise; the split-operand instantiation has none to spare).
+    int kbase[HD == 96 ? 2 : KSTEPS];
+    {
+        const int m = HD == 96 ? ((lc >> 2) & 3) : HD == 64 ? ((lc >> 1) & 7) : (lc & 15);
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            const int row = kt * 32 + lc, c = 2 * ks + lh;
-            const int cs = HD == 96 ? (c ^ ((row >> 2) & 3)) : HD == 64 ? (c ^ ((row >> 1) & 7)) : (c ^ (row & 15));
-            koff[kt][ks] = row * ROW + cs * 16;
-        }
+        for (int i = 0; i < (HD == 96 ? 2 : KSTEPS); ++i) kbase[i] = lc * ROW + (((2 * i + lh) ^ m) << 4);
+    }
+    auto koff_of = [&](int kt, int ks) { return HD == 96 ? kbase[ks & 1] + kt * 32 * ROW + 64 * (ks >> 1) : kbase[ks] + kt * 32 * ROW; };
     // transposed V read: group g = lane>>4 covers keys 4h + q (q = (lane&15)>>2) and d columns
     // 16*(g&1) + 4*(lane&3) .. +3 of a 4-key x 16-d block; for HD 64 the 64-B window of rows 2,3 (mod 4) is swapped
     const int vq = (lane & 15) >> 2;
@@ -248,31 +249,43 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
         const int grp = wave >> 2;
         f32x16 s[2];
         uint4 pf[4], pl[PREC ? 4 : 1];
-        auto act = [&](int t) { return (!CAUSAL || (kbeg + t * KT <= q0 + 31)) && q0 < S; };       // (waves wholly outside the sequence idle)
+        // Fragment reads run PIPE steps ahead of the MFMAs that consume them (round 5).  As compiled until then, every K / V
+        // fragment of the matrix segment was requested, waited for (lgkmcnt(0)) and consumed: one LDS latency exposed per 1-3
+        // MFMAs, 48 times per tile and wave -- 2100 of the segment's 3870 cycles (profiles/r4_attention_stamps.log: "no fragment
+        // reads" 1770).  The LDS array itself was 14 % busy: latency, not bandwidth.  The steps are written in issue order and the
+        // order is pinned with scheduling groups (reads of step n + PIPE, then the MFMAs of step n); the waits are the compiler's
+        // own counted lgkmcnt (LDS returns in order).  Same MFMAs in the same order per accumulator: bit-identical results.
+        constexpr int PIPE = PREC ? 2 : 4;               // steps ahead; a step = 3 MFMAs (split operands) or 1
         auto qk = [&](int t) {
             const char* sK = smem + (t % NSLOT) * NOPS * TILE;
+            constexpr int NQ = 2 * KSTEPS;
+            uint4 kf[NQ], kl[PREC ? NQ : 1];
+            auto ld = [&](int n) {
+                const int kt = n / KSTEPS, ks = n % KSTEPS;
+                kf[n] = *(const uint4*)(sK + koff_of(kt, ks));
+                if constexpr (PREC) kl[n] = *(const uint4*)(sK + 2 * TILE + koff_of(kt, ks));
+            };
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
+            for (int n = 0; n < PIPE; ++n) ld(n);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+            for (int n = 0; n < NQ; ++n) {
+                const int kt = n / KSTEPS, ks = n % KSTEPS;
+                if (n + PIPE < NQ) ld(n + PIPE);
+                if (ks == 0) {
 #pragma unroll
-                for (int ks = 0; ks < KSTEPS; ++ks) {
-#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & (2 | 32))      // diagnostic build: no LDS fragment reads
-                    const uint4 kf = qf[(ks + 1) % KSTEPS];
-#else
-                    const uint4 kf = *(const uint4*)(sK + koff[kt][ks]);
-#endif
-                    s[kt] = Op<OT>::mfma32(kf, qf[ks], s[kt]);
-                    if constexpr (PREC) {
-                        s[kt] = Op<OT>::mfma32(kf, qfl[ks], s[kt]);
-#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & (2 | 32))
-                        const uint4 kl = qfl[(ks + 1) % KSTEPS];
-#else
-                        const uint4 kl = *(const uint4*)(sK + 2 * TILE + koff[kt][ks]);
-#endif
-                        s[kt] = Op<OT>::mfma32(kl, qf[ks], s[kt]);
-                    }
+                    for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
                 }
+                s[kt] = Op<OT>::mfma32(kf[n], qf[ks], s[kt]);
+                if constexpr (PREC) {
+                    s[kt] = Op<OT>::mfma32(kf[n], qfl[ks], s[kt]);
+                    s[kt] = Op<OT>::mfma32(kl[n], qf[ks], s[kt]);
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, PIPE * (PREC ? 2 : 1), 0);
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                if (n + PIPE < NQ) __builtin_amdgcn_sched_group_barrier(0x100, PREC ? 2 : 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, PREC ? 3 : 1, 0);
             }
         };
         auto soft = [&](int t) {
@@ -350,38 +363,38 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
         };
         auto pv = [&](int t) {
             const char* sV = smem + (t % NSLOT) * NOPS * TILE + TILE;
+            constexpr int NP = 4 * DT;                   // steps: (kt, st, d), d fastest
+            uint4 vf[NP], vl[PREC ? NP : 1];
+            auto trd = [&](const char* a) {
+                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 8 * ROW));
+                const uint2 x = __builtin_bit_cast(uint2, v0), y = __builtin_bit_cast(uint2, v1);
+                return make_uint4(x.x, x.y, y.x, y.y);
+            };
+            auto ld = [&](int n) {
+                const int kt = n / (2 * DT), st = (n / DT) & 1, d = n % DT;
+                const char* vb = sV + (kt * 32 + 16 * st) * ROW + voff[d];
+                vf[n] = trd(vb);
+                if constexpr (PREC) vl[n] = trd(vb + 2 * TILE);
+            };
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int n = 0; n < PIPE; ++n) ld(n);
 #pragma unroll
-                for (int st = 0; st < 2; ++st)
+            for (int n = 0; n < NP; ++n) {
+                const int kt = n / (2 * DT), st = (n / DT) & 1, d = n % DT;
+                if (n + PIPE < NP) ld(n + PIPE);
+                o[d] = Op<OT>::mfma32(vf[n], pf[2 * kt + st], o[d]);
+                if constexpr (PREC) {
+                    o[d] = Op<OT>::mfma32(vf[n], pl[2 * kt + st], o[d]);
+                    o[d] = Op<OT>::mfma32(vl[n], pf[2 * kt + st], o[d]);
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, PIPE * (PREC ? 4 : 2), 0);
 #pragma unroll
-                    for (int d = 0; d < DT; ++d) {
-                        const char* vb = sV + (kt * 32 + 16 * st) * ROW + voff[d];
-#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & (2 | 64))
-                        (void)vb;
-                        const uint4 vf = qf[d], vl_diag = qfl[d];
-#else
-                        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb));
-                        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * ROW));
-                        uint4 vf;
-                        const uint2 a = __builtin_bit_cast(uint2, v0), c = __builtin_bit_cast(uint2, v1);
-                        vf.x = a.x; vf.y = a.y; vf.z = c.x; vf.w = c.y;
-#endif
-                        o[d] = Op<OT>::mfma32(vf, pf[2 * kt + st], o[d]);
-                        if constexpr (PREC) {
-                            o[d] = Op<OT>::mfma32(vf, pl[2 * kt + st], o[d]);
-#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & (2 | 64))
-                            const uint4 vl = vl_diag;
-#else
-                            const s16x4 w0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 2 * TILE));
-                            const s16x4 w1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 2 * TILE + 8 * ROW));
-                            uint4 vl;
-                            const uint2 a2 = __builtin_bit_cast(uint2, w0), c2 = __builtin_bit_cast(uint2, w1);
-                            vl.x = a2.x; vl.y = a2.y; vl.z = c2.x; vl.w = c2.y;
-#endif
-                            o[d] = Op<OT>::mfma32(vl, pf[2 * kt + st], o[d]);
-                        }
-                    }
+            for (int n = 0; n < NP; ++n) {
+                if (n + PIPE < NP) __builtin_amdgcn_sched_group_barrier(0x100, PREC ? 4 : 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, PREC ? 3 : 1, 0);
+            }
         };
 #if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 16)           // diagnostic 16 (tools/dbg/attn_stamps.py): cycles per segment of the ping-pong loop, summed
         unsigned long long sg[5] = {0, 0, 0, 0, 0};        // over the tiles: vector, barrier 1, matrix, barrier 2, tiles; workgroup 0, behind O
@@ -397,39 +410,63 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
 #define LR_ATT_STAMP(i, a, b)
         auto stamp = [&]() -> unsigned long long { return 0ull; };
 #endif
+        // act(t) is monotone (causal: the tiles up to the wave's diagonal; dense: all, or none for a wave wholly past the sequence), so
+        // a wave's tiles are `nact` active ones followed by inactive ones in which it only keeps the DMA stream and the barriers going.
+        // Two loops instead of `if (act(t))` around every segment: with the conditions inside one loop S and P were both loop-carried
+        // (each keeps its old value on the untaken path), 64 registers where 32 are live -- the registers the fragment ring needs.
+        int nact = 0;
+        if (q0 < S && ntiles > 0) nact = CAUSAL ? max(0, min(ntiles, (q0 + 31 - kbeg) / KT + 1)) : ntiles;
+        if (CAUSAL && q0 + 31 < kbeg) nact = 0;
+        nact = __builtin_amdgcn_readfirstlane(nact);
+        auto vec_dma = [&](int t) {
+#if !(defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 8))          // diagnostic 8: no DMA in the loop (tiles 0, 1 only), results invalid
+            if (t + 2 < ntiles) issue(t + 2);             // (the issuing group only)
+#endif
+        };
+        auto vec_wait = [&](int t) {
+            if (!PREC && grp == 0) {
+                if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPT) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        };
+        auto bar = [&]() {
+#if !(defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 4))          // diagnostic 4: no barriers in the loop, results invalid
+            __syncthreads();
+#endif
+        };
         if (ntiles > 0) {
             __syncthreads();                              // tiles 0 and 1 landed (the wait above retired them), sBits written
             if (grp) __syncthreads();                     // the late group starts one interval behind
-            if (act(0)) qk(0);
-            for (int t = 0; t < ntiles; ++t) {
+            if (nact > 0) qk(0);
+            else asm volatile("" : "=v"(s[0]), "=v"(s[1]));
+            for (int t = 0; t < nact; ++t) {
                 const unsigned long long ts0 = stamp();
                 // ---- vector segment ----
-#if !(defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 8))          // diagnostic 8: no DMA in the loop (tiles 0, 1 only), results invalid
-                if (t + 2 < ntiles) issue(t + 2);         // (the issuing group only)
-#endif
-                if (act(t)) soft(t);
-                if (!PREC && grp == 0) {
-                    if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPT) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
+                vec_dma(t);
+                soft(t);
+                vec_wait(t);
                 const unsigned long long ts1 = stamp();
-#if !(defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 4))          // diagnostic 4: no barriers in the loop, results invalid
-                __syncthreads();
-#endif
+                bar();
                 const unsigned long long ts2 = stamp();
                 // ---- matrix segment ----
                 __builtin_amdgcn_s_setprio(1);            // the wave in its matrix segment goes first (2-4 % on every shape)
-                if (act(t)) pv(t);
-                if (t + 1 < ntiles && act(t + 1)) qk(t + 1);
+                pv(t);
+                if (t + 1 < nact) qk(t + 1);
+                else asm volatile("" : "=v"(s[0]), "=v"(s[1]));       // (S is dead: no value is carried round the loop on this path)
                 __builtin_amdgcn_s_setprio(0);
                 if (PREC && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const unsigned long long ts3 = stamp();
-#if !(defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 4))
-                if (t + 1 < ntiles || grp == 0) __syncthreads();
-#endif
+                if (t + 1 < ntiles || grp == 0) bar();
                 const unsigned long long ts4 = stamp();
                 LR_ATT_STAMP(0, ts0, ts1); LR_ATT_STAMP(1, ts1, ts2); LR_ATT_STAMP(2, ts2, ts3); LR_ATT_STAMP(3, ts3, ts4);
                 (void)ts0; (void)ts1; (void)ts2; (void)ts3; (void)ts4;
+            }
+            for (int t = nact; t < ntiles; ++t) {         // past this wave's diagonal: the DMA stream and the barriers only
+                vec_dma(t);
+                vec_wait(t);
+                bar();
+                if (PREC && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (t + 1 < ntiles || grp == 0) bar();
             }
         }
 #if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 16)
@@ -468,11 +505,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
                 for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks) {
-                    const uint4 kf = *(const uint4*)(sK + koff[kt][ks]);
+                    const uint4 kf = *(const uint4*)(sK + koff_of(kt, ks));
                     s[kt] = Op<OT>::mfma32(kf, qf[ks], s[kt]);
                     if constexpr (PREC) {
                         s[kt] = Op<OT>::mfma32(kf, qfl[ks], s[kt]);
-                        const uint4 kl = *(const uint4*)(sK + 2 * TILE + koff[kt][ks]);
+                        const uint4 kl = *(const uint4*)(sK + 2 * TILE + koff_of(kt, ks));
                         s[kt] = Op<OT>::mfma32(kl, qf[ks], s[kt]);
                     }
                 }

@@ -174,11 +174,15 @@ def test_operand_form_pin_failed_probe_and_deferred_input_check(monkeypatch):
     seed = 23
     batch = synth.synth_batch(cfg, seed, [7, 3, 5], (1, 1))
     names = [n for n, _ in RewardModel(cfg, synth_seed=seed)._form_candidates()]
-    assert names[0] == "default" and names[1] == "strict-vision" and names[-1] == "strict" and len(set(names)) == len(names) >= 5
+    i0 = names.index("default")          # (cheaper single-pass-tail candidates come first where the decoder is deep enough)
+    assert names[i0 + 1] == "strict-vision" and names[-1] == "strict" and len(set(names)) == len(names) >= 5
+    assert all(n.startswith("default+single-tail/") for n in names[:i0])
+    full = [n for n, _ in RewardModel(synth.full_config(), synth_seed=seed)._form_candidates()]
+    assert full[:4] == ["default+single-tail/4", "default+single-tail/8", "default+single-tail/16", "default"] and full[-1] == "strict"
     with pytest.raises(ValueError):
         RewardModel(cfg, synth_seed=seed, operand_form="nope")
     strict = _fwd(_model(cfg, seed, "f16x2", upload=False), batch)
-    for name in (names[2], "strict"):
+    for name in (names[i0 + 2], "strict"):
         m = _model(cfg, seed, "f16x2f8", upload=False, operand_form=name)
         assert m.operand_form == name and m.form_info["source"].startswith("pinned") and m.form_info["rows"] == 0
         got = _fwd(m, batch)
