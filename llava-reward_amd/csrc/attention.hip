@@ -54,6 +54,16 @@ template <typename OT> __device__ __forceinline__ void split2_unit(float a, floa
     hi = pack2_fast<OT>(a, b);
     lo = pack2_fast<OT>(a - Op<OT>::to_f32((unsigned short)(hi & 0xFFFFu)), b - Op<OT>::to_f32((unsigned short)(hi >> 16)));
 }
+// f16: the residual a - float(hi) as ONE v_fma_mix_f32 (fma(float(hi.half), -1, a): the f16 -> f32 widening rides in the instruction,
+// the product is exact, so the value is the subtraction's, bit for bit) instead of a conversion and (half) a packed subtraction:
+// 16 vector instructions fewer per 64-key tile and wave.  hipcc does not form it from the source above.
+template <> __device__ __forceinline__ void split2_unit<F16>(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = pack2_fast<F16>(a, b);
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hi), "v"(b));
+    lo = pack2_fast<F16>(ra, rb);
+}
 
 constexpr int ATT_MAX_S = 8192;        // keys covered by the LDS bitmask
 
@@ -139,42 +149,83 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
     // ---- LDS-DMA: per-thread (row, swizzled chunk) of each piece; destination is lane-linear ----
     typedef __attribute__((address_space(3))) char lds_char;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_char*)smem;
-    // (the (row, swizzled chunk) of a thread's pieces are recomputed at every issue from its laundered id: kept across the loop they
-    //  cost 3 NPO registers in a kernel whose split-operand form sits at the 256-register limit)
-    auto dma = [&](const unsigned short* src, unsigned dst) {
+    // Source address of a piece = a UNIFORM 64-bit base (operand, sequence, kv head, first key of the tile: SGPRs, rebuilt per tile
+    // with scalar arithmetic) + a per-thread 32-bit byte offset ((row, swizzled chunk) of the piece inside a tile: 2 NPO registers,
+    // constant over the kernel) -- the saddr form of the DMA instruction.  Until round 5 every piece's 64-bit per-lane address was
+    // rebuilt with vector arithmetic at every issue (~20 VALU operations per piece): in-kernel stamps showed the 12 pieces of a
+    // split-operand tile costing the issuing group 2200 cycles of its 4000-cycle vector segment, the critical path of the ping-pong
+    // period once the matrix segments were pipelined.  The clamp that keeps a last, partial tile's rows inside the sequence
+    // (min(key, S - 1): rows past it are masked scores, but must not be read past the buffer) is a per-tile uniform branch.
+    unsigned offK[NPO], offV[NPO];
+#pragma unroll
+    for (int it = 0; it < NPO; ++it) {
+        const int q = it * 256 + (tid & 255);
+        const int r = q / CH, c = q - r * CH;
+        const int dkc = (HD == 96 ? (c ^ ((r >> 2) & 3)) : HD == 64 ? (c ^ ((r >> 1) & 7)) : (c ^ (r & 15))) * 8;
+        const int dvc = (HD == 96 ? c : HD == 64 ? (c ^ (((r >> 1) & 1) << 2)) : (c ^ ((r & 3) << 2))) * 8;
+        offK[it] = (unsigned)(r * p.ldq + dkc) * 2u;
+        offV[it] = (unsigned)(r * p.ldq + dvc) * 2u;
+    }
+    auto dma = [&](const unsigned short* base, unsigned off, unsigned dst) {       // base: uniform
         unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
     };
-    auto issue = [&](int t) {            // tile t (keys kbeg + 64 t ..) -> slot t % NSLOT
-        if (NW > 4 && (wave >> 2) != DMAG) return;  // the DMA pieces are laid out for 256 threads
+    auto uni = [&](const unsigned short* q) {          // a pointer the compiler may not have proved uniform -> SGPR pair
+        const unsigned long long u = (unsigned long long)q;
+        return (const unsigned short*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u));
+    };
+    // SPLIT_DMA (ping-pong, split operands; round 5): the early group issues the K / K_lo pieces of tile t + 2, the late group its
+    // V / V_lo pieces, each in its own vector segment t and each retiring its pieces (vmcnt(0)) at the end of its matrix segment t.
+    // Legal on the 3-slot ring: the K region of slot (t + 2) % 3 was last read by the late group's QK(t - 1), i.e. in its matrix
+    // segment t - 2, which ended two barriers before the early group's vector segment t; the V region is still being read by the
+    // late group's PV(t - 1) then, so only the late group (whose vector segment t follows that) may refill it -- as before.  Why:
+    // a piece costs its issuer ~170 cycles of VMEM issue (stamps: 12 pieces = 2000 of the late group's 3100-cycle vector segment
+    // against 1100 for the early group's); halved, both groups' vector segments fit under the partner's matrix segment.
+#ifndef LR_ATT_SPLIT_DMA
+#define LR_ATT_SPLIT_DMA 0
+#endif
+    constexpr bool SPLIT_DMA = PP && PREC && LR_ATT_SPLIT_DMA;
+    auto issue = [&](int t, bool all = false) {            // tile t (keys kbeg + 64 t ..) -> slot t % NSLOT; all: the prologue's tiles
+        const bool both = all || !SPLIT_DMA;
+        if (both && NW > 4 && (wave >> 2) != DMAG) return;  // the DMA pieces are laid out for 256 threads
+        const bool doK = both || (wave >> 2) == 0, doV = both || (wave >> 2) == 1;
         const int slot = t % NSLOT;
         const int k0 = kbeg + t * KT;
         const unsigned dstK = __builtin_amdgcn_readfirstlane(lds_base + slot * NOPS * TILE + (wave & 3) * 1024);
-        int t256 = tid & 255;
-        asm volatile("" : "+v"(t256));
+        const unsigned short* bK = uni(Kp + (rowbase + k0) * p.ldq);
+        const unsigned short* bV = uni(Vp + (rowbase + k0) * p.ldq);
+        if (k0 + KT <= S) {
 #pragma unroll
-        for (int it = 0; it < NPO; ++it) {
-            const int q = it * 256 + t256;
-            const int r = q / CH, c = q - r * CH;
-            const int dkc = (HD == 96 ? (c ^ ((r >> 2) & 3)) : HD == 64 ? (c ^ ((r >> 1) & 7)) : (c ^ (r & 15))) * 8;
-            const int dvc = (HD == 96 ? c : HD == 64 ? (c ^ (((r >> 1) & 1) << 2)) : (c ^ ((r & 3) << 2))) * 8;
-            const size_t key = rowbase + min(k0 + r, S - 1);
-            const unsigned short* sk = Kp + key * p.ldq + dkc;
-            const unsigned short* sv = Vp + key * p.ldq + dvc;
-            const unsigned dk = dstK + it * 4096;
-            dma(sk, dk);
-            dma(sv, dk + TILE);
-            if constexpr (PREC) {
-                dma(sk + p.lo_off, dk + 2 * TILE);
-                dma(sv + p.lo_off, dk + 3 * TILE);
+            for (int it = 0; it < NPO; ++it) {
+                const unsigned dk = dstK + it * 4096;
+                if (doK) dma(bK, offK[it], dk);
+                if (doV) dma(bV, offV[it], dk + TILE);
+                if constexpr (PREC) {
+                    if (doK) dma(bK + p.lo_off, offK[it], dk + 2 * TILE);
+                    if (doV) dma(bV + p.lo_off, offV[it], dk + 3 * TILE);
+                }
+            }
+        } else {                          // the sequence ends inside this tile: rows clamped to its last key
+#pragma unroll
+            for (int it = 0; it < NPO; ++it) {
+                const int r = (it * 256 + (tid & 255)) / CH;
+                const unsigned back = (unsigned)(max(k0 + r - (S - 1), 0) * p.ldq) * 2u;
+                const unsigned dk = dstK + it * 4096;
+                if (doK) dma(bK, offK[it] - back, dk);
+                if (doV) dma(bV, offV[it] - back, dk + TILE);
+                if constexpr (PREC) {
+                    if (doK) dma(bK + p.lo_off, offK[it] - back, dk + 2 * TILE);
+                    if (doV) dma(bV + p.lo_off, offV[it] - back, dk + 3 * TILE);
+                }
             }
         }
     };
 
     // ---- prologue: first two tiles in flight, then the key bitmask and the Q fragments ----
-    if (ntiles > 0) issue(0);
-    if (PD > 1 && ntiles > 1) issue(1);
+    if (ntiles > 0) issue(0, true);
+    if (PD > 1 && ntiles > 1) issue(1, true);
     {
         const int w0 = kbeg / KT, w1 = (kend + KT - 1) / KT;
         for (int w = w0 + wave; w < w1; w += NW) {
@@ -236,17 +287,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
         voff[d] = row * ROW + win * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
     }
 
-    if constexpr (PP) {
-        // Ping-pong schedule: waves w and w+4 share a SIMD and run half a tile apart, so that one is in its matrix segment
-        // [O += V(t) P(t) ; S(t+1) = K(t+1) Q] while the other is in its vector segment [softmax(t)]; the two workgroup
-        // barriers per tile are the hand-over points (the late group takes one extra barrier first, the early one at the end).
-        // Single pass: waves 0-3 (the early group) issue the DMA: tile t+2 goes out in their vector segment t into the slot of
-        // tile t-2 (4 slots: the late group reads V(t-1) during that very interval), and their counted wait for tile t+1
-        // precedes the barrier that opens both groups' S(t+1).
-        // Split operands (3 slots is all the LDS holds): waves 4-7 (the late group) issue tile t+2 in THEIR vector segment t,
-        // which starts after the barrier that ends the last read of tile t-1, and retire it at the end of their matrix
-        // segment t, one barrier before the early group's S(t+2); one tile period covers the latency.
-        const int grp = wave >> 2;
         f32x16 s[2];
         uint4 pf[4], pl[PREC ? 4 : 1];
         // Fragment reads run PIPE steps ahead of the MFMAs that consume them (round 5).  As compiled until then, every K / V
@@ -255,7 +295,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
         // reads" 1770).  The LDS array itself was 14 % busy: latency, not bandwidth.  The steps are written in issue order and the
         // order is pinned with scheduling groups (reads of step n + PIPE, then the MFMAs of step n); the waits are the compiler's
         // own counted lgkmcnt (LDS returns in order).  Same MFMAs in the same order per accumulator: bit-identical results.
-        constexpr int PIPE = PREC ? 2 : 4;               // steps ahead; a step = 3 MFMAs (split operands) or 1
+#ifndef LR_ATT_PIPE
+#define LR_ATT_PIPE 3
+#endif
+#ifndef LR_ATT_CVT_IN_PV
+#define LR_ATT_CVT_IN_PV 1
+#endif
+#ifndef LR_ATT_PRIO
+#define LR_ATT_PRIO 1                  // s_setprio of the ping-pong loop: 1 = the matrix segment goes first, 2 = the vector segment, 0 = none
+#endif
+        constexpr int PIPE = PREC ? LR_ATT_PIPE : 2 * LR_ATT_PIPE;   // steps ahead; a step = 3 MFMAs (split operands) or 1
         auto qk = [&](int t) {
             const char* sK = smem + (t % NSLOT) * NOPS * TILE;
             constexpr int NQ = 2 * KSTEPS;
@@ -288,6 +337,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
                 __builtin_amdgcn_sched_group_barrier(0x008, PREC ? 3 : 1, 0);
             }
         };
+        auto cvt_chunk = [&](int c) {          // keys 16 c .. 16 c + 15 of the tile: softmax weights in s -> MFMA operands pf / pl
+            const int kt = c >> 1, st = c & 1;
+            uint4& f = pf[c];
+            if constexpr (PREC) {
+                uint4& g = pl[c];
+                split2_unit<OT>(s[kt][8 * st + 0], s[kt][8 * st + 1], f.x, g.x);
+                split2_unit<OT>(s[kt][8 * st + 2], s[kt][8 * st + 3], f.y, g.y);
+                split2_unit<OT>(s[kt][8 * st + 4], s[kt][8 * st + 5], f.z, g.z);
+                split2_unit<OT>(s[kt][8 * st + 6], s[kt][8 * st + 7], f.w, g.w);
+            } else {
+                f.x = pack2_fast<OT>(s[kt][8 * st + 0], s[kt][8 * st + 1]);
+                f.y = pack2_fast<OT>(s[kt][8 * st + 2], s[kt][8 * st + 3]);
+                f.z = pack2_fast<OT>(s[kt][8 * st + 4], s[kt][8 * st + 5]);
+                f.w = pack2_fast<OT>(s[kt][8 * st + 6], s[kt][8 * st + 7]);
+            }
+        };
         auto soft = [&](int t) {
 #if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 1)      // diagnostic build (tools/dbg): no softmax arithmetic, results invalid
             for (int kt = 0; kt < 2; ++kt)
@@ -300,6 +365,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
             return;
 #endif
             const int k0 = kbeg + t * KT;
+#if !(defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 1024))       // diagnostic 1024: no key mask
             const unsigned blo = __builtin_amdgcn_readfirstlane(sBits[2 * (k0 / KT)]);
             const unsigned bhi = __builtin_amdgcn_readfirstlane(sBits[2 * (k0 / KT) + 1]);
             const bool need_causal = CAUSAL && (k0 + KT - 1 > q0);
@@ -315,6 +381,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
                         s[kt][r] = ok ? s[kt][r] : -INFINITY;
                     }
             }
+#endif
+#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 256)           // diagnostic 256: no row maximum, no rescale
+            const float m_new = m_run;
+#else
             float mx = s[0][0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
@@ -322,6 +392,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx * sc);
+#endif
             if (!__all(m_new == m_run)) {
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                 l_run *= alpha;
@@ -336,46 +407,47 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 128)           // diagnostic 128: no exp
+                    const float e = __builtin_fmaf(s[kt][r], sc, -m_run);
+#else
                     const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -m_run));
+#endif
                     s[kt][r] = e;
+#if !(defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 512))        // diagnostic 512: no row sum
                     rs += e;
+#endif
                 }
+#if !(defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 512))
             rs += __shfl_xor(rs, 32, 64);
+#endif
             l_run += rs;
+            // P -> operand type (hi, lo): chunk 0 here; chunks 1-3 inside the matrix segment, each under the MFMAs of the chunk before
+            // it (LR_ATT_CVT_IN_PV, round 5: with the matrix segments pipelined the VECTOR segments set the period -- 3000 cycles
+            // against 2550 -- and the matrix wave issues on 8 of every 32 cycles: the 20 conversions of a chunk ride there for free)
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    uint4& f = pf[2 * kt + st];
-                    if constexpr (PREC) {
-                        uint4& g = pl[2 * kt + st];
-                        split2_unit<OT>(s[kt][8 * st + 0], s[kt][8 * st + 1], f.x, g.x);
-                        split2_unit<OT>(s[kt][8 * st + 2], s[kt][8 * st + 3], f.y, g.y);
-                        split2_unit<OT>(s[kt][8 * st + 4], s[kt][8 * st + 5], f.z, g.z);
-                        split2_unit<OT>(s[kt][8 * st + 6], s[kt][8 * st + 7], f.w, g.w);
-                    } else {
-                        f.x = pack2_fast<OT>(s[kt][8 * st + 0], s[kt][8 * st + 1]);
-                        f.y = pack2_fast<OT>(s[kt][8 * st + 2], s[kt][8 * st + 3]);
-                        f.z = pack2_fast<OT>(s[kt][8 * st + 4], s[kt][8 * st + 5]);
-                        f.w = pack2_fast<OT>(s[kt][8 * st + 6], s[kt][8 * st + 7]);
-                    }
-                }
+            for (int c = 0; c < (LR_ATT_CVT_IN_PV ? 1 : 4); ++c) cvt_chunk(c);
         };
         auto pv = [&](int t) {
-            const char* sV = smem + (t % NSLOT) * NOPS * TILE + TILE;
+            // LDS addresses as 32-bit integers: one VALU add per d block and tile, every other term (key step, +8 rows, the residual
+            // tile) in the read's 16-bit offset field (through generic pointers the compiler spent two VALU operations per read: 96
+            // per tile in the segment that should issue nothing but reads and MFMAs)
+            const unsigned vslot = __builtin_amdgcn_readfirstlane(lds_base + (t % NSLOT) * NOPS * TILE + TILE);
             constexpr int NP = 4 * DT;                   // steps: (kt, st, d), d fastest
+            unsigned va[DT];
+#pragma unroll
+            for (int d = 0; d < DT; ++d) va[d] = vslot + voff[d];
             uint4 vf[NP], vl[PREC ? NP : 1];
-            auto trd = [&](const char* a) {
-                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
-                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 8 * ROW));
+            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+            auto trd = [&](unsigned a, int off) {
+                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(a + off));
+                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(a + off + 8 * ROW));
                 const uint2 x = __builtin_bit_cast(uint2, v0), y = __builtin_bit_cast(uint2, v1);
                 return make_uint4(x.x, x.y, y.x, y.y);
             };
             auto ld = [&](int n) {
                 const int kt = n / (2 * DT), st = (n / DT) & 1, d = n % DT;
-                const char* vb = sV + (kt * 32 + 16 * st) * ROW + voff[d];
-                vf[n] = trd(vb);
-                if constexpr (PREC) vl[n] = trd(vb + 2 * TILE);
+                vf[n] = trd(va[d], (kt * 32 + 16 * st) * ROW);
+                if constexpr (PREC) vl[n] = trd(va[d], (kt * 32 + 16 * st) * ROW + 2 * TILE);
             };
 #pragma unroll
             for (int n = 0; n < PIPE; ++n) ld(n);
@@ -384,6 +456,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
                 const int kt = n / (2 * DT), st = (n / DT) & 1, d = n % DT;
                 if (n + PIPE < NP) ld(n + PIPE);
                 o[d] = Op<OT>::mfma32(vf[n], pf[2 * kt + st], o[d]);
+                if (LR_ATT_CVT_IN_PV && d == 0 && n / DT + 1 < 4) cvt_chunk(n / DT + 1);
                 if constexpr (PREC) {
                     o[d] = Op<OT>::mfma32(vf[n], pl[2 * kt + st], o[d]);
                     o[d] = Op<OT>::mfma32(vl[n], pf[2 * kt + st], o[d]);
@@ -392,10 +465,23 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
             __builtin_amdgcn_sched_group_barrier(0x100, PIPE * (PREC ? 4 : 2), 0);
 #pragma unroll
             for (int n = 0; n < NP; ++n) {
+                // (the conversions of the next chunk are left to the scheduler: VALU groups between the MFMAs made it drop the whole
+                //  read pipeline)
                 if (n + PIPE < NP) __builtin_amdgcn_sched_group_barrier(0x100, PREC ? 4 : 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, PREC ? 3 : 1, 0);
             }
         };
+    if constexpr (PP) {
+        // Ping-pong schedule: waves w and w+4 share a SIMD and run half a tile apart, so that one is in its matrix segment
+        // [O += V(t) P(t) ; S(t+1) = K(t+1) Q] while the other is in its vector segment [softmax(t)]; the two workgroup
+        // barriers per tile are the hand-over points (the late group takes one extra barrier first, the early one at the end).
+        // Single pass: waves 0-3 (the early group) issue the DMA: tile t+2 goes out in their vector segment t into the slot of
+        // tile t-2 (4 slots: the late group reads V(t-1) during that very interval), and their counted wait for tile t+1
+        // precedes the barrier that opens both groups' S(t+1).
+        // Split operands (3 slots is all the LDS holds): waves 4-7 (the late group) issue tile t+2 in THEIR vector segment t,
+        // which starts after the barrier that ends the last read of tile t-1, and retire it at the end of their matrix
+        // segment t, one barrier before the early group's S(t+2); one tile period covers the latency.
+        const int grp = wave >> 2;
 #if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 16)           // diagnostic 16 (tools/dbg/attn_stamps.py): cycles per segment of the ping-pong loop, summed
         unsigned long long sg[5] = {0, 0, 0, 0, 0};        // over the tiles: vector, barrier 1, matrix, barrier 2, tiles; workgroup 0, behind O
         auto stamp = [&]() -> unsigned long long {
@@ -449,12 +535,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
                 bar();
                 const unsigned long long ts2 = stamp();
                 // ---- matrix segment ----
-                __builtin_amdgcn_s_setprio(1);            // the wave in its matrix segment goes first (2-4 % on every shape)
+                if (LR_ATT_PRIO == 1) __builtin_amdgcn_s_setprio(1);            // the wave in its matrix segment goes first (2-4 % on every shape)
+                if (LR_ATT_PRIO == 2) __builtin_amdgcn_s_setprio(0);
                 pv(t);
                 if (t + 1 < nact) qk(t + 1);
                 else asm volatile("" : "=v"(s[0]), "=v"(s[1]));       // (S is dead: no value is carried round the loop on this path)
-                __builtin_amdgcn_s_setprio(0);
-                if (PREC && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (LR_ATT_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+                if (LR_ATT_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+                if (PREC && (grp == 1 || SPLIT_DMA)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const unsigned long long ts3 = stamp();
                 if (t + 1 < ntiles || grp == 0) bar();
                 const unsigned long long ts4 = stamp();
@@ -465,7 +553,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
                 vec_dma(t);
                 vec_wait(t);
                 bar();
-                if (PREC && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (PREC && (grp == 1 || SPLIT_DMA)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (t + 1 < ntiles || grp == 0) bar();
             }
         }
@@ -488,115 +576,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();                                  // tile t landed for every wave (and sBits on the first pass)
-        const char* sK = smem + (t % NSLOT) * NOPS * TILE;
-        const char* sV = sK + TILE;
-
         // waves whose 32 queries all precede this tile have nothing to do (diagonal workgroup tiles); nor have waves whose queries
         // all lie beyond the sequence (577 tokens = 4.5 x 128 queries: the last workgroup's fourth wave).
         // (Skipping the 32-key score halves / 16-key PV steps of a last key tile that holds no key -- 577 = 9 x 64 + 1 -- was built
         //  and measured level: the branches cost what the skipped MFMAs save.)
         const bool active = (!CAUSAL || (k0 <= q0 + 31)) && q0 < S;
         if (active) {
-            // ---- S^T tiles: keys kt*32 + [(r&3) + 8(r>>2) + 4h], query lc ----
-            f32x16 s[2];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < KSTEPS; ++ks) {
-                    const uint4 kf = *(const uint4*)(sK + koff_of(kt, ks));
-                    s[kt] = Op<OT>::mfma32(kf, qf[ks], s[kt]);
-                    if constexpr (PREC) {
-                        s[kt] = Op<OT>::mfma32(kf, qfl[ks], s[kt]);
-                        const uint4 kl = *(const uint4*)(sK + 2 * TILE + koff_of(kt, ks));
-                        s[kt] = Op<OT>::mfma32(kl, qf[ks], s[kt]);
-                    }
-                }
-            }
-            // ---- masks only where a tile needs them (wave-uniform) ----
-            const unsigned blo = __builtin_amdgcn_readfirstlane(sBits[2 * (k0 / KT)]);
-            const unsigned bhi = __builtin_amdgcn_readfirstlane(sBits[2 * (k0 / KT) + 1]);
-            const bool need_causal = CAUSAL && (k0 + KT - 1 > q0);
-            if (need_causal || (blo & bhi) != 0xFFFFFFFFu) {
-                const unsigned wl = blo >> (4 * lh), wh = bhi >> (4 * lh);
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int kb = (r & 3) + 8 * (r >> 2);            // + 4*lh = key index inside the 32-key sub-tile
-                        bool ok = (((kt ? wh : wl) >> kb) & 1u) != 0;
-                        if (CAUSAL) ok = ok && (k0 + kt * 32 + kb + 4 * lh <= qpos);
-                        s[kt][r] = ok ? s[kt][r] : -INFINITY;
-                    }
-            }
-            // ---- online softmax in log2 units; this lane's query is lc ----
-            float mx = s[0][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx * sc);
-            if (!__all(m_new == m_run)) {          // some row maximum moved: rescale (alpha == 1 on unchanged rows)
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                l_run *= alpha;
-                m_run = m_new;
-#pragma unroll
-                for (int d = 0; d < DT; ++d)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-            }
-            float rs = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -m_run));
-                    s[kt][r] = e;
-                    rs += e;
-                }
-            rs += __shfl_xor(rs, 32, 64);
-            l_run += rs;
-
-            // ---- O^T += V^T P^T ----
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    uint4 pf, pl;
-                    if constexpr (PREC) {
-                        split2_unit<OT>(s[kt][8 * st + 0], s[kt][8 * st + 1], pf.x, pl.x);
-                        split2_unit<OT>(s[kt][8 * st + 2], s[kt][8 * st + 3], pf.y, pl.y);
-                        split2_unit<OT>(s[kt][8 * st + 4], s[kt][8 * st + 5], pf.z, pl.z);
-                        split2_unit<OT>(s[kt][8 * st + 6], s[kt][8 * st + 7], pf.w, pl.w);
-                    } else {
-                        pf.x = pack2_fast<OT>(s[kt][8 * st + 0], s[kt][8 * st + 1]);
-                        pf.y = pack2_fast<OT>(s[kt][8 * st + 2], s[kt][8 * st + 3]);
-                        pf.z = pack2_fast<OT>(s[kt][8 * st + 4], s[kt][8 * st + 5]);
-                        pf.w = pack2_fast<OT>(s[kt][8 * st + 6], s[kt][8 * st + 7]);
-                    }
-#pragma unroll
-                    for (int d = 0; d < DT; ++d) {
-                        // keys kt*32 + 16*st + 4h + {0..3} and +8, d columns d*32 + (lane&31)
-                        const char* vb = sV + (kt * 32 + 16 * st) * ROW + voff[d];
-                        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb));
-                        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * ROW));
-                        uint4 vf;
-                        const uint2 a = __builtin_bit_cast(uint2, v0), c = __builtin_bit_cast(uint2, v1);
-                        vf.x = a.x; vf.y = a.y; vf.z = c.x; vf.w = c.y;
-                        o[d] = Op<OT>::mfma32(vf, pf, o[d]);
-                        if constexpr (PREC) {
-                            o[d] = Op<OT>::mfma32(vf, pl, o[d]);
-                            const s16x4 w0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 2 * TILE));
-                            const s16x4 w1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 2 * TILE + 8 * ROW));
-                            uint4 vl;
-                            const uint2 a2 = __builtin_bit_cast(uint2, w0), c2 = __builtin_bit_cast(uint2, w1);
-                            vl.x = a2.x; vl.y = a2.y; vl.z = c2.x; vl.w = c2.y;
-                            o[d] = Op<OT>::mfma32(vl, pf, o[d]);
-                        }
-                    }
-                }
+            qk(t);            // S^T tiles: keys kt*32 + [(r&3) + 8(r>>2) + 4h], query lc
+            soft(t);          // masks where the tile needs them, online softmax in log2 units, P -> operand type (chunk 0)
+            pv(t);            // O^T += V^T P^T (chunks 1-3 converted under the MFMAs)
         }
         __syncthreads();                                  // every wave is done with slot t%3 before tile t+3 is issued into it
     }
