@@ -76,8 +76,8 @@ class RewardModel:
         # operand_form="<name of a _form_candidates entry>" (load_reward_adaptor: args.operand_form) PINS the form: no probe, the same
         # form on every deployment of the checkpoint whatever the engine's capacity (the probe rows depend on max_crops / max_seq).
         self.pinned_form = operand_form
-        if operand_form is not None and operand_form not in dict(self._form_candidates()):
-            raise ValueError(f"operand_form={operand_form!r}: not one of {[n for n, _ in self._form_candidates()]}")
+        if operand_form is not None and operand_form not in dict(self._form_candidates() + self._pinnable_forms()):
+            raise ValueError(f"operand_form={operand_form!r}: not one of {[n for n, _ in self._form_candidates() + self._pinnable_forms()]}")
         # "eager": the reference's exceptions for rows whose image-slot count does not match their image_sizes, raised by this call
         # (host tensors are counted on the host; DEVICE input_ids cost a stream drain per forward).  "deferred": no host-side check
         # and no synchronisation -- the engine itself marks such a row's reward NaN (slot_check_kernel), visible at the caller's next
@@ -140,18 +140,7 @@ class RewardModel:
         decoder strict 8.7e-5 -- noise injected early is what the depth amplifies; the LAST decoder layers never matter
         (decoder 16..31 strict alone: 2.2e-3) -- so the candidates grow from the front of the model."""
         L = int(self.config.layers)
-        # Cheaper than default, tried first (round 5): single-pass operands in the LAST decoder layers, where rounding is amplified
-        # least ("the last layers never matter" above).  Measured on 8 benign full-size Phi-3.5-V rows (tools/prec_map_probe.py 8 0
-        # ladder, distance to the strict form, max): default 6.5e-5; last 2 layers single 1.0e-4 (-0.6 % step time), last 4 1.3e-4
-        # (-2.2 %), last 8 1.5e-4 (-5.4 %); on the outlier-bearing set the tail is immaterial beside the front (default 2.2e-3) and
-        # the ladder below takes over.  The only lever that removes MFMA work from a power-limited chip; locked only when the probe
-        # rows sit inside the same budget as every other form.
-        out = []
-        for den in (4, 8, 16):
-            k = L // den
-            if 2 <= k < L:
-                out.append((f"default+single-tail/{den}", (-1, 0, L - k, 0)))
-        out += [("default", (-1, -1, 0, 0)), ("strict-vision", (1, -1, 0, 0))]
+        out = [("default", (-1, -1, 0, 0)), ("strict-vision", (1, -1, 0, 0))]
         seen = set()
         for num, den, tag in ((1, 8, "/8"), (1, 4, "/4"), (3, 8, "*3/8"), (1, 2, "/2")):
             k = (L * num) // den
@@ -161,10 +150,22 @@ class RewardModel:
         out.append(("strict", (1, 1, 0, 0)))
         return out
 
+    def _pinnable_forms(self):
+        """Forms that can be PINNED (operand_form="<name>") but are never locked by the probe: single-pass operands in the LAST decoder
+        layers on top of the default form -- the only lever that removes MFMA work from a power-limited chip.  Measured (round 5,
+        tools/prec_map_probe.py 8 0 ladder, 8 benign full-size Phi-3.5-V rows, max distance to the strict form): default 6.5e-5; last 2
+        layers single 1.0e-4 (-0.6 % step time), last 4 1.3e-4 (-2.2 %), last 8 1.5e-4 (-5.4 %) -- the last layers amplify rounding
+        least, but 11-bit operands there still cost as much as the whole default form does everywhere.  Tried as probe candidates
+        (cheapest first) on 26 full-size goldens: the locked form became a lottery at the budget's edge (tails passed on some benign
+        seeds at 0.9-1.5e-4 and failed on others at 1.7-4e-4; one LLaVA golden landed 2.5e-4 from the reference, against 9.4e-5 in
+        the default form), so they stay opt-in."""
+        L = int(self.config.layers)
+        return [(f"default+single-tail/{den}", (-1, 0, L - L // den, 0)) for den in (4, 8, 16) if 2 <= L // den < L]
+
     def _apply_form(self) -> None:
         if self.engine is None or self._opts["operand_dtype"] != "f16x2f8":
             return
-        self.engine.set_precision_map(*dict(self._form_candidates())[self.operand_form])
+        self.engine.set_precision_map(*dict(self._form_candidates() + self._pinnable_forms())[self.operand_form])
 
     def _compare_forms(self, batches, budget: float, source: str) -> Dict[str, object]:
         """Score `batches` in the strict form (the yardstick: 16-bit residual passes everywhere) and in the cheaper forms of

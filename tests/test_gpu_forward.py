@@ -174,11 +174,15 @@ def test_operand_form_pin_failed_probe_and_deferred_input_check(monkeypatch):
     seed = 23
     batch = synth.synth_batch(cfg, seed, [7, 3, 5], (1, 1))
     names = [n for n, _ in RewardModel(cfg, synth_seed=seed)._form_candidates()]
-    i0 = names.index("default")          # (cheaper single-pass-tail candidates come first where the decoder is deep enough)
-    assert names[i0 + 1] == "strict-vision" and names[-1] == "strict" and len(set(names)) == len(names) >= 5
-    assert all(n.startswith("default+single-tail/") for n in names[:i0])
-    full = [n for n, _ in RewardModel(synth.full_config(), synth_seed=seed)._form_candidates()]
-    assert full[:4] == ["default+single-tail/4", "default+single-tail/8", "default+single-tail/16", "default"] and full[-1] == "strict"
+    i0 = names.index("default")
+    assert i0 == 0 and names[1] == "strict-vision" and names[-1] == "strict" and len(set(names)) == len(names) >= 5
+    mf = RewardModel(synth.full_config(), synth_seed=seed)
+    full = [n for n, _ in mf._form_candidates()]
+    assert full == ["default", "strict-vision", "strict-vision+decoder/8", "strict-vision+decoder/4", "strict-vision+decoder*3/8",
+                    "strict-vision+decoder/2", "strict"]
+    # single-pass tails: pinnable by name, never probe candidates (a lottery at the budget's edge)
+    assert [n for n, _ in mf._pinnable_forms()] == ["default+single-tail/4", "default+single-tail/8", "default+single-tail/16"]
+    assert RewardModel(synth.full_config(), synth_seed=seed, operand_form="default+single-tail/8").pinned_form == "default+single-tail/8"
     with pytest.raises(ValueError):
         RewardModel(cfg, synth_seed=seed, operand_form="nope")
     strict = _fwd(_model(cfg, seed, "f16x2", upload=False), batch)

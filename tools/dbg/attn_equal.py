@@ -8,7 +8,8 @@ sys.path.insert(0, os.path.join(ROOT, "llava-reward_amd"))
 import torch
 from llava_reward_amd import _lib as L
 
-libs = [(os.path.basename(a), L.load(a)) for a in sys.argv[1:]] + [("product 3-D grid", L.load()), ("product no shift", L.load()), ("product", L.load())]
+libs = [(os.path.basename(a), L.load(a)) for a in sys.argv[1:]] + [("product 3-D grid", L.load()), ("product no shift", L.load()), ("product plain loop", L.load()), ("product", L.load())]
+ENV = {"product 3-D grid": ("LR_ATT_XCD_ORDER", "0"), "product no shift": ("LR_ATT_QSHIFT", "0"), "product plain loop": ("LR_ATT_PINGPONG", "0")}
 P = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
 
 
@@ -32,13 +33,11 @@ def case(name, B, S, H, hd, causal, Hkv=None, pads=None, reps=5):
                 1.0 / math.sqrt(hd), L.LR_DT_F16, C.c_void_p(st.cuda_stream))
     for n, lib in libs:
         out = torch.zeros(B * S, 2 * H * hd, device="cuda", dtype=torch.float16)
-        if n == "product 3-D grid":
-            os.environ["LR_ATT_XCD_ORDER"] = "0"
-        if n == "product no shift":
-            os.environ["LR_ATT_QSHIFT"] = "0"
+        if n in ENV:
+            os.environ[ENV[n][0]] = ENV[n][1]
         assert lib.lr_op_attention_split(*args_for(out)) == 0
-        os.environ.pop("LR_ATT_XCD_ORDER", None)
-        os.environ.pop("LR_ATT_QSHIFT", None)
+        for k, _ in ENV.values():
+            os.environ.pop(k, None)
         torch.cuda.synchronize()
         outs.append(out)
     inner = max(1, int(20.0 / max(0.05, 1e-9 * B * H * S * S * hd / 50)))          # ~20 ms of launches per sample
@@ -46,16 +45,14 @@ def case(name, B, S, H, hd, causal, Hkv=None, pads=None, reps=5):
         for i in ([*range(len(libs))] if r % 2 == 0 else [*range(len(libs))][::-1]):
             a = args_for(outs[i])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            if libs[i][0] == "product 3-D grid":
-                os.environ["LR_ATT_XCD_ORDER"] = "0"
-            if libs[i][0] == "product no shift":
-                os.environ["LR_ATT_QSHIFT"] = "0"
+            if libs[i][0] in ENV:
+                os.environ[ENV[libs[i][0]][0]] = ENV[libs[i][0]][1]
             e0.record(st)
             for _ in range(inner):
                 libs[i][1].lr_op_attention_split(*a)
             e1.record(st)
-            os.environ.pop("LR_ATT_XCD_ORDER", None)
-            os.environ.pop("LR_ATT_QSHIFT", None)
+            for k, _ in ENV.values():
+                os.environ.pop(k, None)
             torch.cuda.synchronize()
             t[i] += e0.elapsed_time(e1) / inner / reps
     valid = torch.ones(B * S, dtype=torch.bool, device="cuda")
