@@ -59,10 +59,7 @@ template <typename OT> __device__ __forceinline__ void split2_unit(float a, floa
 // 16 vector instructions fewer per 64-key tile and wave.  hipcc does not form it from the source above.
 template <> __device__ __forceinline__ void split2_unit<F16>(float a, float b, unsigned& hi, unsigned& lo) {
     hi = pack2_fast<F16>(a, b);
-    float ra, rb;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hi), "v"(a));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hi), "v"(b));
-    lo = pack2_fast<F16>(ra, rb);
+    lo = pack2_fast<F16>(sub_f16_lo_half(a, hi), sub_f16_hi_half(b, hi));
 }
 
 constexpr int ATT_MAX_S = 8192;        // keys covered by the LDS bitmask

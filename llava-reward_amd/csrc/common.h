@@ -105,6 +105,23 @@ template <typename OT> __device__ __forceinline__ void split2p(float a, float b,
     hi = round_pair<OT>(a, b);
     lo = round_pair<OT>(a - Op<OT>::to_f32((unsigned short)(hi & 0xFFFFu)), b - Op<OT>::to_f32((unsigned short)(hi >> 16)));
 }
+#if defined(__HIPCC__)
+// a - float(h) for the low / high f16 half h of `packed`, as ONE v_fma_mix_f32 (fma(float(h), -1, a): the widening rides in the
+// instruction and the product is exact, so this IS the subtraction's correctly rounded value, bit for bit) instead of a conversion
+// and a subtraction.  hipcc does not form it from the plain expression.  The attention kernels' P split uses it (round 5).
+__device__ __forceinline__ float sub_f16_lo_half(float a, unsigned packed) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(a));
+    return r;
+}
+__device__ __forceinline__ float sub_f16_hi_half(float a, unsigned packed) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(a));
+    return r;
+}
+// (Tried in the GEMM epilogues too -- split2p / store_hi_lo8 -- and measured level on every shape, +-0.3 %: their read + store loops
+//  are not bound by the vector-instruction count.  Only the attention kernels use it.)
+#endif
 
 // x * sigmoid(a*x) with the hardware exp2/rcp (1 ulp each; the result is rounded to a 16-bit operand anyway)
 __device__ __forceinline__ float x_sigmoid_fast(float x, float a) {
