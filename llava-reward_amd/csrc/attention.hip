@@ -28,6 +28,7 @@
 //   V (tr reads, 4 rows x 64 B per half-wave):  HD 96: none (192-B rows);     HD 64: chunk ^ (((row>>1)&1)<<2);  HD 128: chunk ^ ((row&3)<<2)
 // Softmax diet: masks only on tiles that need them (wave-uniform), raw v_exp_f32 on log2-domain
 // scores, packed conversions, O rescale only when a row maximum moved, dead diagonal sub-tiles skipped.
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -298,42 +299,20 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
 #ifndef LR_ATT_CVT_IN_PV
 #define LR_ATT_CVT_IN_PV 1
 #endif
+#ifndef LR_ATT_FUSE
+#define LR_ATT_FUSE 0                  // PV(t) and QK(t + 1) of a ping-pong matrix segment as ONE pipeline of fragment reads
+#endif
+#ifndef LR_ATT_LAZY
+#define LR_ATT_LAZY 1                  // 1: the running maximum moves only when a row's new maximum exceeds it by 2^8 (bits change)
+#endif
 #ifndef LR_ATT_PRIO
 #define LR_ATT_PRIO 1                  // s_setprio of the ping-pong loop: 1 = the matrix segment goes first, 2 = the vector segment, 0 = none
 #endif
         constexpr int PIPE = PREC ? LR_ATT_PIPE : 2 * LR_ATT_PIPE;   // steps ahead; a step = 3 MFMAs (split operands) or 1
-        auto qk = [&](int t) {
-            const char* sK = smem + (t % NSLOT) * NOPS * TILE;
-            constexpr int NQ = 2 * KSTEPS;
-            uint4 kf[NQ], kl[PREC ? NQ : 1];
-            auto ld = [&](int n) {
-                const int kt = n / KSTEPS, ks = n % KSTEPS;
-                kf[n] = *(const uint4*)(sK + koff_of(kt, ks));
-                if constexpr (PREC) kl[n] = *(const uint4*)(sK + 2 * TILE + koff_of(kt, ks));
-            };
-#pragma unroll
-            for (int n = 0; n < PIPE; ++n) ld(n);
-#pragma unroll
-            for (int n = 0; n < NQ; ++n) {
-                const int kt = n / KSTEPS, ks = n % KSTEPS;
-                if (n + PIPE < NQ) ld(n + PIPE);
-                if (ks == 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-                }
-                s[kt] = Op<OT>::mfma32(kf[n], qf[ks], s[kt]);
-                if constexpr (PREC) {
-                    s[kt] = Op<OT>::mfma32(kf[n], qfl[ks], s[kt]);
-                    s[kt] = Op<OT>::mfma32(kl[n], qf[ks], s[kt]);
-                }
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, PIPE * (PREC ? 2 : 1), 0);
-#pragma unroll
-            for (int n = 0; n < NQ; ++n) {
-                if (n + PIPE < NQ) __builtin_amdgcn_sched_group_barrier(0x100, PREC ? 2 : 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, PREC ? 3 : 1, 0);
-            }
-        };
+        // One software pipeline over the steps of PV(t) [if DO_PV] followed by QK(tq) [if DO_QK]: the fragment reads of step n + PIPE are
+        // issued in front of the MFMAs of step n, ACROSS the seam between the two contractions (LR_ATT_FUSE: the first K fragments of
+        // QK(t + 1) are requested under the last MFMAs of PV(t), instead of a second pipeline fill per matrix segment).
+        // Declared below cvt_chunk (it converts P chunks on the way); qk / pv are its two halves alone.
         auto cvt_chunk = [&](int c) {          // keys 16 c .. 16 c + 15 of the tile: softmax weights in s -> MFMA operands pf / pl
             const int kt = c >> 1, st = c & 1;
             uint4& f = pf[c];
@@ -388,7 +367,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#if LR_ATT_LAZY
+            // lazy reference maximum: a row's reference moves only when its new maximum exceeds it by more than 8 (log2 units), so the
+            // softmax weights of a tile are <= 2^8 instead of <= 1 (exact in the hi + lo operand pair and in the fp32 sums alike) and
+            // the rescale of the 16 DT output registers -- taken for SOME row of the wave in most tiles of random data -- becomes rare.
+            // Per query: a row's arithmetic does not depend on the other rows of its wave (alpha == 1 exactly where nothing moved).
+            const float mxs = mx * sc;
+            const float m_new = mxs > m_run + 8.f ? mxs : m_run;
+#else
             const float m_new = fmaxf(m_run, mx * sc);
+#endif
 #endif
             if (!__all(m_new == m_run)) {
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -424,16 +412,20 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
 #pragma unroll
             for (int c = 0; c < (LR_ATT_CVT_IN_PV ? 1 : 4); ++c) cvt_chunk(c);
         };
-        auto pv = [&](int t) {
+        auto mat = [&](int t, int tq, auto do_pv, auto do_qk) {
+            constexpr bool DO_PV = decltype(do_pv)::value, DO_QK = decltype(do_qk)::value;
             // LDS addresses as 32-bit integers: one VALU add per d block and tile, every other term (key step, +8 rows, the residual
             // tile) in the read's 16-bit offset field (through generic pointers the compiler spent two VALU operations per read: 96
             // per tile in the segment that should issue nothing but reads and MFMAs)
+            constexpr int NP = DO_PV ? 4 * DT : 0;       // PV steps: (kt, st, d), d fastest
+            constexpr int NQ = DO_QK ? 2 * KSTEPS : 0;   // QK steps: (kt, ks)
+            constexpr int NS = NP + NQ;
             const unsigned vslot = __builtin_amdgcn_readfirstlane(lds_base + (t % NSLOT) * NOPS * TILE + TILE);
-            constexpr int NP = 4 * DT;                   // steps: (kt, st, d), d fastest
+            const char* sK = smem + (tq % NSLOT) * NOPS * TILE;
             unsigned va[DT];
 #pragma unroll
             for (int d = 0; d < DT; ++d) va[d] = vslot + voff[d];
-            uint4 vf[NP], vl[PREC ? NP : 1];
+            uint4 fh[NS], fl[PREC ? NS : 1];             // hi / lo fragment of every step (SSA values: the allocator keeps PIPE + 1 alive)
             typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
             auto trd = [&](unsigned a, int off) {
                 const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(a + off));
@@ -442,31 +434,62 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
                 return make_uint4(x.x, x.y, y.x, y.y);
             };
             auto ld = [&](int n) {
-                const int kt = n / (2 * DT), st = (n / DT) & 1, d = n % DT;
-                vf[n] = trd(va[d], (kt * 32 + 16 * st) * ROW);
-                if constexpr (PREC) vl[n] = trd(va[d], (kt * 32 + 16 * st) * ROW + 2 * TILE);
+                if (n < NP) {
+                    const int kt = n / (2 * DT), st = (n / DT) & 1, d = n % DT;
+                    fh[n] = trd(va[d], (kt * 32 + 16 * st) * ROW);
+                    if constexpr (PREC) fl[n] = trd(va[d], (kt * 32 + 16 * st) * ROW + 2 * TILE);
+                } else {
+                    const int m = n - NP, kt = m / KSTEPS, ks = m % KSTEPS;
+                    fh[n] = *(const uint4*)(sK + koff_of(kt, ks));
+                    if constexpr (PREC) fl[n] = *(const uint4*)(sK + 2 * TILE + koff_of(kt, ks));
+                }
             };
 #pragma unroll
-            for (int n = 0; n < PIPE; ++n) ld(n);
+            for (int n = 0; n < PIPE && n < NS; ++n) ld(n);
 #pragma unroll
-            for (int n = 0; n < NP; ++n) {
-                const int kt = n / (2 * DT), st = (n / DT) & 1, d = n % DT;
-                if (n + PIPE < NP) ld(n + PIPE);
-                o[d] = Op<OT>::mfma32(vf[n], pf[2 * kt + st], o[d]);
-                if (LR_ATT_CVT_IN_PV && d == 0 && n / DT + 1 < 4) cvt_chunk(n / DT + 1);
-                if constexpr (PREC) {
-                    o[d] = Op<OT>::mfma32(vf[n], pl[2 * kt + st], o[d]);
-                    o[d] = Op<OT>::mfma32(vl[n], pf[2 * kt + st], o[d]);
+            for (int n = 0; n < NS; ++n) {
+                if (n + PIPE < NS) ld(n + PIPE);
+                if (n < NP) {
+                    const int kt = n / (2 * DT), st = (n / DT) & 1, d = n % DT;
+                    o[d] = Op<OT>::mfma32(fh[n], pf[2 * kt + st], o[d]);
+                    if (LR_ATT_CVT_IN_PV && d == 0 && n / DT + 1 < 4) cvt_chunk(n / DT + 1);
+                    if constexpr (PREC) {
+                        o[d] = Op<OT>::mfma32(fh[n], pl[2 * kt + st], o[d]);
+                        o[d] = Op<OT>::mfma32(fl[n], pf[2 * kt + st], o[d]);
+                    }
+                } else {
+                    const int m = n - NP, kt = m / KSTEPS, ks = m % KSTEPS;
+                    if (ks == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+                    }
+                    s[kt] = Op<OT>::mfma32(fh[n], qf[ks], s[kt]);
+                    if constexpr (PREC) {
+                        s[kt] = Op<OT>::mfma32(fh[n], qfl[ks], s[kt]);
+                        s[kt] = Op<OT>::mfma32(fl[n], qf[ks], s[kt]);
+                    }
                 }
             }
-            __builtin_amdgcn_sched_group_barrier(0x100, PIPE * (PREC ? 4 : 2), 0);
+            // the issue order above, pinned as scheduling groups (reads per step: PV 2 tr reads per fragment, QK one b128; x2 with
+            // split operands); the conversions of the next P chunk are left to the scheduler (VALU groups between the MFMAs made it drop
+            // the whole read pipeline); the waits are the compiler's own counted lgkmcnt
+            auto reads_of = [&](int n) {       // (the builtin wants literal counts: one call per case, folded once the loops are unrolled)
+                if (n < NP) __builtin_amdgcn_sched_group_barrier(0x100, PREC ? 4 : 2, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x100, PREC ? 2 : 1, 0);
+            };
 #pragma unroll
-            for (int n = 0; n < NP; ++n) {
-                // (the conversions of the next chunk are left to the scheduler: VALU groups between the MFMAs made it drop the whole
-                //  read pipeline)
-                if (n + PIPE < NP) __builtin_amdgcn_sched_group_barrier(0x100, PREC ? 4 : 2, 0);
+            for (int n = 0; n < PIPE && n < NS; ++n) reads_of(n);
+#pragma unroll
+            for (int n = 0; n < NS; ++n) {
+                if (n + PIPE < NS) reads_of(n + PIPE);
                 __builtin_amdgcn_sched_group_barrier(0x008, PREC ? 3 : 1, 0);
             }
+        };
+        auto qk = [&](int t) { mat(t, t, std::false_type{}, std::true_type{}); };
+        auto pv = [&](int t) { mat(t, t, std::true_type{}, std::false_type{}); };
+        auto pvqk = [&](int t) {                  // PV(t) then QK(t + 1)
+            if constexpr (LR_ATT_FUSE) mat(t, t + 1, std::true_type{}, std::true_type{});
+            else { pv(t); qk(t + 1); }
         };
     if constexpr (PP) {
         // Ping-pong schedule: waves w and w+4 share a SIMD and run half a tile apart, so that one is in its matrix segment
@@ -534,9 +557,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
                 // ---- matrix segment ----
                 if (LR_ATT_PRIO == 1) __builtin_amdgcn_s_setprio(1);            // the wave in its matrix segment goes first (2-4 % on every shape)
                 if (LR_ATT_PRIO == 2) __builtin_amdgcn_s_setprio(0);
-                pv(t);
-                if (t + 1 < nact) qk(t + 1);
-                else asm volatile("" : "=v"(s[0]), "=v"(s[1]));       // (S is dead: no value is carried round the loop on this path)
+                if (t + 1 < nact) pvqk(t);
+                else {
+                    pv(t);
+                    asm volatile("" : "=v"(s[0]), "=v"(s[1]));       // (S is dead: no value is carried round the loop on this path)
+                }
                 if (LR_ATT_PRIO == 1) __builtin_amdgcn_s_setprio(0);
                 if (LR_ATT_PRIO == 2) __builtin_amdgcn_s_setprio(1);
                 if (PREC && (grp == 1 || SPLIT_DMA)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

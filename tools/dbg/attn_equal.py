@@ -60,6 +60,12 @@ def case(name, B, S, H, hd, causal, Hkv=None, pads=None, reps=5):
         for b, p_ in enumerate(pads):
             valid[b * S: b * S + p_] = False          # rows of padding positions are never read by the path
     eq = all(torch.equal(outs[0][valid], o[valid]) for o in outs[1:])
+    tol = float(os.environ.get("ATTN_EQ_TOL", "0"))          # > 0: builds that change bits on purpose (e.g. -DLR_ATT_LAZY=1) -- max |diff| of the hi halves
+    if not eq and tol > 0:
+        Hh = H * hd
+        md = max(float((outs[0][valid][:, :Hh].float() - o[valid][:, :Hh].float()).abs().max()) for o in outs[1:])
+        print(f"  (not bit-identical: max |diff| of the hi halves = {md:.3e}, tolerance {tol:g})")
+        eq = md <= tol
     print(f"{name:24s} B={B} S={S} H={H} hd={hd}: bit-identical={eq}  " + "  ".join(f"{n} {x:7.3f} ms ({(x / t[0] - 1) * 100:+.1f} %)" for (n, _), x in zip(libs, t)), flush=True)
     assert eq, name
 
