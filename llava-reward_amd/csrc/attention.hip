@@ -368,12 +368,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
 #if LR_ATT_LAZY
-            // lazy reference maximum: a row's reference moves only when its new maximum exceeds it by more than 8 (log2 units), so the
+            // lazy reference maximum (split-operand forms only: the single-pass forms keep the exact maximum, bit for bit as before): a row's reference moves only when its new maximum exceeds it by more than 8 (log2 units), so the
             // softmax weights of a tile are <= 2^8 instead of <= 1 (exact in the hi + lo operand pair and in the fp32 sums alike) and
             // the rescale of the 16 DT output registers -- taken for SOME row of the wave in most tiles of random data -- becomes rare.
             // Per query: a row's arithmetic does not depend on the other rows of its wave (alpha == 1 exactly where nothing moved).
             const float mxs = mx * sc;
-            const float m_new = mxs > m_run + 8.f ? mxs : m_run;
+            const float m_new = PREC ? (mxs > m_run + 8.f ? mxs : m_run) : fmaxf(m_run, mxs);
 #else
             const float m_new = fmaxf(m_run, mx * sc);
 #endif
