@@ -305,6 +305,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
 #ifndef LR_ATT_LAZY
 #define LR_ATT_LAZY 1                  // 1: the running maximum moves only when a row's new maximum exceeds it by 2^8 (bits change)
 #endif
+#ifndef LR_ATT_LAZY_T
+#define LR_ATT_LAZY_T 8                // the lazy maximum's threshold, log2 units
+#endif
 #ifndef LR_ATT_PRIO
 #define LR_ATT_PRIO 1                  // s_setprio of the ping-pong loop: 1 = the matrix segment goes first, 2 = the vector segment, 0 = none
 #endif
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
             // the rescale of the 16 DT output registers -- taken for SOME row of the wave in most tiles of random data -- becomes rare.
             // Per query: a row's arithmetic does not depend on the other rows of its wave (alpha == 1 exactly where nothing moved).
             const float mxs = mx * sc;
-            const float m_new = PREC ? (mxs > m_run + 8.f ? mxs : m_run) : fmaxf(m_run, mxs);
+            const float m_new = PREC ? (mxs > m_run + (float)LR_ATT_LAZY_T ? mxs : m_run) : fmaxf(m_run, mxs);
 #else
             const float m_new = fmaxf(m_run, mx * sc);
 #endif
