@@ -437,6 +437,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
                 return make_uint4(x.x, x.y, y.x, y.y);
             };
             auto ld = [&](int n) {
+#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 2)      // diagnostic 2: no LDS fragment reads (register stand-ins), results invalid
+                fh[n] = qf[n % KSTEPS];
+                if constexpr (PREC) fl[n] = qfl[n % KSTEPS];
+                return;
+#endif
                 if (n < NP) {
                     const int kt = n / (2 * DT), st = (n / DT) & 1, d = n % DT;
                     fh[n] = trd(va[d], (kt * 32 + 16 * st) * ROW);
