@@ -429,9 +429,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
 #pragma unroll
             for (int d = 0; d < DT; ++d) va[d] = vslot + voff[d];
             uint4 fh[NS], fl[PREC ? NS : 1];             // hi / lo fragment of every step (SSA values: the allocator keeps PIPE + 1 alive)
-#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 32)
-            uint4 sink = make_uint4(0, 0, 0, 0);
-#endif
             typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
             auto trd = [&](unsigned a, int off) {
                 const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(a + off));
@@ -444,24 +441,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
                 fh[n] = qf[n % KSTEPS];
                 if constexpr (PREC) fl[n] = qfl[n % KSTEPS];
                 return;
-#endif
-#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 32)     // diagnostic 32: the reads are ISSUED (and retired) but the MFMAs take register stand-ins:
-                {                                  // what the read traffic costs apart from the MFMAs' waiting for it; results invalid
-                    uint4 d0, d1;
-                    if (n < NP) {
-                        const int kt = n / (2 * DT), st = (n / DT) & 1, d = n % DT;
-                        d0 = trd(va[d], (kt * 32 + 16 * st) * ROW);
-                        d1 = PREC ? trd(va[d], (kt * 32 + 16 * st) * ROW + 2 * TILE) : d0;
-                    } else {
-                        const int m = n - NP, kt = m / KSTEPS, ks = m % KSTEPS;
-                        d0 = *(const uint4*)(sK + koff_of(kt, ks));
-                        d1 = PREC ? *(const uint4*)(sK + 2 * TILE + koff_of(kt, ks)) : d0;
-                    }
-                    sink.x ^= d0.x ^ d1.x; sink.y ^= d0.y ^ d1.y; sink.z ^= d0.z ^ d1.z; sink.w ^= d0.w ^ d1.w;
-                    fh[n] = qf[n % KSTEPS];
-                    if constexpr (PREC) fl[n] = qfl[n % KSTEPS];
-                    return;
-                }
 #endif
                 if (n < NP) {
                     const int kt = n / (2 * DT), st = (n / DT) & 1, d = n % DT;
@@ -513,9 +492,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
                 if (n + PIPE < NS) reads_of(n + PIPE);
                 __builtin_amdgcn_sched_group_barrier(0x008, PREC ? 3 : 1, 0);
             }
-#if defined(LR_ATT_DIAG) && (LR_ATT_DIAG & 32)
-            asm volatile("" :: "v"(sink.x), "v"(sink.y), "v"(sink.z), "v"(sink.w));
-#endif
         };
         auto qk = [&](int t) { mat(t, t, std::false_type{}, std::true_type{}); };
         auto pv = [&](int t) { mat(t, t, std::true_type{}, std::false_type{}); };
