@@ -4,10 +4,11 @@
 
 Weights live on the host until `.to('cuda')`, which creates the HIP engine on that GPU (the
 reference's `load_reward_adaptor` also returns a CPU model that the caller moves).
-Deviations, on purpose: rewards come back in fp32 (the reference returns the model dtype, bf16;
-SURVEY.md §7 shows bf16 rounding alone costs up to 2e-3); `outputs` for return_output=True holds
-`last_hidden_state` (what the reference's callers read) and the hidden row behind the reward, not the
-33 per-layer hidden states the backbone's output object carries."""
+Deviations, on purpose: rewards come back in fp32 unless reward_dtype says otherwise (the reference
+returns the model dtype, bf16; SURVEY.md §7 shows bf16 rounding alone costs up to 2e-3); `outputs` for
+return_output=True holds `last_hidden_state` (what the reference's callers read), the hidden row behind
+the reward, and `hidden_states` as a tuple-like that recomputes a layer's tensor when it is asked for
+(the backbone's output object carries all 33 at once)."""
 from __future__ import annotations
 
 from typing import Dict, Optional
@@ -35,8 +36,46 @@ class _Outputs(dict):
                            "hidden_states[layer_id], rw_model_general_preference.py:349-352), so the final norm of the full stack was never "
                            "computed; read outputs['hidden_states_at_layer_id'], or build the model with layer_id=32")
         if key == "hidden_states":
-            raise KeyError("hidden_states: the per-layer tuple is not materialised (33 x [B, S, hidden]); use layer_id=<k> for one of them")
+            raise KeyError("hidden_states: the per-layer tuple is served on demand for the phi3v / llava branches with layer_id == 32 only "
+                           "(_LazyHiddenStates); here use layer_id=<k> for one of them")
         raise KeyError(key)
+
+
+class _LazyHiddenStates:
+    """`outputs["hidden_states"]` of the reference's backbone output (`output_hidden_states=True`, rw_model_general_preference.py:346-352,
+    :372-375): a tuple of layers + 1 tensors [B, S, hidden] -- element 0 the embeddings (image rows scattered in), element k the residual
+    stream entering decoder layer k, the last element the final norm's output (the same tensor as `last_hidden_state`).  The engine keeps
+    ONE residual stream, so element k is recomputed when it is asked for: the same forward stopped after k layers (lr_set_layer_limits +
+    LR_FWD_NO_FINAL_NORM, the mechanism behind `layer_id`), fp32 on the device.  Holds references to the forward's input tensors; valid
+    while the model's weights are unchanged.  len(), indexing (negative too) and iteration work as on the tuple."""
+
+    def __init__(self, model, args, shape):
+        self._m, self._args, self._shape = model, args, (int(shape[0]), int(shape[1]))
+        self._n = int(model.config.layers)
+
+    def __len__(self):
+        return self._n + 1
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return tuple(self[i] for i in range(*k.indices(len(self))))
+        k = int(k)
+        if k < 0:
+            k += len(self)
+        if not 0 <= k <= self._n:
+            raise IndexError("tuple index out of range")
+        m, (B, S) = self._m, self._shape
+        ids, mask, pix, sz = self._args
+        last = k == self._n
+        m.engine.set_layer_limits(-1, -1 if last else k)
+        try:
+            m.engine.forward(ids, mask, pix, sz, training=False, no_final_norm=not last, keep_hidden_states=True)
+            return m.engine.last_hidden_state(B, S, no_final_norm=not last)
+        finally:
+            m.engine.set_layer_limits(-1, -1)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
 
 
 class RewardModel:
@@ -44,7 +83,7 @@ class RewardModel:
                  max_batch: int = 32, max_seq: int = 2816, max_crops: int = 17, operand_dtype: str = "f16x2f8",
                  layer_id: int = 32, mean_hidden_state=None, max_patches: int = 0, synth_profile: int = 0,
                  calibrate: bool = True, parity_budget: float = 1.5e-4, operand_form: Optional[str] = None,
-                 check_inputs: str = "eager"):
+                 check_inputs: str = "eager", reward_dtype: Optional[torch.dtype] = None):
         if weights is None and synth_seed is None:
             raise ValueError("RewardModel needs weights or a synth_seed")
         # rw_model:349-352: layer_id == 32 (the literal) -> last_hidden_state, else hidden_states[layer_id] = the input of decoder
@@ -85,6 +124,9 @@ class RewardModel:
         if check_inputs not in ("eager", "deferred"):
             raise ValueError("check_inputs must be 'eager' or 'deferred'")
         self.check_inputs = check_inputs
+        # None (default): rewards come back in fp32 (module docstring).  torch.bfloat16: rounded to the dtype the reference's GPU path
+        # returns (its model dtype, rw_model:420-444) -- for callers that compare dtypes or concatenate with the reference's outputs.
+        self.reward_dtype = reward_dtype
         self._in_probe = False
         self.training = False
         self.device = torch.device("cpu")
@@ -317,9 +359,10 @@ class RewardModel:
         self.engine.set_layer_limits(-1, self.layer_id if inner else -1)
         reward = self.engine.forward(input_ids, attention_mask, pixel_values, sz, training=self.training, no_final_norm=inner,
                                      keep_hidden_states=return_output or self.keep_hidden_states)
-        return self._finish(reward, input_ids.shape, return_output, inner)
+        return self._finish(reward, input_ids.shape, return_output, inner,
+                            lazy_args=(input_ids, attention_mask, pixel_values, sz) if return_output and not inner else None)
 
-    def _finish(self, reward, shape, return_output, inner=False):
+    def _finish(self, reward, shape, return_output, inner=False, lazy_args=None):
         """Return convention of rw_model:407-448.  Train mode without mean pooling reads the LAST position (left-padded batches) and
         the BT head then returns [B] (`values.squeeze(-1)[:, -1]`, :413-415) where eval returns [B, 1] (:420-421); GPM returns
         [B, d] in both (:434, :439-444).  `outputs` (return_output=True, :422-425): the reference hands back the backbone's whole
@@ -328,6 +371,8 @@ class RewardModel:
         the reward was read from."""
         if self.training and not self.is_general_preference and not self.mean_hidden_state:
             reward = reward.squeeze(-1)
+        if self.reward_dtype is not None:
+            reward = reward.to(self.reward_dtype)
         if not return_output:
             return reward, None
         B, S = int(shape[0]), int(shape[1])
@@ -340,8 +385,11 @@ class RewardModel:
             # hidden_states[layer_id] (rw_model:351-352), comes back under its own name
             return reward, _Outputs({"hidden_states_at_layer_id": self.engine.last_hidden_state(B, S, no_final_norm=True),
                                      "last_hidden_state_at_reward_token": hl})
-        return reward, _Outputs({"last_hidden_state": self.engine.last_hidden_state(B, S, no_final_norm=False),
-                                 "last_hidden_state_at_reward_token": hl})
+        out = _Outputs({"last_hidden_state": self.engine.last_hidden_state(B, S, no_final_norm=False),
+                        "last_hidden_state_at_reward_token": hl})
+        if lazy_args is not None:
+            out["hidden_states"] = _LazyHiddenStates(self, lazy_args, shape)
+        return reward, out
 
     def _custom_forward_qwen(self, inputs_batch, return_output):
         """rw_model_general_preference.py:354-371: the qwen branch reads everything from `inputs_batch` (the

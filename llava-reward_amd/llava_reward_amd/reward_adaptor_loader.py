@@ -35,8 +35,11 @@ def _attach_adapter(args, cfg, weights, spec_fn, canon=None):
 def _form_args(args):
     """Knobs the reference does not have: args.operand_form = "<name>" pins the operand form of the default parity
     mode across deployments (no probe); args.check_inputs = "deferred" drops the per-forward host check of device-resident inputs."""
+    rd = getattr(args, "reward_dtype", None)
+    if isinstance(rd, str):
+        rd = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": None, "float32": None, "fp16": torch.float16}[rd]
     return dict(operand_form=getattr(args, "operand_form", None), check_inputs=getattr(args, "check_inputs", "eager"),
-                parity_budget=getattr(args, "parity_budget", 1.5e-4))
+                parity_budget=getattr(args, "parity_budget", 1.5e-4), reward_dtype=rd)
 
 
 def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=False):

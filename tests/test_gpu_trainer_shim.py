@@ -153,3 +153,43 @@ def test_score_candidates_in_memory_images():
     assert torch.equal(score_candidates(m, tok, prompt, cands, num_crops=4, pad_token_id=pad), got) and m.training
     with pytest.raises(ValueError):
         score_candidates(m, tok, [prompt] * 4, cands, num_crops=4, pad_token_id=pad)
+
+
+def test_outputs_hidden_states_on_demand_and_reward_dtype():
+    """`outputs["hidden_states"]` (the reference returns the backbone's whole output object, rw_model_general_preference.py:346-353,
+    :422-425): a tuple-like of layers + 1 tensors recomputed on demand -- element 0 the embeddings, element k the stream entering layer k
+    (what layer_id = k reads), the last one the final norm (= last_hidden_state) -- against the oracle's taps; asking for them leaves the
+    model as it was.  reward_dtype=torch.bfloat16: the reference's GPU return dtype, the fp32 reward rounded once."""
+    cfg = synth.tiny_config(layers=3)
+    seed = 67
+    m = RewardModel(cfg, synth_seed=seed, max_batch=4, max_seq=1024, max_crops=5, operand_dtype="f16x2").to("cuda").eval()
+    W = orc.weights_to_torch(synth.make_weights(cfg, seed))
+    b = synth.synth_batch(cfg, seed, [5, 8, 3], (1, 1))
+    tb = {k: torch.from_numpy(v) for k, v in b.items()}
+    args = (tb["input_ids"].cuda(), tb["attention_mask"].cuda(), tb["pixel_values"].cuda(), tb["image_sizes"])
+    r0, outs = m.custom_forward(*args, return_output=True)
+    r0 = r0.clone()
+    hs = outs["hidden_states"]
+    assert len(hs) == cfg.layers + 1
+    taps = {}
+    orc.custom_forward(W, cfg, tb["input_ids"], tb["attention_mask"], tb["pixel_values"], tb["image_sizes"], taps=taps)
+    valid = tb["attention_mask"].bool()
+    want = [taps["embeds"]] + [taps[f"layer{k}"] for k in range(cfg.layers - 1)] + [orc.rms_norm(taps[f"layer{cfg.layers - 1}"], W["model.norm.weight"], cfg.rms_eps)]
+    for k in range(len(hs)):
+        got = hs[k].cpu()
+        assert got.shape == want[k].shape
+        assert (got - want[k])[valid].abs().max().item() < 2e-4 * want[k][valid].abs().max().item() + 1e-5, k
+    assert torch.equal(hs[-1], outs["last_hidden_state"]) and len(list(hs[1:3])) == 2
+    with pytest.raises(IndexError):
+        hs[len(hs)]
+    # element k is what a model built with layer_id = k reads its reward from, bit for bit
+    mk = RewardModel(cfg, synth_seed=seed, max_batch=4, max_seq=1024, max_crops=5, operand_dtype="f16x2", layer_id=1).to("cuda").eval()
+    _, ok = mk.custom_forward(*args, return_output=True)
+    assert torch.equal(ok["hidden_states_at_layer_id"], hs[1])
+    with pytest.raises(KeyError):
+        ok["hidden_states"]
+    # the model is as it was: same rewards
+    assert torch.equal(m.custom_forward(*args)[0], r0)
+    mb = RewardModel(cfg, synth_seed=seed, max_batch=4, max_seq=1024, max_crops=5, operand_dtype="f16x2", reward_dtype=torch.bfloat16).to("cuda").eval()
+    rb = mb.custom_forward(*args)[0]
+    assert rb.dtype == torch.bfloat16 and torch.equal(rb, r0.to(torch.bfloat16))
