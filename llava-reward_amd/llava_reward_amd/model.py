@@ -120,7 +120,7 @@ class RewardModel:
         # "eager": the reference's exceptions for rows whose image-slot count does not match their image_sizes, raised by this call
         # (host tensors are counted on the host; DEVICE input_ids cost a stream drain per forward).  "deferred": no host-side check
         # and no synchronisation -- the engine itself marks such a row's reward NaN (slot_check_kernel), visible at the caller's next
-        # read of the rewards.
+        # read of the rewards (phi3v / llava; the qwen branch always checks: its engine entry has no such kernel).
         if check_inputs not in ("eager", "deferred"):
             raise ValueError("check_inputs must be 'eager' or 'deferred'")
         self.check_inputs = check_inputs
@@ -401,11 +401,12 @@ class RewardModel:
         pix = inputs_batch["pixel_values"]
         grid = torch.as_tensor(inputs_batch["image_grid_thw"]).cpu().long()
         unit = self.config.vision.merge_unit
-        if self.check_inputs == "eager" or not ids.is_cuda:
-            n_slots = int((ids == self.config.image_token_id).sum())
-            n_feat = int(grid.prod(dim=1).sum()) // unit
-            if n_slots != n_feat:
-                raise ValueError(f"Image features and image tokens do not match, tokens: {n_slots}, features: {n_feat}")
+        # (always checked, check_inputs="deferred" included: lr_forward_qwen has no slot check of its own -- a mismatch would neither
+        #  raise nor come back NaN -- and one scalar per forward is all this costs)
+        n_slots = int((ids == self.config.image_token_id).sum())
+        n_feat = int(grid.prod(dim=1).sum()) // unit
+        if n_slots != n_feat:
+            raise ValueError(f"Image features and image tokens do not match, tokens: {n_slots}, features: {n_feat}")
         reward = self.engine.forward_qwen(ids, mask, pix, grid, training=self.training,
                                           keep_hidden_states=return_output or self.keep_hidden_states)
         return self._finish(reward, ids.shape, return_output)
