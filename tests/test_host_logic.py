@@ -429,3 +429,30 @@ def test_bench_final_line_is_compact_and_last(tmp_path, capsys):
     for i in range(200):
         res[f"extra_leg_{i}"] = {"value": 1.0, "ms_per_step": 2.0, "operand_form": {"form": "strict-vision+decoder/2"}}
     assert len(bench.compact_line(res)) <= bench.LINE_BUDGET
+
+
+def test_form_ladder_and_loader_knobs_without_a_gpu():
+    """Host side of the operand-form machinery (round 5): the probe's candidate ladder (cheapest first, strict from the front of the
+    model in eighths of the decoder), the pin-only single-pass tails, the constructor's validation, and the loader's pass-through of the
+    knobs the reference does not have (args.operand_form / check_inputs / parity_budget / reward_dtype)."""
+    from llava_reward_amd.reward_adaptor_loader import _form_args
+    m = RewardModel(synth.full_config(), synth_seed=1)
+    assert [n for n, _ in m._form_candidates()] == ["default", "strict-vision", "strict-vision+decoder/8", "strict-vision+decoder/4",
+                                                    "strict-vision+decoder*3/8", "strict-vision+decoder/2", "strict"]
+    maps = dict(m._form_candidates() + m._pinnable_forms())
+    assert maps["default"] == (-1, -1, 0, 0) and maps["strict"] == (1, 1, 0, 0) and maps["strict-vision"] == (1, -1, 0, 0)
+    assert maps["strict-vision+decoder/8"] == (1, 1, 0, 28) and maps["strict-vision+decoder*3/8"] == (1, 1, 0, 20)      # first 4 / 12 of 32 layers
+    assert maps["default+single-tail/8"] == (-1, 0, 28, 0) and maps["default+single-tail/4"] == (-1, 0, 24, 0)          # last 4 / 8 single-pass
+    tiny = RewardModel(synth.tiny_config(layers=3), synth_seed=1)
+    names = [n for n, _ in tiny._form_candidates()]
+    assert names[0] == "default" and names[-1] == "strict" and len(set(names)) == len(names) and tiny._pinnable_forms() == []
+    with pytest.raises(ValueError):
+        RewardModel(synth.tiny_config(), synth_seed=1, operand_form="default+single-tail/8")        # (2 layers: no such tail)
+    with pytest.raises(ValueError):
+        RewardModel(synth.tiny_config(), synth_seed=1, check_inputs="sometimes")
+    a = types.SimpleNamespace(operand_form="strict", check_inputs="deferred", parity_budget=1e-4, reward_dtype="bf16")
+    kw = _form_args(a)
+    assert kw == dict(operand_form="strict", check_inputs="deferred", parity_budget=1e-4, reward_dtype=torch.bfloat16)
+    assert _form_args(types.SimpleNamespace()) == dict(operand_form=None, check_inputs="eager", parity_budget=1.5e-4, reward_dtype=None)
+    mm = RewardModel(synth.tiny_config(), synth_seed=1, **kw)
+    assert mm.pinned_form == "strict" and mm.check_inputs == "deferred" and mm.reward_dtype == torch.bfloat16
