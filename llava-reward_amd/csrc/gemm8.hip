@@ -36,6 +36,10 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifndef LR_GEMM_SADDR
+#define LR_GEMM_SADDR 1
+#endif
+
 namespace lr {
 
 #define LR_BARRIER() do { asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -184,6 +188,18 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         // loop in VGPRs the accumulators need).
         const unsigned short* gA[2][2];
         const unsigned short* gB[2][2];
+        // SADDR (round 5 experiment, LR_GEMM_SADDR): the DMA's source as a UNIFORM 64-bit base (SGPR pair, one per operand, advanced per
+        // K-tile with scalar adds) + a per-thread 32-bit byte offset that is constant over a segment -- the saddr form of the instruction
+        // -- instead of eight running 64-bit per-lane pointers (16 VGPRs, eight 64-bit vector adds per K-tile).
+        constexpr bool SADDR = PB == 2 && LR_GEMM_SADDR;
+        const unsigned short* bA = nullptr;
+        const unsigned short* bB = nullptr;
+        unsigned oA[2][2], oB[2][2];
+        auto uni64 = [&](const unsigned short* q) {
+            const unsigned long long u = (unsigned long long)q;
+            return (const unsigned short*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                                           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u));
+        };
         int iseg = -1, iseg_end = 0, ikt = 0;          // segment being issued, its last K-tile + 1, K-tile being issued (uniform)
         auto load_seg = [&]() {
             ++iseg;
@@ -205,11 +221,20 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int ga = min(m0 + (NW == 1 ? 0 : h * 128) + row, p.M - 1);
-                    gA[h][it] = Ab + (size_t)ga * la + c * 8 + sg.a_col;
                     const int wrow = NW == 2 ? row : (row >> 5) * 64 + h * 32 + (row & 31);     // 256 x 128: image row = tile column
                     const int gb = min(n0 + wrow, p.N - 1);
-                    gB[h][it] = Wb + (size_t)gb * lw + c * 8 + sg.w_col;
+                    if constexpr (SADDR) {      // byte offsets inside the tile; the tile's (row m0 / n0, column, K-tile) lives in the uniform bases
+                        oA[h][it] = (unsigned)((ga - m0) * la + c * 8) * 2u;
+                        oB[h][it] = (unsigned)((gb - n0) * lw + c * 8) * 2u;
+                    } else {
+                        gA[h][it] = Ab + (size_t)ga * la + c * 8 + sg.a_col;
+                        gB[h][it] = Wb + (size_t)gb * lw + c * 8 + sg.w_col;
+                    }
                 }
+            }
+            if constexpr (SADDR) {
+                bA = uni64(Ab + (size_t)m0 * la + sg.a_col);
+                bB = uni64(Wb + (size_t)n0 * lw + sg.w_col);
             }
         };
         if constexpr (PB != 2) {
@@ -237,6 +262,14 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         // (cdna_hip_programming.md §5.7 item 1).  M0 is saved/restored inside the statement.
         auto issue1 = [&](int j, int kt, int slot, int it) {
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * HT + wave * 1024 + it * 8192);
+            if constexpr (SADDR) {
+                const unsigned short* base = (j == 0 || j == 3) ? bA : bB;
+                const unsigned off = (j == 0) ? oA[0][it] : (j == 1) ? oB[0][it] : (j == 2) ? oB[1][it] : oA[1][it];
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
+                return;
+            }
             const unsigned short* src;
             if constexpr (PB == 2) {             // running pointers: already at this K-tile
                 src = (j == 0) ? gA[0][it] : (j == 1) ? gB[0][it] : (j == 2) ? gB[1][it] : gA[1][it];
@@ -260,7 +293,8 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         auto ktile_begin = [&]() { if (ikt == iseg_end) load_seg(); };
         auto ktile_end = [&]() {
             ++ikt;
-            if constexpr (DBG != 1) {
+            if constexpr (SADDR) { bA += BK; bB += BK; }
+            else if constexpr (DBG != 1) {
 #pragma unroll
                 for (int it = 0; it < 2; ++it)
 #pragma unroll
