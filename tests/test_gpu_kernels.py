@@ -735,7 +735,9 @@ def test_gemm_narrow_tiles_give_the_full_tile_bits(lib, monkeypatch):
 def test_attention_workgroup_order_and_query_tiling_are_bit_neutral(lib, monkeypatch):
     """Round 4: dense attention launches walk their workgroups in an XCD-aware order (all query tiles of a (sequence, kv head) on one
     XCD, heaviest first) and the long-sequence causal kernel shifts its query tiles towards the end of the sequence.  Neither may
-    change a bit: a query's arithmetic does not depend on the workgroup, wave or lane that holds it."""
+    change a bit: a query's arithmetic does not depend on the workgroup, wave or lane that holds it.  Round 5 adds the kernel FORM: the
+    ping-pong schedule and the plain per-tile loop give the same bits (so a row scored in a long batch and alone in a short one differ
+    by nothing the attention kernels do)."""
     def run(B, S, H, hd, causal, Hkv, pads):
         Wd = (H + 2 * Hkv) * hd
         g = torch.Generator(device="cuda").manual_seed(S + hd)
@@ -749,7 +751,9 @@ def test_attention_workgroup_order_and_query_tiling_are_bit_neutral(lib, monkeyp
                 mask[b, :p_] = 0
                 kmin[b] = p_
         outs = []
-        for env in ({}, {"LR_ATT_XCD_ORDER": "0"}, {"LR_ATT_QSHIFT": "0"}, {"LR_ATT_XCD_ORDER": "0", "LR_ATT_QSHIFT": "0"}):
+        # (round 5: LR_ATT_PINGPONG = 0 runs long sequences on the plain per-tile loop instead of the ping-pong schedule -- another
+        #  wave-to-query assignment, tile walk and barrier structure, the same per-query arithmetic, lazy reference maximum included)
+        for env in ({}, {"LR_ATT_XCD_ORDER": "0"}, {"LR_ATT_QSHIFT": "0"}, {"LR_ATT_XCD_ORDER": "0", "LR_ATT_QSHIFT": "0"}, {"LR_ATT_PINGPONG": "0"}):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             out = torch.zeros(B * S, 2 * H * hd, device="cuda", dtype=torch.float16)
