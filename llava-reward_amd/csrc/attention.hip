@@ -650,6 +650,8 @@ static void launch_one(const AttnParams& p0, int batch, hipStream_t st) {
     p.q_end_aligned = (!qe || atoi(qe) != 0) ? 1 : 0;
     const char* pe = getenv("LR_ATT_PINGPONG");              // A/B switch: 0 = the plain per-tile loop for long sequences too
     const bool pingpong = !pe || atoi(pe) != 0;
+    const char* pm = getenv("LR_ATT_PP_MIN_S");              // A/B switch: shortest sequence that takes the ping-pong schedule (1024)
+    const int pp_min = pm ? atoi(pm) : 1024;
     auto grid = [&](int nq) {
         if (p.items || !xcd_order) { p.lin_nqt = 0; p.lin_batch = 0; return dim3(nq, p.heads, batch); }
         p.lin_nqt = nq; p.lin_batch = batch;
@@ -658,10 +660,10 @@ static void launch_one(const AttnParams& p0, int batch, hipStream_t st) {
     };
     // Long sequences: 256-query workgroups on the ping-pong schedule (measured at B=32: HD 128 1.47x, where the 4-wave form
     // fits one workgroup per CU; HD 96 1.03-1.07x; split operands 1.01-1.03x; below ~1k keys the 128-query grid fills better).
-    if (p.lo_off == 0 && !p.items && p.S >= 1024 && pingpong) {
+    if (p.lo_off == 0 && !p.items && p.S >= pp_min && pingpong) {
         const dim3 g = grid(nq8);
         hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, false, 8, true>), g, dim3(512), 0, st, p);
-    } else if (p.lo_off > 0 && !p.items && p.S >= 1024 && HD != 128 && pingpong) {
+    } else if (p.lo_off > 0 && !p.items && p.S >= pp_min && HD != 128 && pingpong) {
         if constexpr (HD != 128) {
             const dim3 g = grid(nq8);
             hipLaunchKernelGGL((attn_kernel<OT, HD, CAUSAL, true, 8, true>), g, dim3(512), 0, st, p);
