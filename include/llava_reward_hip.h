@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LR_ABI_VERSION 8
+#define LR_ABI_VERSION 9
 
 enum { LR_OK = 0, LR_EINVAL = 1, LR_EHIP = 2, LR_ESTATE = 3, LR_ENOTFOUND = 4, LR_ENOMEM = 5 };
 enum { LR_DT_BF16 = 0, LR_DT_F16 = 1, LR_DT_F32 = 2 };
@@ -179,6 +179,11 @@ int lr_forward_qwen(lr_handle h, const int64_t* input_ids, const int64_t* attent
  * [B*S, hidden] written to DEVICE memory `out_dev` on `stream`.  Off the scoring path: the forward itself only norms the row
  * it gathers.  Valid until the next forward on the handle. */
 int lr_last_hidden_state(lr_handle h, float* out_dev, size_t capacity, int no_final_norm, void* hip_stream);
+/* The zero-padded projected image tokens of the last lr_forward, [B, V_max, hidden] fp32 on the device: the tensor the reference's
+ * backbone appends as the LAST entry of `hidden_states` (modeling_phi3_v.py:242-245 img_token_batch_embedding, :1505; read back as the
+ * SkipCA key/value source at rw_model_general_preference.py:353).  *vmax receives V_max of that forward; out_dev == NULL only reports
+ * it (size the buffer, then call again).  Stream-ordered; Phi-3-V / LLaVA handles (ABI 9). */
+int lr_vision_embeds(lr_handle h, float* out_dev, size_t capacity, int* vmax, void* hip_stream);
 /* Debug taps: copy an internal fp32 buffer of the last forward to host (synchronises).  Names:
  * "clip_x" [crops*T, Hc], "ev" [sumV, D], "x" [B*S, D] (residual stream after the last layer),
  * "hL" [B, D]; Qwen: "vit_x" [patches, vit_hidden] (window order), "ev" [patches/merge^2, D] (window order),
@@ -225,6 +230,14 @@ int lr_op_attention(const void* Q, const void* K, const void* V, void* O, const 
 int lr_op_attention_split(const void* Q, const void* K, const void* V, void* O, const int64_t* mask, const int* kmin, int ldq,
                           int ldo, int qoff, int koff, int voff, int lo_off, int o_split, int batch, int S, int heads,
                           int head_dim, int causal, int kv_group, float scale, int operand_dtype, void* hip_stream);
+/* ... with the softmax reference-maximum threshold spelled out (ABI 9): a row's running reference moves only when its new maximum
+ * exceeds it by more than lazy_threshold (log2 units, 0 .. 15).  0 = the exact running maximum of the reference's softmax
+ * (modeling_phi3_v.py:685-701): what the engine runs in strict-form stages; 8 = what it runs in default-form stages and what
+ * lr_op_attention_split runs. */
+int lr_op_attention_split_ex(const void* Q, const void* K, const void* V, void* O, const int64_t* mask, const int* kmin, int ldq,
+                             int ldo, int qoff, int koff, int voff, int lo_off, int o_split, int batch, int S, int heads,
+                             int head_dim, int causal, int kv_group, float scale, float lazy_threshold, int operand_dtype,
+                             void* hip_stream);
 /* Block-diagonal (ragged) dense attention: rows [cu[i], cu[i+1]) attend to each other only (the ViT's windows /
  * images, transformers Qwen2_5_VLVisionAttention over cu_seqlens).  cu_seqlens: HOST int32 [n_seg + 1]. */
 int lr_op_attention_segments(const void* Q, const void* K, const void* V, void* O, const int32_t* cu_seqlens_host, int n_seg,

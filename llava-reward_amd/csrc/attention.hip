@@ -302,12 +302,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
 #ifndef LR_ATT_FUSE
 #define LR_ATT_FUSE 0                  // PV(t) and QK(t + 1) of a ping-pong matrix segment as ONE pipeline of fragment reads
 #endif
-#ifndef LR_ATT_LAZY
-#define LR_ATT_LAZY 1                  // 1: the running maximum moves only when a row's new maximum exceeds it by 2^8 (bits change)
-#endif
-#ifndef LR_ATT_LAZY_T
-#define LR_ATT_LAZY_T 8                // the lazy maximum's threshold, log2 units
-#endif
 #ifndef LR_ATT_PRIO
 #define LR_ATT_PRIO 1                  // s_setprio of the ping-pong loop: 1 = the matrix segment goes first, 2 = the vector segment, 0 = none
 #endif
@@ -370,16 +364,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-#if LR_ATT_LAZY
-            // lazy reference maximum (split-operand forms only: the single-pass forms keep the exact maximum, bit for bit as before): a row's reference moves only when its new maximum exceeds it by more than 8 (log2 units), so the
-            // softmax weights of a tile are <= 2^8 instead of <= 1 (exact in the hi + lo operand pair and in the fp32 sums alike) and
-            // the rescale of the 16 DT output registers -- taken for SOME row of the wave in most tiles of random data -- becomes rare.
-            // Per query: a row's arithmetic does not depend on the other rows of its wave (alpha == 1 exactly where nothing moved).
+            // Lazy reference maximum (split-operand forms; AttnParams::lazy_t, a RUN-TIME threshold in log2 units since round 6): a row's
+            // reference moves only when its new maximum exceeds it by more than lazy_t, so the softmax weights of a tile are <= 2^lazy_t
+            // instead of <= 1 (exact in the hi + lo operand pair and in the fp32 sums alike) and the rescale of the 16 DT output
+            // registers -- taken for SOME row of the wave in most tiles of random data -- becomes rare.  Per query: a row's arithmetic
+            // does not depend on the other rows of its wave (alpha == 1 exactly where nothing moved).  lazy_t == 0 IS the exact running
+            // maximum, bit for bit (x > m ? x : m == fmaxf(m, x) for the finite values here): the strict form's passes run with it
+            // (the yardstick keeps the reference's own arithmetic), the e4m3-residual default form with 8; the single-pass forms
+            // (PREC false) always take the exact maximum.  What the threshold costs in accuracy is the exponent's argument: fma(s, sc,
+            // -m_run) is rounded at ulp(lazy_t) instead of ulp(~0), i.e. up to 2^-21 absolute at 8 against 2^-24 -- fp32-level noise on
+            // the softmax weights that an outlier-bearing model amplifies.
             const float mxs = mx * sc;
-            const float m_new = PREC ? (mxs > m_run + (float)LR_ATT_LAZY_T ? mxs : m_run) : fmaxf(m_run, mxs);
-#else
-            const float m_new = fmaxf(m_run, mx * sc);
-#endif
+            const float m_new = PREC ? (mxs > m_run + p.lazy_t ? mxs : m_run) : fmaxf(m_run, mxs);
 #endif
             if (!__all(m_new == m_run)) {
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -694,6 +690,8 @@ void launch_attention(const AttnParams& p, int batch, int head_dim, bool causal,
     if (p.qsel && (!causal || p.items)) throw std::runtime_error("attention: gathered mode is causal and batched");
     if (p.S > ATT_MAX_S) throw std::runtime_error("attention: sequence length above 8192 is not supported");
     if (p.kv_group < 1 || p.heads % p.kv_group) throw std::runtime_error("attention: heads must be a multiple of kv_group");
+    // (2^lazy_t must fit the f16 hi half of a softmax weight, and the fp32 sums must not lose the small weights: 15 is the ceiling)
+    if (!(p.lazy_t >= 0.f && p.lazy_t <= 15.f)) throw std::runtime_error("attention: lazy_t (reference-maximum threshold, log2 units) must be in [0, 15]");
     const bool f16 = operand_dtype == DT_F16;
     if (head_dim == 96 && causal) { f16 ? launch_one<F16, 96, true>(p, batch, st) : launch_one<BF16, 96, true>(p, batch, st); }
     else if (head_dim == 64 && !causal) { f16 ? launch_one<F16, 64, false>(p, batch, st) : launch_one<BF16, 64, false>(p, batch, st); }

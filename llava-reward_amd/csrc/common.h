@@ -72,6 +72,30 @@ __device__ __forceinline__ float row16_max(float m) {
     v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));    // row_mirror
     return __builtin_bit_cast(float, v);
 }
+// DIAGNOSTIC ONLY (-DLR_EMU_FP6=1, tools/fp6/; never in the product build): what the default form would lose if its residual pass ran
+// in OCP MX FP6 -- e2m3 elements {0, 0.125 .. 7.5}, one power-of-two scale per 32 elements of a row, for A_lo AND for the weight twin
+// (v_mfma_scale_f32_16x16x128_f8f6f4 with cbsz / blgp = 2 issues at twice the e4m3 rate, MI355X_MICROARCH.md).  The residuals are
+// snapped to that grid and THEN encoded in the product's e4m3 / 128-block form, which holds every snapped value exactly (3 mantissa
+// bits either way; a 32-block whose maximum is below 2^-9 of its 128-block's would lose bits, by less than 2^-10 of that maximum), so
+// the unchanged e4m3 kernels compute the products an fp6 pass would -- its numerics without its kernel.
+#ifndef LR_EMU_FP6
+#define LR_EMU_FP6 0
+#endif
+__device__ __forceinline__ float emu_e2m3(float v, float bmax) {     // bmax = max |.| over the 32-element block that holds v
+    if (!(bmax > 0.f)) return v;
+    const int e = ilogbf(bmax) - 2;                // MX: scale = 2^(floor(log2 amax) - emax), emax(e2m3) = 2: amax / scale in [4, 8)
+    const float aq = fminf(fabsf(ldexpf(v, -e)), 7.5f);
+    const int ex = aq >= 1.f ? ilogbf(aq) : 0;     // sub-normals share the grid of [1, 2): 0.125
+    const float ulp = ldexpf(1.f, ex - 3);
+    return copysignf(ldexpf(fminf(rintf(aq / ulp) * ulp, 7.5f), e), v);
+}
+// maximum over the 4 lanes of a quad (8 columns per lane: one 32-column block); m >= 0.  Call in uniform control flow.
+__device__ __forceinline__ float quad_max(float m) {
+    int v = __builtin_bit_cast(int, m);
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));
+    return __builtin_bit_cast(float, v);
+}
 // 2^(E-127) puts amax into [128, 256) <= 448 (e4m3's largest finite value); E = 127 for an all-zero block
 __device__ __forceinline__ int e8m0_of_amax(float amax) { return amax > 0.f ? min(max(127 + (ilogbf(amax) - 7), 1), 253) : 127; }
 __device__ __forceinline__ float e8m0_inv_scale(int E) { return __builtin_bit_cast(float, (unsigned)(254 - E) << 23); }   // 2^(127 - E)
@@ -249,7 +273,13 @@ struct AttnParams {
     // 0 = the 3-D grid (ragged mode).
     int lin_nqt, lin_batch;
     int q_end_aligned;      // causal: query tiles shifted towards the end of the sequence by whole key tiles (see attn_kernel)
+    // ---- set by callers (0 = the exact running maximum) ----
+    // split-operand forms: the softmax reference maximum of a row moves only when the new maximum exceeds it by more than lazy_t
+    // (log2 units, 0 .. 15).  The engine passes ATT_LAZY_T_DEFAULT in stages that run the e4m3-residual default form and 0 (exact,
+    // the reference's own arithmetic) in stages that run the strict form.
+    float lazy_t;
 };
+constexpr float ATT_LAZY_T_DEFAULT = 8.f;
 
 }  // namespace lr
 

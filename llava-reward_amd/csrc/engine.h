@@ -161,7 +161,8 @@ struct lr_engine {
     char* tab_host = nullptr; char* tab_dev = nullptr; size_t tab_bytes = 0;
     hipEvent_t tab_ev[NSLOT] = {}; bool tab_used[NSLOT] = {};
     // last forward geometry (for taps)
-    int lastB = 0, lastS = 0, lastNC = 0, lastSV = 0;
+    int lastB = 0, lastS = 0, lastNC = 0, lastSV = 0, lastVmax = 0;
+    std::vector<int> last_voff;                      // first row in ev of every sample of the last forward (+ the end), lr_vision_embeds
     bool last_pruned = false;                        // the last forward ran its final decoder layer for the gathered rows only (x is stale there)
     // last decoder layer, gathered rows only (run_decoder_stack): compact [max_batch (+ pad), ...] twins of x / h / att / ff
     float* xg = nullptr; void *hg = nullptr, *attg = nullptr, *ffg = nullptr;
@@ -186,8 +187,8 @@ struct lr_engine {
     void release_stale_pair8() {
         for (auto it = pair8.begin(); it != pair8.end();) {
             auto wb = wbuf_of.find(it->first);
-            const bool still = wb != wbuf_of.end() && !inexact.empty() && inexact[wb->second];
-            if (still || !it->second) { ++it; continue; }
+            if (wb == wbuf_of.end() || inexact.empty() || !it->second) { ++it; continue; }      // (not a tracked buffer / flags never read back: keep)
+            if (inexact[wb->second]) { ++it; continue; }                                        // still inexact: still read
             const size_t bytes = (wbufs[wb->second].bytes + 255) & ~(size_t)255;
             for (auto a = allocs.begin(); a != allocs.end(); ++a) if (*a == it->second) { allocs.erase(a); break; }
             (void)hipFree(it->second);
@@ -431,6 +432,12 @@ inline void apply_prec(const lr_engine* e, AttnParams& p) {
     if (!e->prec) return;
     p.lo_off = p.ldq; p.ldq *= 2;
     p.o_split = p.ldo; p.ldo *= 2;
+    // strict stages (16-bit residual passes: the probe's yardstick, and what an amplifying weight set is locked to) keep the exact
+    // softmax maximum; stages in the default form take the lazy one (attention.hip; -14 % per launch)
+    // (A/B switches for tools/outlier_fp64_probe.py, read once: LR_ATT_LAZY_T = the default-form stages' threshold, LR_ATT_LAZY_T_STRICT = the strict stages')
+    static const float t_def = [] { const char* v = getenv("LR_ATT_LAZY_T"); return v ? (float)atof(v) : ATT_LAZY_T_DEFAULT; }();
+    static const float t_strict = [] { const char* v = getenv("LR_ATT_LAZY_T_STRICT"); return v ? (float)atof(v) : 0.f; }();
+    p.lazy_t = e->lo8 ? t_def : t_strict;
 }
 
 // W8A8 mode: quantise the rows of A, make sure W has its e4m3 twin, launch the e4m3 form.  Like lo8_eligible, the choice never

@@ -426,9 +426,10 @@ int lr_upload_weight(lr_handle h, const char* name, const void* data, const int6
         ++h->weights_epoch;
         h->w8.clear();             // W8A8 twins are separate buffers, rebuilt from the packed weights at the next launch
         LR_HIP_CHECK(hipStreamSynchronize(0));
-        if (h->finalized && h->inexact_dev)      // a re-upload after lr_finalize may have made a buffer inexact
+        if (h->finalized && h->inexact_dev) {    // a re-upload after lr_finalize may have made a buffer inexact -- or exact again
             LR_HIP_CHECK(hipMemcpy(h->inexact.data(), h->inexact_dev, h->wbufs.size() * sizeof(int), hipMemcpyDeviceToHost));
-        h->release_stale_pair8();
+            h->release_stale_pair8();
+        }
     });
 }
 
@@ -455,8 +456,8 @@ int lr_synth_weights_ex(lr_handle h, uint64_t seed, int flags) {
         if (h->finalized && h->inexact_dev) {    // re-synthesised after lr_finalize (fp32-valued profile): a buffer may have become inexact
             h->inexact.resize(h->wbufs.size(), 0);
             LR_HIP_CHECK(hipMemcpy(h->inexact.data(), h->inexact_dev, h->wbufs.size() * sizeof(int), hipMemcpyDeviceToHost));
+            h->release_stale_pair8();
         }
-        h->release_stale_pair8();
     });
 }
 
@@ -627,7 +628,8 @@ int lr_forward(lr_handle h, const int64_t* input_ids, const int64_t* attention_m
         const HdSample* d_smp = (const HdSample*)(td + smp_off);
         const LlavaSample* d_lsmp = (const LlavaSample*)(td + smp_off);
         const int* d_voff = (const int*)(td + voff_off);
-        h->lastB = B; h->lastS = S; h->lastNC = NC; h->lastSV = SV;
+        h->lastB = B; h->lastS = S; h->lastNC = NC; h->lastSV = SV; h->lastVmax = Vmax;
+        h->last_voff.assign(voff, voff + B + 1);
 
         // ---- CLIP tower (utils/utils.py:266-273) ----
         const int Rp = NC * (T - 1), Rc = NC * T;
@@ -712,6 +714,24 @@ int lr_last_hidden_state(lr_handle h, float* out_dev, size_t capacity, int no_fi
         if (no_final_norm) LR_HIP_CHECK(hipMemcpyAsync(out_dev, h->x, rows * D * 4, hipMemcpyDeviceToDevice, st));
         else launch_rms_rows_f32(h->x, h->norm_w, h->d.rms_eps, out_dev, (int)rows, (int)D, st);
         LR_HIP_CHECK(hipGetLastError());
+    });
+}
+
+int lr_vision_embeds(lr_handle h, float* out_dev, size_t capacity, int* vmax, void* hip_stream) {
+    if (!h || !vmax) return LR_EINVAL;
+    return guarded(h, [&] {
+        if (!h->finalized || h->lastB <= 0) throw std::logic_error("lr_vision_embeds: no forward has run on this handle");
+        if (h->qwen) throw std::logic_error("lr_vision_embeds: the qwen branch keeps no padded vision rows (its SkipCA reads the embeddings, rw_model:359-371)");
+        *vmax = h->lastVmax;
+        if (!out_dev) return;
+        const size_t D = (size_t)h->d.hidden, B = (size_t)h->lastB, V = (size_t)h->lastVmax;
+        if (capacity < B * V * D) throw std::invalid_argument("lr_vision_embeds: buffer too small");
+        hipStream_t st = (hipStream_t)hip_stream;
+        LR_HIP_CHECK(hipMemsetAsync(out_dev, 0, B * V * D * 4, st));          // F.pad(..., "constant", 0), modeling_phi3_v.py:245
+        for (size_t b = 0; b < B; ++b) {
+            const size_t n = (size_t)(h->last_voff[b + 1] - h->last_voff[b]);
+            if (n) LR_HIP_CHECK(hipMemcpyAsync(out_dev + b * V * D, h->ev + (size_t)h->last_voff[b] * D, n * D * 4, hipMemcpyDeviceToDevice, st));
+        }
     });
 }
 
@@ -860,6 +880,17 @@ int lr_op_attention_split(const void* Q, const void* K, const void* V, void* O, 
                           int causal, int kv_group, float scale, int operand_dtype, void* hip_stream) {
     return op_guard([&] {
         AttnParams p{Q, K, V, O, mask, kmin, 1, ldq, ldo, qoff, koff, voff, S, heads, scale, kv_group, nullptr, 0, lo_off, o_split};
+        p.lazy_t = ATT_LAZY_T_DEFAULT;
+        launch_attention(p, batch, head_dim, causal != 0, operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16, (hipStream_t)hip_stream);
+    });
+}
+
+int lr_op_attention_split_ex(const void* Q, const void* K, const void* V, void* O, const int64_t* mask, const int* kmin, int ldq,
+                             int ldo, int qoff, int koff, int voff, int lo_off, int o_split, int batch, int S, int heads, int head_dim,
+                             int causal, int kv_group, float scale, float lazy_threshold, int operand_dtype, void* hip_stream) {
+    return op_guard([&] {
+        AttnParams p{Q, K, V, O, mask, kmin, 1, ldq, ldo, qoff, koff, voff, S, heads, scale, kv_group, nullptr, 0, lo_off, o_split};
+        p.lazy_t = lazy_threshold;
         launch_attention(p, batch, head_dim, causal != 0, operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16, (hipStream_t)hip_stream);
     });
 }

@@ -726,6 +726,14 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 m = fmaxf(m, fmaxf(fabsf(r[2 * e]), fabsf(r[2 * e + 1])));
             }
             *(uint4*)(crow + col) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+#if LR_EMU_FP6
+            {
+                const float bm = quad_max(m);
+                m = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { r[e] = emu_e2m3(r[e], bm); m = fmaxf(m, fabsf(r[e])); }
+            }
+#endif
             const int E = e8m0_of_amax(row16_max(m));
             const float sc = e8m0_inv_scale(E);
             int p0 = 0, p1 = 0;

@@ -159,6 +159,14 @@ __global__ __launch_bounds__(256) void norm_rows8_kernel(const float* __restrict
                                                 hb[4] | ((unsigned)hb[5] << 16), hb[6] | ((unsigned)hb[7] << 16));
         }
         if (lo8) {              // residual half as block-scaled e4m3 (common.h): 16 lanes = one 128-column block (H % 128 == 0)
+#if LR_EMU_FP6
+            {
+                const float bm = quad_max(c < n8 ? m : 0.f);
+                m = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { r[j] = c < n8 ? emu_e2m3(r[j], bm) : 0.f; m = fmaxf(m, fabsf(r[j])); }
+            }
+#endif
             const int E = e8m0_of_amax(row16_max(m));
             if (c < n8) {
                 const float sc = e8m0_inv_scale(E);
@@ -1108,6 +1116,14 @@ __global__ __launch_bounds__(256) void quantize_lo_inplace_kernel(unsigned short
             f[2 * i + 1] = Op<OT>::to_f32((unsigned short)(w[i] >> 16));
             m = fmaxf(m, fmaxf(fabsf(f[2 * i]), fabsf(f[2 * i + 1])));
         }
+#if LR_EMU_FP6
+        {
+            const float bm = quad_max(m);
+            m = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { f[i] = emu_e2m3(f[i], bm); m = fmaxf(m, fabsf(f[i])); }
+        }
+#endif
         const int E = e8m0_of_amax(row16_max(m));
         if (k < K) {
             const float sc = e8m0_inv_scale(E);
@@ -1181,12 +1197,31 @@ __global__ __launch_bounds__(256) void weight_to_e4m3_kernel(const unsigned shor
     if (row >= N) return;
     const unsigned short* wr = w + (size_t)row * ldw;
     unsigned char* q = dst + (size_t)row * ldw * 2;
+#if LR_EMU_FP6
+    for (int k0 = 0; k0 < K; k0 += 256) {          // (uniform trip count: the 8 lanes of a 32-column block reduce together)
+        const int k = k0 + lane * 4;
+        float f[4] = {0.f, 0.f, 0.f, 0.f};
+        float bm = 0.f;
+        if (k < K) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { f[i] = Op<OT>::to_f32(wr[k + i]); bm = fmaxf(bm, fabsf(f[i])); }
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 1, 64)); bm = fmaxf(bm, __shfl_xor(bm, 2, 64)); bm = fmaxf(bm, __shfl_xor(bm, 4, 64));
+        if (k < K) {
+            int pk = 0;
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(emu_e2m3(f[0], bm), 127 - E), ldexpf(emu_e2m3(f[1], bm), 127 - E), pk, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(emu_e2m3(f[2], bm), 127 - E), ldexpf(emu_e2m3(f[3], bm), 127 - E), pk, true);
+            *(unsigned*)(q + k) = (unsigned)pk;
+        }
+    }
+#else
     for (int k = lane * 4; k < K; k += 256) {
         int pk = 0;
         pk = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(Op<OT>::to_f32(wr[k]), 127 - E), ldexpf(Op<OT>::to_f32(wr[k + 1]), 127 - E), pk, false);
         pk = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(Op<OT>::to_f32(wr[k + 2]), 127 - E), ldexpf(Op<OT>::to_f32(wr[k + 3]), 127 - E), pk, true);
         *(unsigned*)(q + k) = (unsigned)pk;
     }
+#endif
 }
 
 // Weights that are not exact in the operand type: `twin` holds their 16-bit residuals (same layout as W).  The residuals become

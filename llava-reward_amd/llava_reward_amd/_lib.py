@@ -14,7 +14,7 @@ LR_MAX_HALF_HEAD = 64
 LR_MAX_PINPOINTS = 8
 LR_MAX_FULLATT = 8
 LR_BACKBONE_PHI3V, LR_BACKBONE_LLAVA_NEXT, LR_BACKBONE_QWEN2_5_VL = 0, 1, 2
-LR_ABI_VERSION = 8
+LR_ABI_VERSION = 9
 EPI_OUT_OP, EPI_OUT_F32, EPI_RESADD_F32, EPI_SWIGLU_OP, EPI_ROPE_OP = 0, 1, 2, 3, 4
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2
 
@@ -72,6 +72,7 @@ _SIGS = {
     "lr_forward_qwen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64),
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "lr_last_hidden_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "lr_vision_embeds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.c_void_p]),
     "lr_read_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "lr_set_layer_limits": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "lr_set_precision_map": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -83,6 +84,7 @@ _SIGS = {
     "lr_op_gemm_rope": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p]),
     "lr_op_attention": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 11 + [C.c_float, C.c_int, C.c_void_p]),
     "lr_op_attention_split": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 13 + [C.c_float, C.c_int, C.c_void_p]),
+    "lr_op_attention_split_ex": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 13 + [C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "lr_op_attention_segments": (C.c_int, [C.c_void_p] * 4 + [C.POINTER(C.c_int32)] + [C.c_int] * 8 + [C.c_float, C.c_int, C.c_void_p]),
     "lr_op_quantize_rows_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "lr_op_gemm_fp8": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_void_p]),

@@ -233,6 +233,18 @@ class RewardEngine:
                                                         C.c_void_p(stream)), self.h, "lr_last_hidden_state")
         return out
 
+    def vision_embeds(self, B: int) -> torch.Tensor:
+        """[B, V_max, hidden] fp32 on the device: the zero-padded projected image tokens of the last forward (lr_vision_embeds) -- the
+        last entry of the reference backbone's `hidden_states` (modeling_phi3_v.py:242-245, :1505)."""
+        dev = torch.device("cuda", self.device)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        vmax = C.c_int(0)
+        L.check(self.lib, self.lib.lr_vision_embeds(self.h, C.c_void_p(0), 0, C.byref(vmax), C.c_void_p(stream)), self.h, "lr_vision_embeds")
+        out = torch.empty(B, vmax.value, self.cfg.hidden, device=dev, dtype=torch.float32)
+        L.check(self.lib, self.lib.lr_vision_embeds(self.h, C.c_void_p(out.data_ptr()), out.numel(), C.byref(vmax), C.c_void_p(stream)),
+                self.h, "lr_vision_embeds")
+        return out
+
     def read_tap(self, name: str, numel: int) -> np.ndarray:
         buf = np.empty(numel, dtype=np.float32)
         n = C.c_size_t(0)

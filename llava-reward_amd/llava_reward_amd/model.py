@@ -7,8 +7,8 @@ reference's `load_reward_adaptor` also returns a CPU model that the caller moves
 Deviations, on purpose: rewards come back in fp32 unless reward_dtype says otherwise (the reference
 returns the model dtype, bf16; SURVEY.md §7 shows bf16 rounding alone costs up to 2e-3); `outputs` for
 return_output=True holds `last_hidden_state` (what the reference's callers read), the hidden row behind
-the reward, and `hidden_states` as a tuple-like that recomputes a layer's tensor when it is asked for
-(the backbone's output object carries all 33 at once)."""
+the reward, and `hidden_states` as a tuple-like in the reference's layout (phi3v: layers + 2 entries, `vision_embeds`
+last) that recomputes an inner layer's tensor when it is asked for (the backbone's output object carries all at once)."""
 from __future__ import annotations
 
 from typing import Dict, Optional
@@ -38,23 +38,41 @@ class _Outputs(dict):
         if key == "hidden_states":
             raise KeyError("hidden_states: the per-layer tuple is served on demand for the phi3v / llava branches with layer_id == 32 only "
                            "(_LazyHiddenStates); here use layer_id=<k> for one of them")
+        if key == "vision_embeds":
+            raise KeyError("vision_embeds: read outputs['hidden_states'][-1] (phi3v branch, layer_id == 32), as the reference does "
+                           "(rw_model_general_preference.py:353)")
         raise KeyError(key)
 
 
 class _LazyHiddenStates:
-    """`outputs["hidden_states"]` of the reference's backbone output (`output_hidden_states=True`, rw_model_general_preference.py:346-352,
-    :372-375): a tuple of layers + 1 tensors [B, S, hidden] -- element 0 the embeddings (image rows scattered in), element k the residual
-    stream entering decoder layer k, the last element the final norm's output (the same tensor as `last_hidden_state`).  The engine keeps
-    ONE residual stream, so element k is recomputed when it is asked for: the same forward stopped after k layers (lr_set_layer_limits +
-    LR_FWD_NO_FINAL_NORM, the mechanism behind `layer_id`), fp32 on the device.  Holds references to the forward's input tensors; valid
-    while the model's weights are unchanged.  len(), indexing (negative too) and iteration work as on the tuple."""
+    """`outputs["hidden_states"]` of the reference's backbone output (`output_hidden_states=True`, rw_model_general_preference.py:346-353,
+    :372-375), in the reference's layout:
 
-    def __init__(self, model, args, shape):
+      phi3v  (modeling_phi3_v.py:1467-1505)  layers + 2 entries: [k], k < layers = the residual stream entering decoder layer k ([0] = the
+             embeddings with the image rows scattered in), [layers] = the final norm's output (the same tensor as `last_hidden_state`),
+             [-1] = `vision_embeds` [B, V_max, hidden], the projected image tokens zero-padded per sample (:242-245) -- the entry
+             custom_forward itself reads back as the SkipCA key / value source (rw_model:353, vision_layer_id = -1);
+      llava  (transformers LlavaNext, rw_model:372-375)  layers + 1 entries, [-1] = the final norm's output.
+
+    The engine keeps ONE residual stream, so an inner element is recomputed when it is asked for -- the same forward stopped after k
+    layers (lr_set_layer_limits + LR_FWD_NO_FINAL_NORM, the mechanism behind `layer_id`) -- and cached; the final norm and
+    `vision_embeds` are taken at the forward itself.  fp32, on the device.  Holds references to the forward's input tensors.  The
+    weights the elements belong to are those of the forward: an access after a weight upload / re-synthesis (lr_weights_epoch moved)
+    raises instead of returning another model's states.  An access runs a forward on the shared engine, i.e. it replaces the engine's
+    last-forward state (read_tap / lr_last_hidden_state) like any other custom_forward call.  len(), indexing (negative, slices) and
+    iteration work as on the tuple."""
+
+    def __init__(self, model, args, shape, final_norm, vision_embeds):
         self._m, self._args, self._shape = model, args, (int(shape[0]), int(shape[1]))
         self._n = int(model.config.layers)
+        self._epoch = model.engine.weights_epoch()
+        self._engine = model.engine
+        self._cache = {self._n: final_norm}
+        if vision_embeds is not None:
+            self._cache[self._n + 1] = vision_embeds
 
     def __len__(self):
-        return self._n + 1
+        return self._n + (2 if self._n + 1 in self._cache else 1)
 
     def __getitem__(self, k):
         if isinstance(k, slice):
@@ -62,17 +80,22 @@ class _LazyHiddenStates:
         k = int(k)
         if k < 0:
             k += len(self)
-        if not 0 <= k <= self._n:
+        if not 0 <= k < len(self):
             raise IndexError("tuple index out of range")
+        if k in self._cache:
+            return self._cache[k]
         m, (B, S) = self._m, self._shape
+        if m.engine is not self._engine or m.engine.weights_epoch() != self._epoch:
+            raise RuntimeError("outputs['hidden_states']: the model's weights changed (or it moved to another device) after the forward these "
+                               "states belong to; run custom_forward(return_output=True) again")
         ids, mask, pix, sz = self._args
-        last = k == self._n
-        m.engine.set_layer_limits(-1, -1 if last else k)
+        m.engine.set_layer_limits(-1, k)
         try:
-            m.engine.forward(ids, mask, pix, sz, training=False, no_final_norm=not last, keep_hidden_states=True)
-            return m.engine.last_hidden_state(B, S, no_final_norm=not last)
+            m.engine.forward(ids, mask, pix, sz, training=False, no_final_norm=True, keep_hidden_states=True)
+            self._cache[k] = m.engine.last_hidden_state(B, S, no_final_norm=True)
         finally:
             m.engine.set_layer_limits(-1, -1)
+        return self._cache[k]
 
     def __iter__(self):
         return (self[i] for i in range(len(self)))
@@ -83,9 +106,17 @@ class RewardModel:
                  max_batch: int = 32, max_seq: int = 2816, max_crops: int = 17, operand_dtype: str = "f16x2f8",
                  layer_id: int = 32, mean_hidden_state=None, max_patches: int = 0, synth_profile: int = 0,
                  calibrate: bool = True, parity_budget: float = 1.5e-4, operand_form: Optional[str] = None,
-                 check_inputs: str = "eager", reward_dtype: Optional[torch.dtype] = None):
+                 check_inputs: str = "eager", reward_dtype: Optional[torch.dtype] = None, vision_layer_id: int = -1):
         if weights is None and synth_seed is None:
             raise ValueError("RewardModel needs weights or a synth_seed")
+        # rw_model:296,353: the SkipCA key / value source is hidden_states[vision_layer_id][:, :V_max]; -1 (the reference's default, which
+        # no caller or script of the reference overrides) = the zero-padded projected image tokens.  Any other index would read the
+        # first V_max TOKEN positions of a decoder state instead -- not served (the engine keeps one residual stream and folds W_k / W_v
+        # onto the image rows); refused here rather than silently scored with the default source.
+        if int(vision_layer_id) != -1:
+            raise NotImplementedError(f"vision_layer_id={vision_layer_id}: only -1 (hidden_states[-1] = vision_embeds, the reference's default, "
+                                      "rw_model_general_preference.py:296,353) is served")
+        self.vision_layer_id = -1
         # rw_model:349-352: layer_id == 32 (the literal) -> last_hidden_state, else hidden_states[layer_id] = the input of decoder
         # layer `layer_id` (un-normed residual stream; index `layers` is the final-norm output again).  phi3v branch only.
         if not (layer_id == 32 or 0 <= layer_id <= cfg.layers):
@@ -371,7 +402,8 @@ class RewardModel:
         the reward was read from."""
         if self.training and not self.is_general_preference and not self.mean_hidden_state:
             reward = reward.squeeze(-1)
-        if self.reward_dtype is not None:
+        if self.reward_dtype is not None and not self._in_probe:
+            # (never inside the operand-form check: its budget, 1.5e-4, is far below a bf16 ulp of the rewards it compares)
             reward = reward.to(self.reward_dtype)
         if not return_output:
             return reward, None
@@ -388,7 +420,8 @@ class RewardModel:
         out = _Outputs({"last_hidden_state": self.engine.last_hidden_state(B, S, no_final_norm=False),
                         "last_hidden_state_at_reward_token": hl})
         if lazy_args is not None:
-            out["hidden_states"] = _LazyHiddenStates(self, lazy_args, shape)
+            out["hidden_states"] = _LazyHiddenStates(self, lazy_args, shape, out["last_hidden_state"],
+                                                     self.engine.vision_embeds(B) if self.model_type == "phi3v" else None)
         return reward, out
 
     def _custom_forward_qwen(self, inputs_batch, return_output):

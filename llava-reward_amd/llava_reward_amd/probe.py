@@ -1,15 +1,21 @@
-"""The seeded probe batch behind the operand-form self-check that `RewardModel.to('cuda')` runs (model.py `_lock_operand_form`).
+"""The seeded probe rows behind the operand-form self-check that `RewardModel.to('cuda')` runs (model.py `_lock_operand_form`).
 
 No reference counterpart: the reference runs one operand type (bf16 on the GPU, fp32 on the CPU).  Here the default parity form
 (f16 hi + e4m3 residual passes, ~15 bits per operand) is only as good as the loaded weights let it be -- weight sets that amplify
 operand rounding (massive activations, large norm gains: what trained checkpoints show) need the strict form (16-bit residual
-passes, 22 bits) -- so the engine measures the distance between the two forms on the weights it was given, on rows that are a
-function of (model geometry, engine capacity) ALONE: every rank, every shard and every batch size of one deployment sees the same
-rows and therefore locks the same form.
+passes, 22 bits) -- so the engine measures the distance between the two forms on the weights it was given.
 
-Rows: `PROBE_ROWS` full-length rows in chunks of `PROBE_CHUNK` (the largest crop grid / image that fits the engine's capacity,
-captions of 128 / 96 / 64 / 33 and 112 / 80 / 48 / 17 tokens: left padding and the long-sequence regime are both inside), token ids from the counter hash of synth.py, pixels filled in
-HBM by the same hash (lr_op_synth_fill), std 1 like CLIP-normalised images."""
+Round 6: the rows are a function of the MODEL alone.  They come in fixed TIERS -- a tier is a fixed batch: one image geometry, captions
+of fixed lengths left-padded to the tier's common length (left padding and the long-sequence regime are both inside), token ids from the
+counter hash of synth.py, pixels filled in HBM by the same hash (lr_op_synth_fill), std 1 like CLIP-normalised images -- and an engine
+scores EVERY tier that fits its capacity (max_crops / max_seq / max_patches) and skips the others whole; nothing is reshaped to fit
+(until round 5 the largest geometry that fitted was chosen and the captions were cut to the room left, so two deployments of one
+checkpoint could probe different rows: `ref_llava_full_bt` locked `strict-vision` on a test engine and `default` on the bench's).
+A tier is scored in chunks of min(max_batch, PROBE_CHUNK) rows: slices of the one fixed batch, and a row's reward does not depend on
+the rows beside it (same S, same V_max inside a tier), so the chunking is invisible in the numbers.  Two engines that fit the same tiers
+therefore measure the same distances bit for bit (tests/test_gpu_forward.py::test_probe_rows_do_not_depend_on_the_engine_capacity);
+an engine too small for the large tiers decides on the rows it could ever be asked to score.  `PROBE_MIN_SEQ[model_type]` = the
+max_seq that admits every tier (what bench.py and the golden tests size their engines to)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -22,9 +28,17 @@ from . import _lib as L
 from . import synth
 
 PROBE_SEED = 0x5EED0F0A
-PROBE_ROWS = 8                   # round 5: 8 rows (4 until then): the decision is the MAX over the rows, and rows are draws of one noise
-PROBE_CHUNK = 4                  # scored 4 at a time: the rows (their left padding) do not depend on max_batch once it is >= 4
+PROBE_ROWS = 8                   # rows of the first (largest) tier; the decision is the MAX over all scored rows: rows are draws of one noise
+PROBE_CHUNK = 4                  # rows per forward (slices of a tier's fixed batch)
 PROBE_CAPTIONS = (128, 96, 64, 33, 112, 80, 48, 17)
+# (geometry, rows) per tier, largest first.  phi3v: HD crop grid; llava: original image (h, w); qwen: patch grid per image
+PHI_TIERS = (((4, 4), 8), ((2, 2), 4), ((1, 1), 4))
+LLAVA_TIERS = (((672, 672), 4), ((336, 336), 8), ((200, 200), 4))
+QWEN_TIERS = (((32, 32), 8), ((16, 16), 4), ((8, 8), 4))
+_FRAME = 5                        # tokens of a row besides image slots and caption (synth.*_synth_batch)
+PROBE_MIN_SEQ = {"phi3v": synth.num_img_tokens(336 * 4, 336 * 4) + _FRAME + max(PROBE_CAPTIONS),
+                 "llava": synth.llava_geometry(672, 672)[6] + _FRAME + max(PROBE_CAPTIONS),
+                 "qwen": 32 * 32 // 4 + _FRAME + max(PROBE_CAPTIONS)}
 
 
 def _fill(lib, t: torch.Tensor, name: str) -> None:
@@ -37,81 +51,64 @@ def _fill(lib, t: torch.Tensor, name: str) -> None:
         raise RuntimeError(f"lr_op_synth_fill failed ({rc})")
 
 
-def _captions(room: int, n: int) -> List[int]:
-    return [max(1, min(c, room)) for c in PROBE_CAPTIONS[:n]] + [max(1, min(17, room))] * max(0, n - len(PROBE_CAPTIONS))
-
-
 def _chunks(rows: int, cap: int):
     cap = max(1, min(rows, cap))
     return [(i, min(i + cap, rows)) for i in range(0, rows, cap)]
 
 
 def probe_batches(model, rows: int = PROBE_ROWS) -> List[Dict[str, object]]:
-    """-> a list of custom_forward keyword dicts covering `rows` probe rows in chunks of at most max_batch rows."""
+    """-> custom_forward keyword dicts covering every probe tier that fits the engine (`rows` caps the rows taken from each tier)."""
     cfg, opts, dev = model.config, model._opts, model.device
     lib = L.load()
     mb, ms = int(opts["max_batch"]), int(opts["max_seq"])
     out = []
+
+    def pixels(shape_of_row, lo, hi, tier, cat=False):
+        per = [torch.empty(*shape_of_row, device=dev, dtype=torch.float32) for _ in range(lo, hi)]
+        for r, t in zip(range(lo, hi), per):
+            _fill(lib, t, f"probe.pixel_values.{r}" if tier == 0 else f"probe.t{tier}.pixel_values.{r}")
+        return torch.cat(per, dim=0) if cat else torch.stack(per, dim=0)
+
     if model.model_type == "phi3v":
-        grid = None
-        for hc, wc in ((4, 4), (3, 4), (3, 3), (2, 3), (2, 2), (1, 2), (1, 1)):
-            if hc * wc + 1 <= int(opts["max_crops"]) and synth.num_img_tokens(336 * hc, 336 * wc) + 5 + 1 <= ms:
-                grid = (hc, wc)
-                break
-        if grid is None:
-            return []
-        room = ms - (synth.num_img_tokens(336 * grid[0], 336 * grid[1]) + 5)
-        caps = _captions(room, rows)
-        b = synth.synth_batch(cfg, PROBE_SEED, caps, grid, with_pixels=False)
-        ncr = grid[0] * grid[1] + 1
-        for lo, hi in _chunks(rows, min(mb, PROBE_CHUNK)):
-            pix = torch.empty(hi - lo, ncr, 3, cfg.clip.image, cfg.clip.image, device=dev, dtype=torch.float32)
-            for r in range(lo, hi):
-                _fill(lib, pix[r - lo], f"probe.pixel_values.{r}")
-            out.append(dict(input_ids=torch.from_numpy(b["input_ids"][lo:hi]).to(dev), attention_mask=torch.from_numpy(b["attention_mask"][lo:hi]).to(dev),
-                            pixel_values=pix, image_sizes=torch.from_numpy(b["image_sizes"][lo:hi])))
+        for tier, (grid, n) in enumerate(PHI_TIERS):
+            n = min(n, rows)
+            caps = list(PROBE_CAPTIONS[:n])
+            ncr = grid[0] * grid[1] + 1
+            if ncr > int(opts["max_crops"]) or synth.num_img_tokens(336 * grid[0], 336 * grid[1]) + _FRAME + max(caps) > ms:
+                continue
+            b = synth.synth_batch(cfg, PROBE_SEED + tier, caps, grid, with_pixels=False)
+            for lo, hi in _chunks(n, min(mb, PROBE_CHUNK)):
+                out.append(dict(input_ids=torch.from_numpy(b["input_ids"][lo:hi]).to(dev), attention_mask=torch.from_numpy(b["attention_mask"][lo:hi]).to(dev),
+                                pixel_values=pixels((ncr, 3, cfg.clip.image, cfg.clip.image), lo, hi, tier), image_sizes=torch.from_numpy(b["image_sizes"][lo:hi])))
         return out
     if model.model_type == "llava":
-        size = None
-        for h, w in ((672, 672), (336, 672), (336, 336), (200, 200), (100, 100)):
-            g = synth.llava_geometry(h, w, cfg.pinpoints, cfg.clip.image, cfg.clip.grid)
-            if 1 + g[0] * g[1] <= int(opts["max_crops"]) and g[6] + 5 + 1 <= ms:
-                size = (h, w)
-                break
-        if size is None:
-            return []
-        g = synth.llava_geometry(size[0], size[1], cfg.pinpoints, cfg.clip.image, cfg.clip.grid)
-        ncr = 1 + g[0] * g[1]
-        caps = _captions(ms - (g[6] + 5), rows)
-        b = synth.llava_synth_batch(cfg, PROBE_SEED, caps, [size] * rows, with_pixels=False)
-        for lo, hi in _chunks(rows, min(mb, PROBE_CHUNK)):
-            pix = torch.empty(hi - lo, ncr, 3, cfg.clip.image, cfg.clip.image, device=dev, dtype=torch.float32)
-            for r in range(lo, hi):
-                _fill(lib, pix[r - lo], f"probe.pixel_values.{r}")
-            out.append(dict(inputs_batch=dict(input_ids=torch.from_numpy(b["input_ids"][lo:hi]).to(dev),
-                                              attention_mask=torch.from_numpy(b["attention_mask"][lo:hi]).to(dev), pixel_values=pix,
-                                              image_sizes=torch.from_numpy(b["image_sizes"][lo:hi]))))
+        for tier, (size, n) in enumerate(LLAVA_TIERS):
+            n = min(n, rows)
+            caps = list(PROBE_CAPTIONS[:n])
+            g = synth.llava_geometry(size[0], size[1], cfg.pinpoints, cfg.clip.image, cfg.clip.grid)
+            ncr = 1 + g[0] * g[1]
+            if ncr > int(opts["max_crops"]) or g[6] + _FRAME + max(caps) > ms:
+                continue
+            b = synth.llava_synth_batch(cfg, PROBE_SEED + tier, caps, [size] * n, with_pixels=False)
+            for lo, hi in _chunks(n, min(mb, PROBE_CHUNK)):
+                out.append(dict(inputs_batch=dict(input_ids=torch.from_numpy(b["input_ids"][lo:hi]).to(dev),
+                                                  attention_mask=torch.from_numpy(b["attention_mask"][lo:hi]).to(dev),
+                                                  pixel_values=pixels((ncr, 3, cfg.clip.image, cfg.clip.image), lo, hi, tier),
+                                                  image_sizes=torch.from_numpy(b["image_sizes"][lo:hi]))))
         return out
     # qwen: one image of g x g patches per row (g even)
     v = cfg.vision
     mp = int(model.engine.max_patches) if model.engine is not None else int(opts.get("max_patches", 0))
-    grid = None
-    for gsz in (32, 24, 16, 12, 8, 4):
-        per_row = gsz * gsz
-        chunk = max(1, min(rows, mb, PROBE_CHUNK))
-        if per_row * chunk <= mp and per_row // v.merge_unit + 5 + 1 <= ms:
-            grid = (gsz, gsz)
-            break
-    if grid is None:
-        return []
-    caps = _captions(ms - (grid[0] * grid[1] // v.merge_unit + 5), rows)
-    b = synth.qwen_synth_batch(cfg, PROBE_SEED, caps, grid, with_pixels=False)
-    per_row = grid[0] * grid[1]
-    for lo, hi in _chunks(rows, min(mb, PROBE_CHUNK)):
-        pix = torch.empty((hi - lo) * per_row, v.patch_dim, device=dev, dtype=torch.float32)
-        for r in range(lo, hi):
-            _fill(lib, pix[(r - lo) * per_row:(r - lo + 1) * per_row], f"probe.pixel_values.{r}")
-        out.append(dict(inputs_batch=dict(input_ids=torch.from_numpy(b["input_ids"][lo:hi]).to(dev),
-                                          attention_mask=torch.from_numpy(b["attention_mask"][lo:hi]).to(dev), pixel_values=pix,
-                                          image_grid_thw=torch.from_numpy(b["image_grid_thw"][lo:hi]))))
+    for tier, (grid, n) in enumerate(QWEN_TIERS):
+        n = min(n, rows)
+        caps = list(PROBE_CAPTIONS[:n])
+        per_row = grid[0] * grid[1]
+        if per_row > mp or per_row // v.merge_unit + _FRAME + max(caps) > ms:
+            continue
+        b = synth.qwen_synth_batch(cfg, PROBE_SEED + tier, caps, grid, with_pixels=False)
+        for lo, hi in _chunks(n, min(mb, PROBE_CHUNK, mp // per_row)):
+            out.append(dict(inputs_batch=dict(input_ids=torch.from_numpy(b["input_ids"][lo:hi]).to(dev),
+                                              attention_mask=torch.from_numpy(b["attention_mask"][lo:hi]).to(dev),
+                                              pixel_values=pixels((per_row, v.patch_dim), lo, hi, tier, cat=True),
+                                              image_grid_thw=torch.from_numpy(b["image_grid_thw"][lo:hi]))))
     return out

@@ -39,7 +39,8 @@ def _form_args(args):
     if isinstance(rd, str):
         rd = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": None, "float32": None, "fp16": torch.float16}[rd]
     return dict(operand_form=getattr(args, "operand_form", None), check_inputs=getattr(args, "check_inputs", "eager"),
-                parity_budget=getattr(args, "parity_budget", 1.5e-4), reward_dtype=rd)
+                parity_budget=getattr(args, "parity_budget", 1.5e-4), reward_dtype=rd,
+                vision_layer_id=getattr(args, "vision_layer_id", -1))          # rw_model:296 (only -1, its default, is served: RewardModel refuses others)
 
 
 def load_reward_adaptor(args, model_type, reward_config_path, load_tokenizer=False):

@@ -156,21 +156,21 @@ def hd_project(W, feats: torch.Tensor, image_sizes, cfg, opr=Ident):
 # --------------------------------------------------------------------------------------- decoder
 def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
     """PHI:377-391 / RW:19-33 Phi3RMSNorm."""
-    var = x.float().pow(2).mean(-1, keepdim=True)
+    var = x.to(torch.promote_types(x.dtype, torch.float32)).pow(2).mean(-1, keepdim=True)      # (.float() for fp32 / bf16 inputs)
     return w * (x * torch.rsqrt(var + eps))
 
 
-def su_rope_cos_sin(position_ids: torch.Tensor, cfg, seq_len: Optional[int] = None):
+def su_rope_cos_sin(position_ids: torch.Tensor, cfg, seq_len: Optional[int] = None, dtype=torch.float32):
     """PHI:446-476 Phi3SuScaledRotaryEmbedding.forward: short factors unless seq_len > original max; the attention layers pass
     seq_len = kv_seq_len = the padded length S (PHI:673, :1081; use_cache=False), so `max(position_ids)+1` (PHI:448) is only the
     fallback for callers that pass none; cos/sin of cat(freqs,freqs) scaled by sqrt(1 + ln(max_pos/orig)/ln(orig))."""
     hd = cfg.head_dim
     seq_len = seq_len or int(position_ids.max()) + 1
     fac = cfg.long_factor if seq_len > cfg.orig_max_pos else cfg.short_factor
-    ext = torch.tensor(fac, dtype=torch.float32)
-    inv_shape = torch.arange(0, hd, 2, dtype=torch.int64).float() / hd
+    ext = torch.tensor(fac, dtype=dtype)
+    inv_shape = torch.arange(0, hd, 2, dtype=torch.int64).to(dtype) / hd
     inv_freq = 1.0 / (ext * cfg.rope_theta ** inv_shape)
-    freqs = position_ids[:, :, None].float() * inv_freq[None, None, :]
+    freqs = position_ids[:, :, None].to(dtype) * inv_freq[None, None, :]
     emb = torch.cat((freqs, freqs), dim=-1)
     scale = cfg.max_pos / cfg.orig_max_pos
     sf = 1.0 if scale <= 1.0 else math.sqrt(1 + math.log(scale) / math.log(cfg.orig_max_pos))
@@ -209,7 +209,7 @@ def decoder_layer(W, l: int, x, mask4d, cos, sin, cfg, opr=Ident):
     q = q * c + rotate_half(q) * s                       # PHI:529-553
     k = k * c + rotate_half(k) * s
     att = torch.matmul(opr(q), opr(k).transpose(2, 3)) / math.sqrt(hd) + mask4d
-    att = torch.softmax(att, dim=-1, dtype=torch.float32)
+    att = torch.softmax(att, dim=-1, dtype=torch.promote_types(att.dtype, torch.float32))
     o = torch.matmul(opr(att), opr(v)).transpose(1, 2).reshape(B, S, D)
     x = x + proj(W, p + "self_attn.o_proj", o, None, opr)
     h = rms_norm(x, W[p + "post_attention_layernorm.weight"], cfg.rms_eps)
@@ -223,14 +223,16 @@ def decoder_layer(W, l: int, x, mask4d, cos, sin, cfg, opr=Ident):
 @torch.no_grad()
 def custom_forward(W: Dict[str, torch.Tensor], cfg, input_ids, attention_mask, pixel_values, image_sizes,
                    training: bool = False, opr: Callable = Ident, taps: Optional[dict] = None, layer_id: int = 32,
-                   mean_hidden_state: bool = False) -> torch.Tensor:
+                   mean_hidden_state: bool = False, dtype=torch.float32) -> torch.Tensor:
     """RW:334-448 CustomRewardModel.custom_forward, phi3v branch; layer_id == 32 -> last_hidden_state, else
     hidden_states[layer_id] (RW:349-352; PHI:1467-1505: entry k < L is the input of decoder layer k, entry L the final-norm
     output); mean_hidden_state unset.  Returns reward [B,1] (BT) or [B,d] (GPM), fp32.
-    `taps`, if given, receives intermediate tensors keyed by stage name."""
+    `taps`, if given, receives intermediate tensors keyed by stage name.
+    `dtype=torch.float64` (with W = UpcastWeights(...)) evaluates the same function in double precision: the yardstick that says how
+    far the reference's OWN fp32 arithmetic sits from the exact result on a row (tests/golden/make_fp64_fixture.py)."""
     input_ids = torch.as_tensor(input_ids)
     attention_mask = torch.as_tensor(attention_mask)
-    pixel_values = torch.as_tensor(pixel_values, dtype=torch.float32)
+    pixel_values = torch.as_tensor(pixel_values, dtype=torch.float32).to(dtype)
     B, S = input_ids.shape
     D = cfg.hidden
     # RW:344-345
@@ -246,7 +248,7 @@ def custom_forward(W: Dict[str, torch.Tensor], cfg, input_ids, attention_mask, p
     counts = neg.sum(dim=1).tolist()                      # PHI:242 bincount(positions[0])
     assert sum(counts) == proj.shape[0], "image-slot count != projected image tokens (PHI:247 index_put)"
     vmax = max(counts)
-    ev = torch.zeros(B, vmax, D)
+    ev = torch.zeros(B, vmax, D, dtype=dtype)
     off = 0
     for b, n in enumerate(counts):                        # PHI:243-245 split + zero-pad
         ev[b, :n] = proj[off:off + n]
@@ -257,7 +259,7 @@ def custom_forward(W: Dict[str, torch.Tensor], cfg, input_ids, attention_mask, p
         taps["clip_out"], taps["proj"], taps["embeds"] = feats, proj, x.clone()
     # PHI:1468-1500 decoder stack + final norm
     mask4d = causal_padding_mask(attention_mask)
-    cos, sin = su_rope_cos_sin(position_ids, cfg, seq_len=S)
+    cos, sin = su_rope_cos_sin(position_ids, cfg, seq_len=S, dtype=dtype)
     states = []
     for l in range(cfg.layers):
         states.append(x)
@@ -312,3 +314,19 @@ def f16_round(x: torch.Tensor) -> torch.Tensor:
 
 def weights_to_torch(W_np) -> Dict[str, torch.Tensor]:
     return {k: torch.from_numpy(v) for k, v in W_np.items()}
+
+
+class UpcastWeights(dict):
+    """fp32 weights handed out in `dtype` one tensor at a time (a full-size model is 16 GB in fp32: the fp64 run never holds more than
+    one up-cast tensor).  For custom_forward(..., dtype=torch.float64)."""
+
+    def __init__(self, W, dtype=torch.float64):
+        super().__init__(W)
+        self._dtype = dtype
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        return v.to(self._dtype) if torch.is_tensor(v) and v.is_floating_point() else v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default

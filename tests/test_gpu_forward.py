@@ -31,11 +31,17 @@ TOL_F16 = 1e-3
 TOL_X2 = 1e-4
 TOL_X8 = 3e-4          # "f16x2f8": residual pass of the deep-pipelined GEMMs in e4m3 (measured <= 8e-5 on the full-size rows)
 TOL_BF16 = 8e-3
-# Outlier-bearing full-size rows (synth.PROFILE_OUTLIER: |reward| up to 3.8, every rounding amplified 15-25x): numerically EQUIVALENT
-# builds of the strict form -- other GEMM tile shapes, other fp32 roundings inside the attention softmax -- land 3e-5 .. 5.2e-4 from the
-# reference on the GPM row (14 draws, rms 2.7e-4: profiles/r5_outlier_noise_floor.log); the reference's own fp32 arithmetic is one such
-# draw.  Until round 5 these rows were held to 3e-4, which the builds of the time met by their draw (1.07e-4).  Still inside the 1e-3 bar.
-TOL_OUTLIER = 8e-4
+# Outlier-bearing full-size rows (synth.PROFILE_OUTLIER: |reward| up to 3.8, every rounding amplified 15-25x).  Round 6 settled whose
+# error the distance to the reference is there: tests/golden/fp64_full_rows.json holds the oracle's DOUBLE-precision reward of these rows
+# (make_fp64_fixture.py), and on the GPM row the REFERENCE's own fp32 arithmetic sits 2.1e-4 from it (|reference_fp32 - fp64|; the fp32
+# oracle, another draw of the same noise: 3.1e-5), while the HIP strict form sits 1.5e-5 .. 1.0e-4 from the fp64 value (two GEMM tile shapes,
+# profiles/r6_outlier_fp64.log).  So |hip - reference| <= 3e-4 on these rows is mostly the reference's noise (2.1e-4) plus ours (<= 1.1e-4),
+# and the sharper statement is the one against fp64: the strict form within TOL_FP64 of it.  (Round 5 had widened the bound to 8e-4
+# after the attention kernels' lazy softmax maximum moved the strict form to 5.2e-4 from the reference / 3.1e-4 from fp64: the strict
+# stages run the exact maximum again -- AttnParams::lazy_t = 0 -- and the 3e-4 bound is back.)
+TOL_OUTLIER = 3e-4
+TOL_FP64 = 1.5e-4      # |hip - fp64 oracle| on the rows of fp64_full_rows.json, strict form and the form .to('cuda') locks
+FP64_ROWS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fp64_full_rows.json")))
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -131,7 +137,7 @@ def test_operand_form_is_locked_on_the_weights_by_to_cuda():
         info = m.form_info
         got = _fwd(m, batch)
         print(f"[form probe, profile {profile}] {info}; err {(got - ref).abs().max().item():.2e}")
-        assert info["source"] == "probe" and info["rows"] == probe_mod.PROBE_ROWS == 8 and info["seconds"] > 0 and info["form"] == m.operand_form and info["default_vs_strict"] < 1.0
+        assert info["source"] == "probe" and info["rows"] == 8 and info["seconds"] > 0      # (this engine fits the (2, 2) and (1, 1) tiers: 4 + 4 rows) and info["form"] == m.operand_form and info["default_vs_strict"] < 1.0
         assert (got - ref).abs().max().item() < TOL_X8
         if profile == 0:
             assert m.operand_form == "default" and info["default_vs_strict"] < m.parity_budget
@@ -166,6 +172,24 @@ def test_operand_form_is_locked_on_the_weights_by_to_cuda():
             assert torch.equal(again, got)
     off = _model(cfg, seed, "f16x2f8", upload=False, calibrate=False)
     assert off.form_info is None and off.operand_form == "default"
+
+
+def test_probe_rows_do_not_depend_on_the_engine_capacity():
+    """Round 6: the probe rows are fixed tiers (probe.py) -- an engine scores every tier that fits and reshapes nothing -- so two engines of
+    different capacity (batch 1 / 6, other max_seq and max_crops, hence other chunkings of the same fixed batches) on ONE weight set
+    measure the same distances, bit for bit, and lock the same form; an engine too small for a tier skips it whole."""
+    cfg = synth.tiny_config(hidden=1024, intermediate=2048, heads=16, layers=3)
+    seed = 29
+    for profile in (0, synth.PROFILE_OUTLIER):
+        a = _model(cfg, seed, "f16x2f8", upload=False, max_batch=1, max_seq=900, max_crops=5, profile=profile)
+        b = _model(cfg, seed, "f16x2f8", upload=False, max_batch=6, max_seq=1500, max_crops=6, profile=profile)
+        print(f"[probe capacity, profile {profile}] {a.form_info['distance_to_strict']} | {b.form_info['distance_to_strict']}")
+        assert a.form_info["rows"] == b.form_info["rows"] == 8
+        assert a.form_info["distance_to_strict"] == b.form_info["distance_to_strict"] and a.operand_form == b.operand_form
+        small = _model(cfg, seed, "f16x2f8", upload=False, max_batch=2, max_seq=512, max_crops=2, profile=profile)      # only the (1, 1) tier fits
+        assert small.form_info["rows"] == 4
+    assert probe_mod.PROBE_MIN_SEQ == {"phi3v": 2642, "llava": 3061, "qwen": 389}
+    assert [len(x["input_ids"]) for x in probe_mod.probe_batches(a)] == [1] * 8 and [len(x["input_ids"]) for x in probe_mod.probe_batches(b)] == [4, 4]
 
 
 def test_operand_form_pin_failed_probe_and_deferred_input_check(monkeypatch):
@@ -492,13 +516,22 @@ def test_reference_golden_full_size(path, dtype):
     ref = torch.tensor(g["reward"], dtype=torch.float32)
     B, S = batch["input_ids"].shape
     outlier = bool(g.get("weight_profile", 0) & synth.PROFILE_OUTLIER)
-    m = _model(cfg, g["seed"], dtype, upload=False, max_batch=2 * B, max_seq=S, max_crops=17, profile=g.get("weight_profile", 0))
+    # (max_seq admits every probe tier, as bench.py's engines do: the locked form is then the one any full-size deployment locks)
+    m = _model(cfg, g["seed"], dtype, upload=False, max_batch=2 * B, max_seq=max(S, probe_mod.PROBE_MIN_SEQ["phi3v"]), max_crops=17, profile=g.get("weight_profile", 0))
     got = _fwd(m, batch).reshape(ref.shape)
     err = (got - ref).abs().max().item()
     print(f"[{g['name']} {dtype}] reward hip={got.flatten().tolist()} ref={ref.flatten().tolist()} err={err:.3e}")
+    f64 = FP64_ROWS.get(g["name"])
+    err64 = None
+    if f64 is not None and dtype != "f16":
+        # beside the reference's fp32 reward: the double-precision value of the same function (ORACLE fixture, make_fp64_fixture.py)
+        err64 = (got.double() - torch.tensor(f64["reward_fp64"], dtype=torch.float64).reshape(ref.shape)).abs().max().item()
+        print(f"[{g['name']} {dtype}] |hip - fp64 oracle| = {err64:.3e}   (|reference_fp32 - fp64| = {f64['reference_minus_fp64']:.3e})")
+        assert err64 < TOL_FP64
     if dtype == "f16x2":
         # strict parity form: measured 2.6e-6 / 5.5e-6 on benign rows.  On the outlier-bearing rows (|reward| up to 3.8, every rounding
-        # amplified 15-25x) the fp32 summation order itself shows: 5e-6 (BT row), 1.07e-4 (GPM row) -- held to 3e-4 there
+        # amplified 15-25x) the fp32 summation order itself shows: 5e-6 (BT row), 1.07e-4 (GPM row, where the reference itself is
+        # 2.1e-4 from the fp64 value and this form 1.0e-4) -- held to 3e-4 there
         assert err < (TOL_OUTLIER if outlier else TOL_X2)
     elif dtype == "f16x2f8" and outlier:
         # The outlier-bearing weight set amplifies ANY operand rounding 15-25x (single-pass f16 lands 1.3e-2 from the strict form there

@@ -397,6 +397,85 @@ def test_attention_split_operand_matches_fp32(lib, hd, causal, group, S):
     assert err < 5e-6 * ref[valid].abs().max().item(), err
 
 
+@pytest.mark.parametrize("pingpong", [1, 0], ids=["pingpong", "plain-loop"])
+@pytest.mark.parametrize("hd,causal,group", [(96, True, 1), (64, False, 1), (128, True, 4)])
+def test_attention_lazy_maximum_on_ramped_scores(lib, monkeypatch, hd, causal, group, pingpong):
+    """The lazy reference maximum's OWN branch (attention.hip: a row's reference moves only when the new maximum exceeds it by more than
+    AttnParams::lazy_t; alpha != 1 rescales, softmax weights up to 2^lazy_t).  N(0, 0.8) data never reaches it after the first key
+    tile, so here the scores RAMP along the key axis: one head-dim coordinate carries +3 log2 units per 64-key tile and one jump of +20
+    at key 700, i.e. the running maximum moves in every tile, sometimes by less than the threshold (reference kept, weights > 1) and
+    sometimes by more (reference moved, outputs rescaled), on top of N(0, 0.8) noise.  Thresholds 0 (exact maximum: what the engine
+    runs in strict stages), 3 and 8 (default stages) against fp64 softmax attention (the reference's softmax, modeling_phi3_v.py:685-701):
+    the lazy forms within 2e-6 of the exact form's own error (whose floor here is the fp32 rounding of scores this large); threshold 0 must give lr_op_attention_split_ex's bits whatever the
+    schedule (ping-pong / plain per-tile loop), and out-of-range thresholds are refused."""
+    monkeypatch.setenv("LR_ATT_PINGPONG", str(pingpong))
+    code, tdt = L.LR_DT_F16, torch.float16
+    B, H, S = 2, 4, 1300
+    Hkv = H // group
+    wq, wkv = H * hd, Hkv * hd
+    W = wq + 2 * wkv
+    scale = hd ** -0.5
+    qkv32 = rnd((B * S, W), 91, 0.8)
+    j = torch.arange(S, device="cuda", dtype=torch.float32)
+    ramp = 3.0 * torch.floor(j / 64) + 20.0 * (j >= 700).float()            # log2 units
+    q0 = 4.0
+    v = qkv32.view(B, S, W)
+    for h in range(H):
+        v[:, :, h * hd] = q0                                                  # the carrier coordinate of every query head
+    for h in range(Hkv):
+        v[:, :, wq + h * hd] = (ramp / (q0 * scale * 1.4426950408889634))[None, :]
+    hi, lo = _split(qkv32, tdt)
+    qkv2 = torch.cat([hi, lo], dim=1).contiguous()
+    mask = torch.ones(B, S, dtype=torch.int64, device="cuda")
+    mask[1, :37] = 0
+    kmin = torch.tensor([0, 37], dtype=torch.int32, device="cuda")
+    f = (hi.double() + lo.double()).view(B, S, W)                             # what the kernel is given: the 22-bit operands
+    q = f[..., :wq].view(B, S, H, hd).transpose(1, 2)
+    k = f[..., wq:wq + wkv].view(B, S, Hkv, hd).transpose(1, 2).repeat_interleave(group, dim=1)
+    vv = f[..., wq + wkv:].view(B, S, Hkv, hd).transpose(1, 2).repeat_interleave(group, dim=1)
+    sc = q @ k.transpose(2, 3) * scale
+    if causal:
+        ok = torch.tril(torch.ones(S, S, dtype=torch.bool, device="cuda"))[None, None] & (mask[:, None, None, :] != 0)
+        sc = sc.masked_fill(~ok, float("-inf"))
+    ref = (torch.softmax(sc, dim=-1) @ vv).transpose(1, 2).reshape(B * S, wq).float()
+    valid = (mask.reshape(-1) != 0) if causal else torch.ones(B * S, dtype=torch.bool, device="cuda")
+    outs, errs = {}, {}
+    for thr in (0.0, 3.0, 8.0):
+        out = torch.zeros(B * S, 2 * wq, device="cuda", dtype=tdt)
+        rc = lib.lr_op_attention_split_ex(P(qkv2), P(qkv2), P(qkv2), P(out), P(mask if causal else None), P(kmin if causal else None),
+                                          2 * W, 2 * wq, 0, wq, wq + wkv, W, wq, B, S, H, hd, 1 if causal else 0, group, scale, thr, code, stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+        got = out[:, :wq].float() + out[:, wq:].float()
+        err = (got - ref).abs()[valid].max().item() / ref[valid].abs().max().item()
+        print(f"[lazy maximum hd={hd} causal={causal} pingpong={pingpong} threshold {thr}] rel err {err:.2e}")
+        errs[thr] = err
+        outs[thr] = out
+    # The exact form's own floor on THIS data is the fp32 rounding of the scores themselves: they reach 80 log2 units (|q . k| ~ 540),
+    # so one ulp of a score is 80 x 2^-23 ~ 1e-5 log2 units -> ~7e-6 on a softmax weight (measured 3 .. 7e-6; on N(0, 0.8) data,
+    # scores <= ~8, the same kernels sit below 5e-6: test_attention_split_operand_matches_fp32).  What is asserted of the lazy
+    # thresholds is that they add nothing visible on top of it.
+    assert errs[0.0] < 1.2e-5, errs
+    assert errs[3.0] < errs[0.0] + 2e-6 and errs[8.0] < errs[0.0] + 2e-6, errs
+    # the thresholds really differ in their arithmetic on this data (the branch under test is alive) ...
+    assert not torch.equal(outs[0.0], outs[8.0])
+    # ... lr_op_attention_split is the threshold-8 form, and the exact form does not depend on the schedule
+    o8 = torch.zeros(B * S, 2 * wq, device="cuda", dtype=tdt)
+    assert lib.lr_op_attention_split(P(qkv2), P(qkv2), P(qkv2), P(o8), P(mask if causal else None), P(kmin if causal else None),
+                                     2 * W, 2 * wq, 0, wq, wq + wkv, W, wq, B, S, H, hd, 1 if causal else 0, group, scale, code, stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o8[valid], outs[8.0][valid])
+    monkeypatch.setenv("LR_ATT_PINGPONG", str(1 - pingpong))
+    o0 = torch.zeros(B * S, 2 * wq, device="cuda", dtype=tdt)
+    assert lib.lr_op_attention_split_ex(P(qkv2), P(qkv2), P(qkv2), P(o0), P(mask if causal else None), P(kmin if causal else None),
+                                        2 * W, 2 * wq, 0, wq, wq + wkv, W, wq, B, S, H, hd, 1 if causal else 0, group, scale, 0.0, code, stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o0[valid], outs[0.0][valid])
+    for bad in (-1.0, 16.0, float("nan")):
+        assert lib.lr_op_attention_split_ex(P(qkv2), P(qkv2), P(qkv2), P(o0), P(None), P(None), 2 * W, 2 * wq, 0, wq, wq + wkv, W, wq, B, S, H, hd,
+                                            0, group, scale, bad, code, stream()) != 0
+
+
 @pytest.mark.parametrize("tile", [4, 6])
 @pytest.mark.parametrize("shape", [(8192, 8192, 512), (5284, 9216, 3072), (8192, 8192, 128)])
 def test_gemm_persistent_walk_many_tiles(lib, tile, shape):

@@ -204,7 +204,7 @@ def test_qwen_reference_golden_full_size(path, dtype):
     batch = synth.qwen_synth_batch(cfg, g["seed"], g["caption_lens"], [tuple(x) for x in g["grids"]])
     ref = torch.tensor(g["reward"], dtype=torch.float32)
     S = batch["input_ids"].shape[1]
-    m = _model(cfg, g["seed"], dtype, upload=False, max_batch=2, max_seq=S, max_patches=2 * int(batch["pixel_values"].shape[0]),
+    m = _model(cfg, g["seed"], dtype, upload=False, max_batch=2, max_seq=max(S, 389), max_patches=max(2 * int(batch["pixel_values"].shape[0]), 1024),      # (every probe tier fits: probe.PROBE_MIN_SEQ)
                profile=g.get("weight_profile", 0))
     got = _fwd(m, batch).reshape(ref.shape)
     err = (got - ref).abs().max().item()

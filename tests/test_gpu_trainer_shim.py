@@ -157,29 +157,44 @@ def test_score_candidates_in_memory_images():
 
 def test_outputs_hidden_states_on_demand_and_reward_dtype():
     """`outputs["hidden_states"]` (the reference returns the backbone's whole output object, rw_model_general_preference.py:346-353,
-    :422-425): a tuple-like of layers + 1 tensors recomputed on demand -- element 0 the embeddings, element k the stream entering layer k
-    (what layer_id = k reads), the last one the final norm (= last_hidden_state) -- against the oracle's taps; asking for them leaves the
-    model as it was.  reward_dtype=torch.bfloat16: the reference's GPU return dtype, the fp32 reward rounded once."""
+    :422-425) in the reference's layout: layers + 2 entries for phi3v -- element 0 the embeddings, element k the stream entering layer k
+    (what layer_id = k reads), element `layers` the final norm (= last_hidden_state), the LAST one `vision_embeds` [B, V_max, hidden]
+    (modeling_phi3_v.py:1505) -- against the oracle's taps; inner elements are recomputed on demand and cached; asking for them leaves the
+    model as it was; after a weight change an access raises.  reward_dtype=torch.bfloat16: the reference's GPU return dtype, the fp32
+    reward rounded once."""
     cfg = synth.tiny_config(layers=3)
     seed = 67
     m = RewardModel(cfg, synth_seed=seed, max_batch=4, max_seq=1024, max_crops=5, operand_dtype="f16x2").to("cuda").eval()
     W = orc.weights_to_torch(synth.make_weights(cfg, seed))
-    b = synth.synth_batch(cfg, seed, [5, 8, 3], (1, 1))
+    b = synth.synth_batch(cfg, seed, [5, 8, 3], [(1, 1), (1, 2), (1, 1)], max_crops=3)          # ragged crop grids: V_max zero padding
     tb = {k: torch.from_numpy(v) for k, v in b.items()}
     args = (tb["input_ids"].cuda(), tb["attention_mask"].cuda(), tb["pixel_values"].cuda(), tb["image_sizes"])
     r0, outs = m.custom_forward(*args, return_output=True)
     r0 = r0.clone()
     hs = outs["hidden_states"]
-    assert len(hs) == cfg.layers + 1
+    assert len(hs) == cfg.layers + 2
     taps = {}
     orc.custom_forward(W, cfg, tb["input_ids"], tb["attention_mask"], tb["pixel_values"], tb["image_sizes"], taps=taps)
     valid = tb["attention_mask"].bool()
     want = [taps["embeds"]] + [taps[f"layer{k}"] for k in range(cfg.layers - 1)] + [orc.rms_norm(taps[f"layer{cfg.layers - 1}"], W["model.norm.weight"], cfg.rms_eps)]
-    for k in range(len(hs)):
+    for k in range(cfg.layers + 1):
         got = hs[k].cpu()
         assert got.shape == want[k].shape
         assert (got - want[k])[valid].abs().max().item() < 2e-4 * want[k][valid].abs().max().item() + 1e-5, k
-    assert torch.equal(hs[-1], outs["last_hidden_state"]) and len(list(hs[1:3])) == 2
+    assert hs[1] is hs[1]                                              # cached: one extra forward per inner element, not one per access
+    assert torch.equal(hs[cfg.layers], outs["last_hidden_state"]) and torch.equal(hs[-2], outs["last_hidden_state"]) and len(list(hs[1:3])) == 2
+    # the last entry: the oracle's projected image tokens, zero-padded per sample to V_max (modeling_phi3_v.py:242-245)
+    counts = (tb["input_ids"] < 0).sum(dim=1).tolist()
+    ve = hs[-1].cpu()
+    assert ve.shape == (3, max(counts), cfg.hidden) and len(set(counts)) > 1
+    off = 0
+    for i, n in enumerate(counts):
+        assert (ve[i, :n] - taps["proj"][off:off + n]).abs().max().item() < 2e-4 * taps["proj"].abs().max().item() + 1e-5
+        assert not ve[i, n:].any()
+        off += n
+    # what rw_model:353 evaluates on the reference's object works on this one and gives that tensor
+    vision_embedding = outs["hidden_states"][-1][:, :outs["hidden_states"][-1].shape[1], :]
+    assert torch.equal(vision_embedding, hs[-1])
     with pytest.raises(IndexError):
         hs[len(hs)]
     # element k is what a model built with layer_id = k reads its reward from, bit for bit
@@ -190,6 +205,85 @@ def test_outputs_hidden_states_on_demand_and_reward_dtype():
         ok["hidden_states"]
     # the model is as it was: same rewards
     assert torch.equal(m.custom_forward(*args)[0], r0)
+    # other weights behind the same object: an element that is not cached yet refuses (it would be another model's state)
+    _, outs2 = m.custom_forward(*args, return_output=True)
+    m.engine.synth_weights(seed + 1, False, 0)
+    with pytest.raises(RuntimeError, match="weights changed"):
+        outs2["hidden_states"][2]
+    assert outs2["hidden_states"][-1] is not None                     # (taken at the forward itself)
     mb = RewardModel(cfg, synth_seed=seed, max_batch=4, max_seq=1024, max_crops=5, operand_dtype="f16x2", reward_dtype=torch.bfloat16).to("cuda").eval()
     rb = mb.custom_forward(*args)[0]
     assert rb.dtype == torch.bfloat16 and torch.equal(rb, r0.to(torch.bfloat16))
+    with pytest.raises(NotImplementedError, match="vision_layer_id"):
+        RewardModel(cfg, synth_seed=seed, vision_layer_id=3)
+
+
+def _fingerprint_err(fp, t):
+    """|t.flatten()[idx] - vals| / (1 + |vals|) of a make_goldens.py fingerprint (taken of the REFERENCE's tensor)."""
+    assert list(t.shape) == fp["shape"], (t.shape, fp["shape"])
+    a = t.reshape(-1)[torch.tensor(fp["idx"])].cpu()
+    v = torch.tensor(fp["vals"])
+    return ((a - v).abs() / (1.0 + v.abs())).max().item()
+
+
+@pytest.mark.parametrize("name", ["ref_small_bt_ca", "ref_small_bt_ca_ragged", "ref_full_b2_ragged_bt_ca"])
+def test_outputs_hidden_states_match_the_reference_held_fingerprints(name):
+    """The tuple a drop-in caller indexes, against what the REFERENCE's own tuple held (make_goldens.py fingerprints hs[0] = embeds,
+    hs[-1] = vision_embeds, outputs['last_hidden_state'] = final_norm and hs[l + 1] = layerL of the reference's run): same length
+    (layers + 2), same shapes -- [B, V_max, hidden] for the last entry, zero-padded rows included in the full-size ragged B = 2 case --
+    and the sampled values within 5e-5 (2e-4 at full depth), relative to 1 + |value|."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", name + ".json")))
+    cfg = synth.RewardConfig.from_json(g["config"])
+    grids = g["grids"]
+    grids = tuple(grids) if isinstance(grids[0], int) else [tuple(x) for x in grids]
+    b = synth.synth_batch(cfg, g["seed"], g["caption_lens"], grids, max_crops=g["max_crops"])
+    B, S = b["input_ids"].shape
+    full = cfg.layers > 4
+    m = RewardModel(cfg, synth_seed=g["seed"], max_batch=B, max_seq=max(S, 1024), max_crops=17 if full else 5, operand_dtype="f16x2").to("cuda").eval()
+    tb = {k: torch.from_numpy(v) for k, v in b.items()}
+    _, outs = m.custom_forward(tb["input_ids"].cuda(), tb["attention_mask"].cuda(), tb["pixel_values"].cuda(), tb["image_sizes"], return_output=True)
+    hs = outs["hidden_states"]
+    assert len(hs) == cfg.layers + 2
+    tol = 2e-4 if full else 5e-5
+    t = g["taps"]
+    errs = {"vision_embeds": _fingerprint_err(t["vision_embeds"], hs[-1]), "final_norm": _fingerprint_err(t["final_norm"], hs[cfg.layers]),
+            "embeds": _fingerprint_err(t["embeds"], hs[0])}
+    # (fingerprints sample padded token rows too, where the states are don't-care values on both sides: valid rows only)
+    valid = tb["attention_mask"].bool().reshape(-1)
+
+    def on_valid(fp, ten):
+        idx = torch.tensor(fp["idx"])
+        keep = valid[idx // cfg.hidden]
+        a = ten.reshape(-1)[idx[keep]].cpu()
+        v = torch.tensor(fp["vals"])[keep]
+        return ((a - v).abs() / (1.0 + v.abs())).max().item()
+    errs["final_norm"] = on_valid(t["final_norm"], hs[cfg.layers])
+    errs["embeds"] = on_valid(t["embeds"], hs[0])
+    l = min(int(k[5:]) for k in t if k.startswith("layer"))
+    errs[f"layer{l}"] = on_valid(t[f"layer{l}"], hs[l + 1])
+    print(f"[{name}] hidden_states vs the reference's fingerprints: {errs}")
+    assert max(errs.values()) < tol, errs
+
+
+def test_outputs_hidden_states_llava_layout():
+    """llava branch (rw_model:372-375, LlavaNext's output object): layers + 1 entries, the last one the final norm (no vision_embeds
+    entry), inner elements against the oracle's taps."""
+    from oracle import llava_next_reward_oracle as lorc
+    cfg = synth.llava_tiny_config()
+    seed = 23
+    batch = synth.llava_synth_batch(cfg, seed, [7, 3], [(336, 336), (512, 640)], max_crops=5)
+    W = orc.weights_to_torch(synth.llava_make_weights(cfg, seed))
+    taps = {}
+    lorc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"], taps=taps)
+    m = RewardModel(cfg, synth_seed=seed, max_batch=3, max_seq=4096, max_crops=5, operand_dtype="f16x2").to("cuda").eval()
+    tb = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
+    _, outs = m.custom_forward(inputs_batch=tb, return_output=True)
+    hs = outs["hidden_states"]
+    assert len(hs) == cfg.layers + 1 and torch.equal(hs[-1], outs["last_hidden_state"])
+    valid = torch.from_numpy(batch["attention_mask"]).bool()
+    want = [taps["embeds"]] + [taps[f"layer{k}"] for k in range(cfg.layers - 1)]
+    for k, w in enumerate(want):
+        got = hs[k].cpu()
+        assert got.shape == w.shape and (got - w)[valid].abs().max().item() < 2e-4 * w[valid].abs().max().item() + 1e-5, k
