@@ -22,7 +22,7 @@ template <> struct Op<BF16> {
     static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
-    static __device__ __forceinline__ f32x4 mfma16(uint4 a, uint4 b, f32x4 c) {
+    template <typename V> static __device__ __forceinline__ f32x4 mfma16(V a, V b, f32x4 c) {      // V: 16 bytes (uint4, or a native 4 x u32 vector)
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ unsigned short from_f32(float x) {
@@ -37,7 +37,7 @@ template <> struct Op<F16> {
     static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
-    static __device__ __forceinline__ f32x4 mfma16(uint4 a, uint4 b, f32x4 c) {
+    template <typename V> static __device__ __forceinline__ f32x4 mfma16(V a, V b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ unsigned short from_f32(float x) {

@@ -843,6 +843,24 @@ int lr_op_gemm_bt_mixed(void* A, const void* W, void* W8, void* scratch, void* C
     });
 }
 
+#ifdef LR_FP6_AB
+// Round 6 A/B builds only (tools/fp6/build_ab.sh; not declared in include/llava_reward_hip.h, not in the product library): the
+// split-operand GEMM with an FP6 residual pass.  A = [A_hi f16 x K | FP6 K-tiles, 96 bytes per 128 columns], W [N, K] f16,
+// W6 = rows of ldw = K two-byte units holding W's FP6 K-tiles, ascales / wscales = per-(row, 32 elements) E8M0 bytes in the kernel's
+// slice order ([K-tile][256-row tile] x 1 KB each).  flags & 16: the K loop alone (no epilogue, results not written).
+int lr_op_gemm_bt_fp6ab(const void* A, const void* W, const void* W6, const void* ascales, const void* wscales, void* C, const float* bias,
+                        int M, int N, int K, int epi, int act, int flags, void* hip_stream) {
+    return op_guard([&] {
+        const int nout = epi == EPI_SWIGLU_OP ? N / 2 : N;
+        const bool op_out = epi == EPI_OUT_OP || epi == EPI_SWIGLU_OP;
+        GemmParams p{A, W, C, bias, M, N, K + K / 2, 2 * K, K, op_out ? 2 * nout : nout, epi, act, nullptr, 0, 0, K, op_out ? nout : 0, W6};
+        p.aexp = (const unsigned char*)ascales; p.wscale = (const float*)wscales; p.wexp = 127;
+        // flags & 64: in-kernel stamps of the FP6 form, & 128: of the e4m3 form (W6 = the e4m3 twin, ascales = its block scales then), into `bias`
+        launch_gemm_bt8_fp6ab(p, (hipStream_t)hip_stream, (flags & 16) ? 1 : (flags & 64) ? 2 : (flags & 128) ? 3 : 0);
+    });
+}
+#endif
+
 int lr_op_quantize_rows_fp8(const void* x, int rows, int K, int ldx, void* q, float* scale, int operand_dtype, void* hip_stream) {
     return op_guard([&] {
         launch_quantize_rows_fp8(x, ldx, K, rows, q, K, scale, operand_dtype == LR_DT_F16 ? DT_F16 : DT_BF16, (hipStream_t)hip_stream);

@@ -56,18 +56,41 @@ namespace lr {
 // contraction sees a consistent permutation of k.  One instruction per 16x16 tile and K-tile (twice the K at the same MFMA
 // time); the per-row / per-channel dequantisation scales multiply the accumulators in front of the epilogue.
 typedef int v8i_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f32x4 mfma_f8(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1, const f32x4 c) {
-    const v8i_t a = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
-    const v8i_t b = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
-    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127);     // e4m3 x e4m3, scales 2^0
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+// MFMA operand fragments of the product K loop as NATIVE vectors (round 6).  As HIP's uint4 -- a struct -- the fragment arrays were
+// taken apart by the optimiser into {x}, {y, z}, {w} pieces; the scaled matrix instruction's 8-register operands were then register
+// sequences of six pieces each, and the backend left copies of the {y, z} pairs in front of the MFMAs (see join32).
+typedef unsigned frag_t __attribute__((ext_vector_type(4)));
+typedef unsigned frag2_t __attribute__((ext_vector_type(2)));
+// The 32 operand bytes of a lane = the two 16-byte fragments it holds, joined as TWO 128-bit halves (one shufflevector: a register
+// sequence the allocator coalesces with the ds_read_b128 destinations).  Built element by element -- {a0.x, a0.y, ...}, as until round 6
+// -- the backend left identity copies through a temporary pair in front of the MFMAs (v_pk_mov_b32 + 2 v_mov_b32 per fragment, ~20
+// VALU operations per COMPUTE segment) whose operands made it wait for the B1 fragments (lgkmcnt(0)) in front of the SECOND matrix
+// instruction of the segment instead of the ninth: the reads' LDS latency was exposed in every residual K-tile (in-kernel stamps,
+// profiles/r6_fp6_stamps.log: COMPUTE 900 cycles for 16 e4m3 MFMAs against 606 for the 32 f16 ones of the same nominal MFMA time).
+__device__ __forceinline__ v8i_t join32(const frag_t lo, const frag_t hi) {
+    return __builtin_shufflevector(__builtin_bit_cast(v4i_t, lo), __builtin_bit_cast(v4i_t, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ f32x4 mfma_f8(const frag_t a0, const frag_t a1, const frag_t b0, const frag_t b1, const f32x4 c) {
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(join32(a0, a1), join32(b0, b1), c, 0, 0, 0, 127, 0, 127);     // e4m3 x e4m3, scales 2^0
 }
 
 // SEL: which byte of `ea` holds the E8M0 scale of the A rows (four row tiles share one register)
 template <int SEL>
-__device__ __forceinline__ f32x4 mfma_f8s(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1, const f32x4 c, const int ea, const int eb) {
-    const v8i_t a = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
-    const v8i_t b = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
-    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, SEL, ea, 0, eb);   // x 2^(ea.byte[SEL] - 127) x 2^(eb - 127)
+__device__ __forceinline__ f32x4 mfma_f8s(const frag_t a0, const frag_t a1, const frag_t b0, const frag_t b1, const f32x4 c, const int ea, const int eb) {
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(join32(a0, a1), join32(b0, b1), c, 0, 0, SEL, ea, 0, eb);   // x 2^(ea.byte[SEL] - 127) x 2^(eb - 127)
+}
+// FP6 (OCP MX e2m3, cbsz = blgp = 2): 24 bytes per lane and operand -- the 16-byte and the 8-byte part of the lane's 32 elements --
+// and one E8M0 scale per lane (= per row and 32-element block) and operand, byte SELA of `ea` / SELB of `eb`.  Half the cycles of the
+// e4m3 form (MI355X_MICROARCH.md: FP6 at the FP4 rate).  F8 == 3 kernels only (round 6 A/B, tools/fp6).
+template <int SELA, int SELB>
+__device__ __forceinline__ f32x4 mfma_f6s(const frag_t a0, const frag2_t a1, const frag_t b0, const frag2_t b1, const f32x4 c, const int ea, const int eb) {
+    typedef int v2i_t __attribute__((ext_vector_type(2)));
+    const v4i_t ah = __builtin_bit_cast(v4i_t, a0), bh = __builtin_bit_cast(v4i_t, b0);
+    const v2i_t al = __builtin_bit_cast(v2i_t, a1), bl = __builtin_bit_cast(v2i_t, b1);
+    const v4i_t al4 = __builtin_shufflevector(al, al, 0, 1, -1, -1), bl4 = __builtin_shufflevector(bl, bl, 0, 1, -1, -1);
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(ah, al4, 0, 1, 2, 3, 4, 5, 6, 7),
+                                                            __builtin_shufflevector(bh, bl4, 0, 1, 2, 3, 4, 5, 6, 7), c, 2, 2, SELA, ea, SELB, eb);
 }
 template <int I> struct IC { static constexpr int value = I; };
 template <typename F> __device__ __forceinline__ void for4(F&& f) { f(IC<0>{}); f(IC<1>{}); f(IC<2>{}); f(IC<3>{}); }
@@ -86,6 +109,13 @@ template <typename F> __device__ __forceinline__ void for4(F&& f) { f(IC<0>{}); 
 template <typename OT, int PF, int NS, int DBG, int EPI, int PB, int F8 = 0, int NW = 0>
 __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
     static_assert(!F8 || PB == 2, "the fp8 operand path exists in the super-phase schedule only");
+    static_assert(F8 != 3 || (NW == 0 && LR_GEMM_SADDR), "the FP6 residual form (A/B): full tiles, saddr DMA");
+    // F8 == 3 (round 6 A/B, tools/fp6/): as F8 == 2, but the residual K-tiles are OCP MX FP6 -- e2m3 elements, 96 bytes per row and
+    // 128-deep K-tile stored [4 x 16 B | 4 x 8 B] (lane q of a row's four takes 16-byte part q and 8-byte part q), one E8M0 scale per
+    // (row, 32 elements) for A_lo AND for the weight twin.  A half-tile is 12 KB in its 16 KB ring slot: plane H = 128 rows x 64 B
+    // (ds_read_b128), plane L = 128 rows x 32 B behind it (ds_read_b64), 12 LDS-DMA pieces instead of 16; the two half-tiles of a LOAD
+    // segment go out as 3 pieces per wave (waves 0-3 the first, 4-7 the second).  Exact weights, no adapter, no third segment.
+    constexpr bool MIX = F8 == 2 || F8 == 3;
     static_assert(NW == 0 || PB == 2, "narrow tiles exist in the super-phase schedule only");
     static_assert(NW != 2 || (EPI & 15) == EPI_OUT_OP, "256 x 128 tiles: operand-out epilogue only");
     constexpr int E_ = EPI & 15;          // epilogue selector; bit 4 = bias present (SwiGLU / RoPE epilogues)
@@ -107,8 +137,8 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
     // PB == 2 (product): the K loop is the segment list the launcher built (GemmParams::seg); the A/B variants keep the older
     // closed-form addressing (16-bit operands only)
     const int nk = PB == 2 ? p.nk : p.K / BK;
-    const int nk_hi = (PB == 2 && F8 == 2) ? p.nk_f16 : nk;      // K-tiles of 16-bit operands; the rest are e4m3
-    const int nk_lo = (PB == 2 && F8 == 2) ? p.nk_e1 : nk;       // end of the residual segment; beyond it: A_hi8 x Wlo8 (inexact weights)
+    const int nk_hi = (PB == 2 && MIX) ? p.nk_f16 : nk;      // K-tiles of 16-bit operands; the rest are e4m3 (F8 == 3: FP6)
+    const int nk_lo = (PB == 2 && MIX) ? p.nk_e1 : nk;       // end of the residual segment; beyond it: A_hi8 x Wlo8 (inexact weights)
     const int Gtot = 4 * nk;
     typedef __attribute__((address_space(3))) char lds_char;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_char*)smem;
@@ -201,6 +231,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u));
         };
         int iseg = -1, iseg_end = 0, ikt = 0;          // segment being issued, its last K-tile + 1, K-tile being issued (uniform)
+        unsigned o6A[3], o6B[3];      // F8 == 3: byte offsets of this wave's 3 pieces of its A / its B half-tile (load_seg6)
         auto load_seg = [&]() {
             ++iseg;
             const GemmParams::KSeg sg = p.seg[iseg];
@@ -212,6 +243,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
             const int la = a2 ? p.lda2 : p.lda, lw = w2 ? p.ldw2 : p.ldw;
             int t = tid;
             asm volatile("" : "+v"(t));
+
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int q = it * 512 + t;
@@ -236,6 +268,29 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 bA = uni64(Ab + (size_t)m0 * la + sg.a_col);
                 bB = uni64(Wb + (size_t)n0 * lw + sg.w_col);
             }
+        };
+        // F8 == 3: the FP6 residual segment (always the last one), entered from the peeled K-tile that issues its first half-tiles:
+        // waves 0-3 carry A half 0 and B half 1, waves 4-7 A half 1 and B half 0
+        auto load_seg6 = [&]() {
+            ++iseg;
+            const GemmParams::KSeg sg = p.seg[iseg];
+            iseg_end = sg.kt_end;
+            int t = tid;
+            asm volatile("" : "+v"(t));
+            const int ln = t & 63, hA = wr, hB = 1 - wr;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int pc = 3 * wc + i;                      // piece of the half-tile: 0-7 plane H (16 rows each), 8-11 plane L (32 rows each)
+                int row, boff6;
+                if (pc < 8) { row = 16 * pc + (ln >> 2); boff6 = (((ln & 3) ^ ((0 - (ln >> 4)) & 3)) << 4); }
+                else { row = 32 * (pc - 8) + (ln >> 1); boff6 = 64 + (((ln & 1) ^ ((row >> 3) & 1)) << 4); }
+                const int ga = min(m0 + hA * 128 + row, p.M - 1);
+                const int gb = min(n0 + (row >> 5) * 64 + hB * 32 + (row & 31), p.N - 1);
+                o6A[i] = (unsigned)((ga - m0) * p.lda * 2 + boff6);
+                o6B[i] = (unsigned)((gb - n0) * p.ldw * 2 + boff6);
+            }
+            bA = uni64((const unsigned short*)p.A + (size_t)m0 * p.lda + sg.a_col);
+            bB = uni64((const unsigned short*)p.Wlo + (size_t)n0 * p.ldw + sg.w_col);
         };
         if constexpr (PB != 2) {
 #pragma unroll
@@ -292,6 +347,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         // PB == 2: in front of the first / behind the last half-tile of the K-tile being issued
         auto ktile_begin = [&]() { if (ikt == iseg_end) load_seg(); };
         auto ktile_end = [&]() {
+            if constexpr (F8 == 3) { const int adv = ikt >= nk_hi ? 48 : BK; bA += adv; bB += adv; ++ikt; return; }      // an FP6 K-tile is 96 bytes of a row (scalar arithmetic)
             ++ikt;
             if constexpr (SADDR) { bA += BK; bB += BK; }
             else if constexpr (DBG != 1) {
@@ -354,6 +410,25 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                          : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
         };
 
+        // F8 == 3: the FP6 K-tiles' scales, one byte per (row, 32 elements) for both operands: per residual K-tile j one KB of A scales
+        // (lane (row, q) of wave group wr: 8 bytes = its 4 row tiles of A half 0, then of A half 1, block q) and one KB of W scales
+        // (wave column wc: 4 bytes per lane = column tiles 0, 1 of B half 0, then of B half 1), in LDS slots 2j and 2j + 1 (mod 32)
+        // behind the ring: 16 K-tiles resident, the first 16 issued in the tile's prologue, K-tile j + 14 into the slots of K-tile
+        // j - 2 while K-tile j is multiplied.  Source layout: [K-tile][256-row tile] x 1 KB (p.aexp) and [K-tile][256-column tile] x 1 KB
+        // (p.wscale, bytes).
+        auto issue_scales6 = [&](int x) {          // piece x: K-tile x >> 1, A (even) or W (odd)
+            const int j6 = x >> 1;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + NS * HT + ((x & 31) << 10));
+            int l16 = lane * 16;
+            asm volatile("" : "+v"(l16));
+            const unsigned char* src = (x & 1) ? (const unsigned char*)p.wscale + ((size_t)j6 * Nt + ni) * 1024 + l16
+                                               : p.aexp + ((size_t)j6 * Mt + mi) * 1024 + l16;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        };
+        int a6H = 0, a6L = 0, b6H = 0, b6L = 0, ew6 = 0x7F7F7F7F;      // F8 == 3: fragment offsets inside an FP6 half-tile image; W scales of the K-tile
+
         if constexpr (PB == 2) {
         // ================= super-phase schedule (product) =================
         // Two quadrants per barrier interval: LOAD = 8 A reads + both half-tiles of the interval by LDS-DMA + counted wait;
@@ -377,6 +452,24 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         if constexpr (F8 == 2) {         // this tile's scale groups first: the oldest entries of the queue, retired by the prologue's wait
             for (int g = wave; g < min(nsg, SC_GROUPS); g += 8) issue_scales(g);
         }
+        if constexpr (F8 == 3) {
+            for (int x = wave; x < min(2 * nsl, 32); x += 8) issue_scales6(x);
+        }
+        // the two half-tiles of an FP6 LOAD segment (first = B1 / A0, second = A1 / B0 for sp = 0 / 1) as 3 pieces per wave
+        auto issue6 = [&](int sp, int slot0) {
+            const bool isA = (wr == 0) == (sp == 1);
+            int slot = slot0 + wr; slot = slot >= NS ? slot - NS : slot;
+            const unsigned short* base = isA ? bA : bB;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int pc = 3 * wc + i;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * HT + (pc < 8 ? pc * 1024 : 8192 + (pc - 8) * 1024));
+                const unsigned off = isA ? o6A[i] : o6B[i];
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
+            }
+        };
 #pragma unroll
         for (int g = 0; g < PF2; ++g) {
             if (g < Gtot) {
@@ -391,18 +484,28 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         LR_BARRIER();
         if (wr == 1) LR_BARRIER();                      // stagger the second wave group by one barrier
         tstamp(1);
-        uint4 af[8], bf[4], bg[4];
+        frag_t af[8], bf[4], bg[4];
+        frag2_t bfl[2], bgl[2];          // F8 == 3: the 8-byte parts of the FP6 B fragments (their 16-byte parts live in bf[0..1] / bg[0..1])
+        auto init6 = [&]() {           // FP6 half-tile image: plane H rows of 64 B (chunk q ^ f(row)), plane L rows of 32 B behind it
+            int ln = lane;
+            asm volatile("" : "+v"(ln));           // (computed behind the 16-bit K-tiles: not live across them)
+            const int r15 = ln & 15, q4 = ln >> 4;
+            const int sw4 = (q4 ^ ((0 - (r15 >> 2)) & 3)) << 4, sw8 = (q4 ^ (((r15 >> 3) & 1) << 1)) << 3;
+            a6H = (wr * 64 + r15) * 64 + sw4; a6L = 8192 + (wr * 64 + r15) * 32 + sw8;
+            b6H = (wc * 32 + r15) * 64 + sw4; b6L = 8192 + (wc * 32 + r15) * 32 + sw8;
+        };
         if constexpr (DBG != 4) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) bf[f] = *(const uint4*)(smem + 1 * HT + boff[f]);      // B0 of K-tile 0 (slot 1)
+            for (int f = 0; f < 4; ++f) bf[f] = *(const frag_t*)(smem + 1 * HT + boff[f]);      // B0 of K-tile 0 (slot 1)
         }
         int rslot = 0, gi = PF2;
         bool scl = false;          // this wave issued a scale slice in this LOAD segment: one more entry in its vmcnt queue
         // One K-tile.  A generic lambda so that the mixed form (F8 == 2) can run two loops, 16-bit tiles then e4m3 tiles, each
         // with its own straight-line body: a run-time branch around the two MFMA kinds merges 64 accumulator registers behind it
         // and spills inside the K loop.
-        auto ktile = [&](auto lo_tag, const int kt) {
-            constexpr int LO = decltype(lo_tag)::value;          // 0: 16-bit K-tile, 1: e4m3 residual K-tile, 2: e4m3 A_hi x W_lo K-tile
+        auto ktile = [&](auto lo_tag, auto iss_tag, const int kt) {
+            constexpr int LO = decltype(lo_tag)::value;          // 0: 16-bit K-tile, 1: e4m3 residual K-tile, 2: e4m3 A_hi x W_lo K-tile, 3: FP6 residual K-tile
+            constexpr int ISS = decltype(iss_tag)::value;        // F8 == 3: what this K-tile's LOAD segments ISSUE: 0 = 16-bit half-tiles, 1 = FP6 ones, 2 = 16-bit in sp 0, FP6 in sp 1
             int s2 = rslot + 2; s2 = s2 >= NS ? s2 - NS : s2;
             int s3 = rslot + 3; s3 = s3 >= NS ? s3 - NS : s3;
             int s5 = rslot + 5; s5 = s5 >= NS ? s5 - NS : s5;
@@ -416,11 +519,36 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 if constexpr (DBG == 3) t0 = stamp();
                 // ---------------- LOAD ----------------
                 const bool more = gi < Gtot;
+                frag_t ah6[4];
+                frag2_t al6[4];          // FP6 A fragments of this super-phase: 16-byte and 8-byte part of each row tile
                 if constexpr (DBG != 4) {
-                    if (NW != 1 || sp == 0) {
+                    if constexpr (LO == 3) {
                         const char* sa = sp == 0 ? sA0 : sA1;
 #pragma unroll
-                        for (int f = 0; f < 8; ++f) af[f] = *(const uint4*)(sa + aoff[f]);
+                        for (int i = 0; i < 4; ++i) {
+                            ah6[i] = *(const frag_t*)(sa + a6H + i * 1024);
+                            al6[i] = *(const frag2_t*)(sa + a6L + i * 512);
+                        }
+                    } else if (NW != 1 || sp == 0) {
+                        const char* sa = sp == 0 ? sA0 : sA1;
+#pragma unroll
+                        for (int f = 0; f < 8; ++f) af[f] = *(const frag_t*)(sa + aoff[f]);
+                    }
+                }
+                if constexpr (F8 == 3 && LO == 3) {
+                    const int j = kt - nk_hi;
+                    if (sp == 0) {
+                        typedef int v2i_t __attribute__((ext_vector_type(2)));
+                        typedef __attribute__((address_space(3))) const volatile v2i_t lds_scale_t;
+                        typedef __attribute__((address_space(3))) const volatile int lds_scale1_t;
+                        const v2i_t e2 = *(lds_scale_t*)(lds_base + NS * HT + (((2 * j) & 31) << 10) + (wr * 64 + lane) * 8);
+                        ea[0] = e2.x; ea[1] = e2.y;
+                        ew6 = *(lds_scale1_t*)(lds_base + NS * HT + (((2 * j + 1) & 31) << 10) + (wc * 64 + lane) * 4);
+                        // K-tile j + 14 into the slots of K-tile j - 2 (read two K-tiles ago by both wave groups)
+                        if (j >= 2 && j + 14 < nsl) {
+                            if (wave == (j & 7)) { issue_scales6(2 * (j + 14)); scl = true; }
+                            else if (wave == ((j + 4) & 7)) { issue_scales6(2 * (j + 14) + 1); scl = true; }
+                        }
                     }
                 }
                 // the scales of this residual K-tile's rows (both A halves) from LDS; a late scale group (K > 16384) into the slot of
@@ -437,16 +565,27 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                     }
                 }
                 if (more) {
+                    const bool i6 = F8 == 3 && (ISS == 1 || (ISS == 2 && sp == 1));      // the K-tile being ISSUED is an FP6 one (3 pieces per wave instead of 4); folds
                     if constexpr (DBG != 5) {                 // second half of K-tile kt+1, then first half of kt+2
-                        if (sp == 1) ktile_begin();
-                        issue(sp == 0 ? 2 : 0, kt + 2, islot);
-                        islot = (islot + 1 == NS) ? 0 : islot + 1;
-                        issue(sp == 0 ? 3 : 1, kt + 2, islot);
-                        islot = (islot + 1 == NS) ? 0 : islot + 1;
+                        if (sp == 1) { if (F8 == 3 && ISS == 2) load_seg6(); else ktile_begin(); }
+                        if (F8 == 3 && i6) {
+                            issue6(sp, islot);
+                            islot += 2; islot = islot >= NS ? islot - NS : islot;
+                        } else {
+                            issue(sp == 0 ? 2 : 0, kt + 2, islot);
+                            islot = (islot + 1 == NS) ? 0 : islot + 1;
+                            issue(sp == 0 ? 3 : 1, kt + 2, islot);
+                            islot = (islot + 1 == NS) ? 0 : islot + 1;
+                        }
                         if (sp == 0) ktile_end();
                     }
-                    if (scl) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT2 + 1) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT2) : "memory");
+                    if (F8 == 3 && i6) {
+                        if (scl) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3) : "memory");
+                    } else {
+                        if (scl) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT2 + 1) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT2) : "memory");
+                    }
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
@@ -458,14 +597,28 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 // ---------------- COMPUTE ----------------
                 __builtin_amdgcn_s_setprio(1);
                 if constexpr (DBG != 4) {
-                    if (sp == 0 && NW != 2) {
+                    if constexpr (LO == 3) {
+                        if (sp == 0) {
 #pragma unroll
-                        for (int f = 0; f < 4; ++f) bg[f] = *(const uint4*)(sB1 + boff[f]);
+                            for (int j = 0; j < 2; ++j) {
+                                bg[j] = *(const frag_t*)(sB1 + b6H + j * 1024);
+                                bgl[j] = *(const frag2_t*)(sB1 + b6L + j * 512);
+                            }
+                        }
+                    } else if (sp == 0 && NW != 2) {
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) bg[f] = *(const frag_t*)(sB1 + boff[f]);
                     }
                     constexpr int q0 = 0, q1 = 1, q3 = 3, q2 = 2;
                     const int qa = sp == 0 ? q0 : q3, qb = sp == 0 ? q1 : q2;      // first block uses bf (B0), second bg (B1)
                     const bool do_a = NW != 1 || sp == 0, do_b = do_a && NW != 2;        // (compile-time constants after unrolling)
-                    if (!do_a) {
+                    if constexpr (LO == 3) {
+                        for4([&](auto ic) {
+                            constexpr int i = decltype(ic)::value;
+                            acc[qa][i][0] = mfma_f6s<i, 0>(ah6[i], al6[i], bf[0], bfl[0], acc[qa][i][0], ea[sp], ew6);
+                            acc[qa][i][1] = mfma_f6s<i, 1>(ah6[i], al6[i], bf[1], bfl[1], acc[qa][i][1], ea[sp], ew6);
+                        });
+                    } else if (!do_a) {
                     } else if constexpr (F8 == 1 || (F8 == 2 && LO)) {
                         for4([&](auto ic) {
                             constexpr int i = decltype(ic)::value;
@@ -482,11 +635,23 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 #pragma unroll
                             for (int j = 0; j < 2; ++j) acc[qa][i][j] = Op<OT>::mfma16(af[i * 2 + ks], bf[j * 2 + ks], acc[qa][i][j]);
                     }
-                    if (sp == 1 && kt + 1 < nk) {
+                    if (F8 == 3 && ISS == 1 && sp == 1 && kt + 1 < nk) {      // the next K-tile is an FP6 one
 #pragma unroll
-                        for (int f = 0; f < 4; ++f) bf[f] = *(const uint4*)(sB0n + boff[f]);
+                        for (int j = 0; j < 2; ++j) {
+                            bf[j] = *(const frag_t*)(sB0n + b6H + j * 1024);
+                            bfl[j] = *(const frag2_t*)(sB0n + b6L + j * 512);
+                        }
+                    } else if (sp == 1 && kt + 1 < nk) {
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) bf[f] = *(const frag_t*)(sB0n + boff[f]);
                     }
-                    if (!do_b) {
+                    if constexpr (LO == 3) {
+                        for4([&](auto ic) {
+                            constexpr int i = decltype(ic)::value;
+                            acc[qb][i][0] = mfma_f6s<i, 2>(ah6[i], al6[i], bg[0], bgl[0], acc[qb][i][0], ea[sp], ew6);
+                            acc[qb][i][1] = mfma_f6s<i, 3>(ah6[i], al6[i], bg[1], bgl[1], acc[qb][i][1], ea[sp], ew6);
+                        });
+                    } else if (!do_b) {
                     } else if constexpr (F8 == 1 || (F8 == 2 && LO)) {
                         for4([&](auto ic) {
                             constexpr int i = decltype(ic)::value;
@@ -521,8 +686,9 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 if constexpr (DBG == 3) {
                     t4 = stamp();
                     if (sp == 0) { const unsigned long long t5 = stamp(); lsegs[0] += (unsigned)(t5 - t4); }   // cost of one stamp
-                    segs[sp][0] += (unsigned)(t1 - t0); segs[sp][1] += (unsigned)(t2 - t1);
-                    segs[sp][2] += (unsigned)(t3 - t2); segs[sp][3] += (unsigned)(t4 - t3);
+                    const int row = sp + (LO ? 2 : 0);              // rows 2, 3: the residual K-tiles (e4m3 / FP6), summed apart from the 16-bit ones
+                    segs[row][0] += (unsigned)(t1 - t0); segs[row][1] += (unsigned)(t2 - t1);
+                    segs[row][2] += (unsigned)(t3 - t2); segs[row][3] += (unsigned)(t4 - t3);
                 }
             }
             rslot += 4;
@@ -530,10 +696,19 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         };
         {
             int kt = 0;
-            for (; kt < nk_hi; ++kt) ktile(IC<0>{}, kt);
-            if constexpr (F8 == 2) {
-                for (; kt < nk_lo; ++kt) ktile(IC<1>{}, kt);
-                for (; kt < nk; ++kt) ktile(IC<2>{}, kt);
+            if constexpr (F8 == 3) {
+                // the last two 16-bit K-tiles issue the first FP6 half-tiles: peeled, so that the main loop's body is the product's
+                for (; kt < nk_hi - 2; ++kt) ktile(IC<0>{}, IC<0>{}, kt);
+                init6();
+                ktile(IC<0>{}, IC<2>{}, kt); ++kt;
+                ktile(IC<0>{}, IC<1>{}, kt); ++kt;
+                for (; kt < nk; ++kt) ktile(IC<3>{}, IC<1>{}, kt);
+            } else {
+                for (; kt < nk_hi; ++kt) ktile(IC<0>{}, IC<0>{}, kt);
+                if constexpr (F8 == 2) {
+                    for (; kt < nk_lo; ++kt) ktile(IC<1>{}, IC<0>{}, kt);
+                    for (; kt < nk; ++kt) ktile(IC<2>{}, IC<0>{}, kt);
+                }
             }
         }
         if (wr == 0) LR_BARRIER();                      // balance the stagger barrier
@@ -1215,6 +1390,29 @@ void launch_gemm_bt8_mixed(const GemmParams& p0, int operand_dtype, hipStream_t 
     if (operand_dtype == DT_F16) launch8_epi<F16, 6, 0, 2, 2>(p, true, st);
     else launch8_epi<BF16, 6, 0, 2, 2>(p, true, st);
 }
+
+#ifdef LR_FP6_AB
+// Round 6 A/B (tools/fp6/, -DLR_FP6_AB=1 builds only): the split-operand GEMM with its residual pass in OCP MX FP6 (kernel form F8 == 3).
+// p as for launch_gemm_bt8_mixed; the residual half of A and the rows of p.Wlo hold 96-byte FP6 K-tiles, p.aexp / p.wscale (bytes) the
+// per-(row, 32 elements) scales in the kernel's slice order.  noepi: the K loop alone (results not written).
+void launch_gemm_bt8_fp6ab(const GemmParams& p0, hipStream_t st, int noepi) {
+    if (p0.M <= 0) return;
+    GemmParams p = p0;
+    if (p.kw <= 0 || p.kw % 128 || !p.Wlo || !p.aexp || !p.wscale || p.aexp2 || p.Wlo16 || p.A2 || p.oexp)
+        throw std::runtime_error("gemm_bt8_fp6ab: needs kw % 128 == 0, FP6 twin rows and both scale arrays; exact weights, no adapter");
+    build_segments(p, 2);
+    if (noepi == 1) { launch8<F16, 6, 2, EPI_OUT_F32, 2, 3>(p, true, st); return; }
+    if (noepi == 2) { launch8<F16, 6, 3, EPI_OUT_F32, 2, 3>(p, false, st); return; }      // in-kernel stamps -> the buffer passed as `bias` (FP6 residual tiles)
+    if (noepi == 3) { p.wscale = nullptr; launch8<F16, 6, 3, EPI_OUT_F32, 2, 2>(p, false, st); return; }      // ... of the product's e4m3 form
+    switch (p.epi) {
+        case EPI_OUT_OP: launch8<F16, 6, 0, EPI_OUT_OP, 2, 3>(p, true, st); break;
+        case EPI_OUT_F32: launch8<F16, 6, 0, EPI_OUT_F32, 2, 3>(p, true, st); break;
+        case EPI_RESADD_F32: launch8<F16, 6, 0, EPI_RESADD_F32, 2, 3>(p, true, st); break;
+        case EPI_SWIGLU_OP: launch8<F16, 6, 0, EPI_SWIGLU_OP, 2, 3>(p, true, st); break;
+        default: throw std::runtime_error("gemm_bt8_fp6ab: epilogue not built");
+    }
+}
+#endif
 
 void launch_gemm_bt8(const GemmParams& p, int operand_dtype, int variant, hipStream_t st) {
     if (p.N % 8 || p.ldc % 8 || ((uintptr_t)p.C & 15) || (p.bias && ((uintptr_t)p.bias & 15)))

@@ -14,6 +14,9 @@ void launch_gemm_bt8(const GemmParams& p, int operand_dtype, int variant, hipStr
 // W8A8: e4m3 operands (K, lda, ldw in bytes), per-row / per-channel fp32 scales in p.ascale / p.wscale
 void launch_gemm_bt8_fp8(GemmParams p, int operand_dtype, hipStream_t st);
 void launch_gemm_bt8_mixed(const GemmParams& p, int operand_dtype, hipStream_t st, int dbg = 0);
+#ifdef LR_FP6_AB
+void launch_gemm_bt8_fp6ab(const GemmParams& p, hipStream_t st, int noepi);      // round 6 A/B builds only (tools/fp6/)
+#endif
 void launch_emulate_lo8(void* qkv, size_t rows, int ld, int col0, int heads, int hd, int operand_dtype, hipStream_t st);      // diagnostic only
 void launch_quantize_lo_inplace(void* a, int ld, int K, int rows, unsigned char* scales, int operand_dtype, hipStream_t st, int* aexp2 = nullptr);
 void prepare_weight_e4m3_pair(const void* w, void* twin, int ldw, int K, int N, void* tmp, int operand_dtype, unsigned* scratch_word,

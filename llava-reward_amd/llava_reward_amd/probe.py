@@ -5,17 +5,17 @@ No reference counterpart: the reference runs one operand type (bf16 on the GPU, 
 operand rounding (massive activations, large norm gains: what trained checkpoints show) need the strict form (16-bit residual
 passes, 22 bits) -- so the engine measures the distance between the two forms on the weights it was given.
 
-Round 6: the rows are a function of the MODEL alone.  They come in fixed TIERS -- a tier is a fixed batch: one image geometry, captions
-of fixed lengths left-padded to the tier's common length (left padding and the long-sequence regime are both inside), token ids from the
-counter hash of synth.py, pixels filled in HBM by the same hash (lr_op_synth_fill), std 1 like CLIP-normalised images -- and an engine
-scores EVERY tier that fits its capacity (max_crops / max_seq / max_patches) and skips the others whole; nothing is reshaped to fit
-(until round 5 the largest geometry that fitted was chosen and the captions were cut to the room left, so two deployments of one
-checkpoint could probe different rows: `ref_llava_full_bt` locked `strict-vision` on a test engine and `default` on the bench's).
-A tier is scored in chunks of min(max_batch, PROBE_CHUNK) rows: slices of the one fixed batch, and a row's reward does not depend on
-the rows beside it (same S, same V_max inside a tier), so the chunking is invisible in the numbers.  Two engines that fit the same tiers
-therefore measure the same distances bit for bit (tests/test_gpu_forward.py::test_probe_rows_do_not_depend_on_the_engine_capacity);
-an engine too small for the large tiers decides on the rows it could ever be asked to score.  `PROBE_MIN_SEQ[model_type]` = the
-max_seq that admits every tier (what bench.py and the golden tests size their engines to)."""
+Round 6: the rows are a function of the MODEL alone.  They come in fixed TIERS -- a tier is a fixed batch of 8 rows: one image geometry,
+captions of fixed lengths left-padded to the tier's common length (left padding and the long-sequence regime are both inside), token ids
+from the counter hash of synth.py, pixels filled in HBM by the same hash (lr_op_synth_fill), std 1 like CLIP-normalised images -- and an
+engine scores the LARGEST tier that fits its capacity whole (max_crops / max_seq / max_patches); nothing is reshaped to fit (until round 5
+the captions were cut to the room left and the chunking followed max_batch, so two deployments of one checkpoint could probe different
+rows: `ref_llava_full_bt` locked `strict-vision` on a test engine and `default` on the bench's).  A tier is scored in chunks of
+min(max_batch, PROBE_CHUNK) rows: slices of the one fixed batch, and a row's reward does not depend on the rows beside it (same S, same
+V_max inside a tier), so the chunking is invisible in the numbers.  Two engines that fit the same tier therefore measure the same
+distances bit for bit (tests/test_gpu_forward.py::test_probe_rows_do_not_depend_on_the_engine_capacity); an engine too small for the
+first tier decides on rows of the largest geometry it could ever be asked to score.  `PROBE_MIN_SEQ[model_type]` = the max_seq that
+admits the first tier (what bench.py and the golden tests size their engines to: every full-size deployment probes the same rows)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -28,13 +28,13 @@ from . import _lib as L
 from . import synth
 
 PROBE_SEED = 0x5EED0F0A
-PROBE_ROWS = 8                   # rows of the first (largest) tier; the decision is the MAX over all scored rows: rows are draws of one noise
+PROBE_ROWS = 8                   # rows per tier; the decision is the MAX over the rows: they are draws of one noise
 PROBE_CHUNK = 4                  # rows per forward (slices of a tier's fixed batch)
 PROBE_CAPTIONS = (128, 96, 64, 33, 112, 80, 48, 17)
 # (geometry, rows) per tier, largest first.  phi3v: HD crop grid; llava: original image (h, w); qwen: patch grid per image
-PHI_TIERS = (((4, 4), 8), ((2, 2), 4), ((1, 1), 4))
-LLAVA_TIERS = (((672, 672), 4), ((336, 336), 8), ((200, 200), 4))
-QWEN_TIERS = (((32, 32), 8), ((16, 16), 4), ((8, 8), 4))
+PHI_TIERS = (((4, 4), 8), ((2, 2), 8), ((1, 1), 8))
+LLAVA_TIERS = (((672, 672), 8), ((336, 336), 8), ((200, 200), 8))
+QWEN_TIERS = (((32, 32), 8), ((16, 16), 8), ((8, 8), 8))
 _FRAME = 5                        # tokens of a row besides image slots and caption (synth.*_synth_batch)
 PROBE_MIN_SEQ = {"phi3v": synth.num_img_tokens(336 * 4, 336 * 4) + _FRAME + max(PROBE_CAPTIONS),
                  "llava": synth.llava_geometry(672, 672)[6] + _FRAME + max(PROBE_CAPTIONS),
@@ -57,7 +57,7 @@ def _chunks(rows: int, cap: int):
 
 
 def probe_batches(model, rows: int = PROBE_ROWS) -> List[Dict[str, object]]:
-    """-> custom_forward keyword dicts covering every probe tier that fits the engine (`rows` caps the rows taken from each tier)."""
+    """-> custom_forward keyword dicts covering the largest probe tier that fits the engine (`rows` caps the rows taken from it)."""
     cfg, opts, dev = model.config, model._opts, model.device
     lib = L.load()
     mb, ms = int(opts["max_batch"]), int(opts["max_seq"])
@@ -80,6 +80,7 @@ def probe_batches(model, rows: int = PROBE_ROWS) -> List[Dict[str, object]]:
             for lo, hi in _chunks(n, min(mb, PROBE_CHUNK)):
                 out.append(dict(input_ids=torch.from_numpy(b["input_ids"][lo:hi]).to(dev), attention_mask=torch.from_numpy(b["attention_mask"][lo:hi]).to(dev),
                                 pixel_values=pixels((ncr, 3, cfg.clip.image, cfg.clip.image), lo, hi, tier), image_sizes=torch.from_numpy(b["image_sizes"][lo:hi])))
+            break
         return out
     if model.model_type == "llava":
         for tier, (size, n) in enumerate(LLAVA_TIERS):
@@ -95,6 +96,7 @@ def probe_batches(model, rows: int = PROBE_ROWS) -> List[Dict[str, object]]:
                                                   attention_mask=torch.from_numpy(b["attention_mask"][lo:hi]).to(dev),
                                                   pixel_values=pixels((ncr, 3, cfg.clip.image, cfg.clip.image), lo, hi, tier),
                                                   image_sizes=torch.from_numpy(b["image_sizes"][lo:hi]))))
+            break
         return out
     # qwen: one image of g x g patches per row (g even)
     v = cfg.vision
@@ -111,4 +113,5 @@ def probe_batches(model, rows: int = PROBE_ROWS) -> List[Dict[str, object]]:
                                               attention_mask=torch.from_numpy(b["attention_mask"][lo:hi]).to(dev),
                                               pixel_values=pixels((per_row, v.patch_dim), lo, hi, tier, cat=True),
                                               image_grid_thw=torch.from_numpy(b["image_grid_thw"][lo:hi]))))
+        break
     return out

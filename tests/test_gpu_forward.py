@@ -137,7 +137,7 @@ def test_operand_form_is_locked_on_the_weights_by_to_cuda():
         info = m.form_info
         got = _fwd(m, batch)
         print(f"[form probe, profile {profile}] {info}; err {(got - ref).abs().max().item():.2e}")
-        assert info["source"] == "probe" and info["rows"] == 8 and info["seconds"] > 0      # (this engine fits the (2, 2) and (1, 1) tiers: 4 + 4 rows) and info["form"] == m.operand_form and info["default_vs_strict"] < 1.0
+        assert info["source"] == "probe" and info["rows"] == probe_mod.PROBE_ROWS == 8 and info["seconds"] > 0 and info["form"] == m.operand_form and info["default_vs_strict"] < 1.0
         assert (got - ref).abs().max().item() < TOL_X8
         if profile == 0:
             assert m.operand_form == "default" and info["default_vs_strict"] < m.parity_budget
@@ -175,9 +175,9 @@ def test_operand_form_is_locked_on_the_weights_by_to_cuda():
 
 
 def test_probe_rows_do_not_depend_on_the_engine_capacity():
-    """Round 6: the probe rows are fixed tiers (probe.py) -- an engine scores every tier that fits and reshapes nothing -- so two engines of
-    different capacity (batch 1 / 6, other max_seq and max_crops, hence other chunkings of the same fixed batches) on ONE weight set
-    measure the same distances, bit for bit, and lock the same form; an engine too small for a tier skips it whole."""
+    """Round 6: the probe rows are fixed tiers (probe.py) -- an engine scores the largest tier that fits it whole and reshapes nothing --
+    so two engines of different capacity (batch 1 / 6, other max_seq and max_crops, hence other chunkings of the same fixed batch) on ONE
+    weight set measure the same distances, bit for bit, and lock the same form; an engine too small for that tier takes the next one."""
     cfg = synth.tiny_config(hidden=1024, intermediate=2048, heads=16, layers=3)
     seed = 29
     for profile in (0, synth.PROFILE_OUTLIER):
@@ -187,9 +187,10 @@ def test_probe_rows_do_not_depend_on_the_engine_capacity():
         assert a.form_info["rows"] == b.form_info["rows"] == 8
         assert a.form_info["distance_to_strict"] == b.form_info["distance_to_strict"] and a.operand_form == b.operand_form
         small = _model(cfg, seed, "f16x2f8", upload=False, max_batch=2, max_seq=512, max_crops=2, profile=profile)      # only the (1, 1) tier fits
-        assert small.form_info["rows"] == 4
+        assert small.form_info["rows"] == 8 and probe_mod.probe_batches(small)[0]["pixel_values"].shape[1] == 2
     assert probe_mod.PROBE_MIN_SEQ == {"phi3v": 2642, "llava": 3061, "qwen": 389}
     assert [len(x["input_ids"]) for x in probe_mod.probe_batches(a)] == [1] * 8 and [len(x["input_ids"]) for x in probe_mod.probe_batches(b)] == [4, 4]
+    assert probe_mod.probe_batches(a)[0]["input_ids"].shape[1] == probe_mod.probe_batches(b)[0]["input_ids"].shape[1] == 757 + 5 + 128      # the (2, 2) tier
 
 
 def test_operand_form_pin_failed_probe_and_deferred_input_check(monkeypatch):
