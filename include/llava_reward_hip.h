@@ -200,6 +200,22 @@ int lr_set_layer_limits(lr_handle h, int n_clip_layers, int n_layers);
  * form's than its parity budget; (2) measurements (tools/prec_map_probe.py).  The map survives weight uploads; callers that
  * derive it from the weights re-derive it when lr_weights_epoch has moved. */
 int lr_set_precision_map(lr_handle h, int clip_form, int decoder_mid_form, int decoder_first, int decoder_last);
+/* Operand form per SITE of the decoder layers the map above covers (ABI 9): -1 = the layer's form (decoder_mid_form), 1 = 16-bit
+ * residual passes, 2 = e4m3 residual passes.  Sites: qkv = input norm + qkv projection; attention (both forms are three-pass split
+ * operands; 1 = the exact softmax maximum, 2 = the lazy one); o_proj; gate_up = post-attention norm + gate_up projection; down.  A
+ * site is an operand's producer together with the launch that reads it, so the forms of neighbouring sites are independent
+ * (modeling_phi3_v.py:1144-1205 runs them all in one dtype; which of them a weight set that amplifies operand rounding needs strict
+ * was measured with tools/prec_map_probe.py sites: DESIGN.md 4c).  Layers outside the map's range keep the descriptor's form. */
+int lr_set_precision_sites(lr_handle h, int qkv_form, int attention_form, int o_proj_form, int gate_up_form, int down_form);
+/* Thresholds of the attention kernels' lazy softmax reference maximum (ABI 9; log2 units, 0 .. 15): a row's reference moves only when
+ * its new maximum exceeds it by more than the threshold, which spares most rescales of the output accumulators (-14 % per launch) at the
+ * price of fp32-level noise on the softmax weights (exponent arguments rounded at ulp(threshold) instead of ulp(0)) -- invisible on
+ * benign weights, up to 3e-4 on a weight set that amplifies rounding (profiles/r6_outlier_fp64.log).  0 = the exact running maximum of
+ * the reference's softmax (modeling_phi3_v.py:685-701).  default_stages (8 at lr_create): launches of stages in the e4m3-residual
+ * default form; strict_stages (0 at lr_create): launches of stages in the strict form -- the yardstick keeps the reference's own
+ * arithmetic; the Python layer raises it to 8 for ONE pass of its operand-form probe, as a numerically equivalent re-statement of the
+ * strict form whose distance to the exact one is the weight set's own fp32 noise floor (model.py _compare_forms). */
+int lr_set_attention_lazy_threshold(lr_handle h, float default_stages, float strict_stages);
 /* Counts the calls that changed this handle's weights (lr_upload_weight, lr_synth_weights*): anything derived from the weights --
  * the operand form the Python layer locks at .to('cuda') -- is stale once it has moved. */
 uint64_t lr_weights_epoch(lr_handle h);

@@ -170,7 +170,16 @@ struct lr_engine {
     // precision map (lr_set_precision_map): operand form per stage, -1 = the descriptor's.  0 single pass, 1 split (16-bit residuals),
     // 2 split with e4m3 residual passes.  Decoder layers [pm_first, layers - pm_last) take pm_mid, the others the descriptor's form.
     int prec0 = 0, lo8_0 = 0, pm_clip = -1, pm_mid = -1, pm_first = 0, pm_last = 0;
+    // ... and per SITE of a decoder layer in that range (lr_set_precision_sites, round 6): -1 = the layer's form.  A site = an operand
+    // producer together with the GEMM (or attention launch) that reads it, so a site's form never crosses into its neighbours'.
+    enum : int { SITE_QKV = 0, SITE_ATTN = 1, SITE_O = 2, SITE_GATE_UP = 3, SITE_DOWN = 4, N_SITES = 5 };
+    int pm_site[N_SITES] = {-1, -1, -1, -1, -1};
+    // lazy reference maximum of the attention launches in DEFAULT-form stages (lr_set_attention_lazy_threshold; log2 units, 0 = exact).
+    // Strict stages run the exact maximum (att_lazy_t_strict = 0) except in the probe's noise-floor pass (model.py _compare_forms).
+    float att_lazy_t = ATT_LAZY_T_DEFAULT, att_lazy_t_strict = 0.f;
     void set_form(int m) { if (m < 0) { prec = prec0; lo8 = lo8_0; } else { prec = m ? 1 : 0; lo8 = m == 2 ? 1 : 0; } pre_enc = nullptr; }
+    int layer_form(int l) const { return (pm_mid >= 0 && l >= pm_first && l < d.layers - pm_last) ? pm_mid : -1; }
+    int site_form(int l, int site) const { const int f = layer_form(l); return (f >= 0 && pm_site[site] >= 0) ? pm_site[site] : f; }
 
     void* dalloc(size_t bytes, bool weight) {
         void* p = nullptr;
@@ -434,10 +443,10 @@ inline void apply_prec(const lr_engine* e, AttnParams& p) {
     p.o_split = p.ldo; p.ldo *= 2;
     // strict stages (16-bit residual passes: the probe's yardstick, and what an amplifying weight set is locked to) keep the exact
     // softmax maximum; stages in the default form take the lazy one (attention.hip; -14 % per launch)
-    // (A/B switches for tools/outlier_fp64_probe.py, read once: LR_ATT_LAZY_T = the default-form stages' threshold, LR_ATT_LAZY_T_STRICT = the strict stages')
-    static const float t_def = [] { const char* v = getenv("LR_ATT_LAZY_T"); return v ? (float)atof(v) : ATT_LAZY_T_DEFAULT; }();
+    // (A/B switches for tools/outlier_fp64_probe.py, read once: LR_ATT_LAZY_T overrides the default-form stages' threshold, LR_ATT_LAZY_T_STRICT the strict stages')
+    static const float t_def = [] { const char* v = getenv("LR_ATT_LAZY_T"); return v ? (float)atof(v) : -1.f; }();
     static const float t_strict = [] { const char* v = getenv("LR_ATT_LAZY_T_STRICT"); return v ? (float)atof(v) : 0.f; }();
-    p.lazy_t = e->lo8 ? t_def : t_strict;
+    p.lazy_t = e->lo8 ? (t_def >= 0.f ? t_def : e->att_lazy_t) : (t_strict > 0.f ? t_strict : e->att_lazy_t_strict);
 }
 
 // W8A8 mode: quantise the rows of A, make sure W has its e4m3 twin, launch the e4m3 form.  Like lo8_eligible, the choice never
@@ -505,7 +514,17 @@ inline void mark_lo8_out(lr_engine* e, const GemmParams& p) {
 // One linear layer, p in LOGICAL shapes (as gemm() takes them).  With an adapter L: t = x A^T first (always on the deep-pipelined
 // kernel, in the same operand form as the main GEMM -- they read the same rows of x), then the main GEMM with the K-extension.
 // next_W / next_N: the weight of the GEMM that reads this one's output as its operand (lo8_out_target), or null.
-inline void gemm_p(lr_engine* e, hipStream_t st, GemmParams p, const Lora* L = nullptr, const void* next_W = nullptr, int next_N = 0) {
+// next_form: the operand form of the site that reads this GEMM's output (lr_engine::site_form), -2 = the form in force now: decides
+// whether the epilogue writes one-byte residuals (lo8_out_target looks at the CONSUMER's form, not at this GEMM's).
+inline unsigned char* lo8_out_target_for(lr_engine* e, const GemmParams& p, const void* next_W, int next_N, int next_form) {
+    if (next_form == -2) return lo8_out_target(e, p, next_W, next_N);
+    const int sp = e->prec, sl = e->lo8;
+    if (next_form < 0) { e->prec = e->prec0; e->lo8 = e->lo8_0; } else { e->prec = next_form ? 1 : 0; e->lo8 = next_form == 2 ? 1 : 0; }
+    unsigned char* t = (e->prec == sp) ? lo8_out_target(e, p, next_W, next_N) : nullptr;      // (a single-pass neighbour: no residual half at all)
+    e->prec = sp; e->lo8 = sl;
+    return t;
+}
+inline void gemm_p(lr_engine* e, hipStream_t st, GemmParams p, const Lora* L = nullptr, const void* next_W = nullptr, int next_N = 0, int next_form = -2) {
     p.sched_mem = e->sched_mem;
     if (L && L->k2 > 0) {
         if (e->w8a8) throw std::logic_error("W8A8 mode runs merged weights only (no un-merged adapters)");
@@ -523,20 +542,20 @@ inline void gemm_p(lr_engine* e, hipStream_t st, GemmParams p, const Lora* L = n
         if (it != e->wbuf_of.end() && !e->inexact.empty() && e->inexact[it->second]) p.W2lo = e->wbufs[it->second].lo;
         apply_prec_base(e, p);
         if (both8) upgrade_lo8(e, p, st);
-        p.oexp = lo8_out_target(e, p, next_W, next_N);
+        p.oexp = lo8_out_target_for(e, p, next_W, next_N, next_form);
         launch_gemm_bt(p, e->op_dt, e->gemm_tile, st);
         mark_lo8_out(e, p);
         return;
     }
     if (launch_w8a8(e, p, st)) return;
     apply_prec(e, p, st);
-    p.oexp = lo8_out_target(e, p, next_W, next_N);
+    p.oexp = lo8_out_target_for(e, p, next_W, next_N, next_form);
     launch_gemm_bt(p, e->op_dt, e->gemm_tile, st);
     mark_lo8_out(e, p);
 }
 inline void gemm(lr_engine* e, hipStream_t st, const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int lda,
-          int ldw, int ldc, int epi, int act, const Lora* L = nullptr, const void* next_W = nullptr, int next_N = 0) {
-    gemm_p(e, st, GemmParams{A, W, C, bias, M, N, K, lda, ldw, ldc, epi, act, nullptr, 0, 0}, L, next_W, next_N);
+          int ldw, int ldc, int epi, int act, const Lora* L = nullptr, const void* next_W = nullptr, int next_N = 0, int next_form = -2) {
+    gemm_p(e, st, GemmParams{A, W, C, bias, M, N, K, lda, ldw, ldc, epi, act, nullptr, 0, 0}, L, next_W, next_N, next_form);
 }
 
 // Adapter slots of one linear `mod` (checkpoint names mod.lora_A.weight [r, K], mod.lora_B.weight [n_rows, r]); part / parts: this

@@ -211,7 +211,10 @@ bool run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_ma
     bool pruned = false;
     for (int l = 0; l < nl; ++l) {
         const DecLayer& L = h->dl[l];
-        h->set_form((h->pm_mid >= 0 && l >= h->pm_first && l < d.layers - h->pm_last) ? h->pm_mid : -1);
+        // the operand form of every site of this layer (lr_set_precision_map / lr_set_precision_sites); set right in front of the
+        // site's producer, in force until its consumer has been launched
+        auto site = [&](int s) { h->set_form(h->site_form(l, s)); };
+        site(lr_engine::SITE_QKV);
         {   // qkv projection with RoPE on q,k: fused in the GEMM epilogue when the deep-pipelined kernel runs
             GemmParams gp{h->h, L.qkv_w, h->qkv, L.qkv_b, Rl, Nqkv, D, D, D, Nqkv, EPI_ROPE_OP, ACT_NONE, h->cs, Hq + Hkv, h->hd};
             const bool tiles_ok = (Hq + Hkv) % 256 == 0;
@@ -236,25 +239,35 @@ bool run_decoder_stack(lr_engine* h, hipStream_t st, const int64_t* attention_ma
             // the GEMM kernels never look at M when they pick their form, so these rows come out bit-identical to a full layer.
             ap.O = h->attg;
             ap.qsel = h->tstat; ap.qsel_stride = 4; ap.qsel_last = gather == 2 ? 1 : 0;
+            site(lr_engine::SITE_ATTN);
             apply_prec(h, ap);
             emulate_attention_lo8(h, ap, Rl, d.kv_heads, h->hd, st);
             launch_attention(ap, B, h->hd, true, h->op_dt, st);
             launch_gather_norm_rows(h->x, h->tstat, S, gather == 2 ? 1 : 0, nullptr, 0.f, h->xg, B, D, st);      // (no weight: a plain row gather)
+            site(lr_engine::SITE_O);
             gemm(h, st, h->attg, L.o_w, h->xg, nullptr, B, D, Hq, Hq, Hq, D, EPI_RESADD_F32, ACT_NONE, &L.lo);
+            site(lr_engine::SITE_GATE_UP);
             launch_norm_rows(h->xg, L.ln2, nullptr, h->hg, B, D, d.rms_eps, h->op_dt, st, h->prec, 1,
                              lo8_norm_target(h, GemmParams{h->hg, L.gu_w, h->ffg, nullptr, B, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE, nullptr, 0, 0}));
-            gemm(h, st, h->hg, L.gu_w, h->ffg, nullptr, B, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE, &L.lgu, L.down_w, D);
+            gemm(h, st, h->hg, L.gu_w, h->ffg, nullptr, B, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE, &L.lgu, L.down_w, D, h->site_form(l, lr_engine::SITE_DOWN));
+            { const void* enc = h->pre_enc; const unsigned char* esc = h->pre_enc_sc; const bool e8 = h->pre_enc_hi8;
+              site(lr_engine::SITE_DOWN); h->pre_enc = enc; h->pre_enc_sc = esc; h->pre_enc_hi8 = e8; }      // (ffg's residual format was chosen for THIS site: keep its mark)
             gemm(h, st, h->ffg, L.down_w, h->xg, nullptr, B, D, I, I, I, D, EPI_RESADD_F32, ACT_NONE, &L.ldown);
             pruned = true;
             break;
         }
+        site(lr_engine::SITE_ATTN);
         apply_prec(h, ap);
         emulate_attention_lo8(h, ap, Rl, d.kv_heads, h->hd, st);
         launch_attention(ap, B, h->hd, true, h->op_dt, st);
+        site(lr_engine::SITE_O);
         gemm(h, st, h->att, L.o_w, h->x, nullptr, Rl, D, Hq, Hq, Hq, D, EPI_RESADD_F32, ACT_NONE, &L.lo);
+        site(lr_engine::SITE_GATE_UP);
         launch_norm_rows(h->x, L.ln2, nullptr, h->h, Rl, D, d.rms_eps, h->op_dt, st, h->prec, 1,
                          lo8_norm_target(h, GemmParams{h->h, L.gu_w, h->ff, nullptr, Rl, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE, nullptr, 0, 0}));
-        gemm(h, st, h->h, L.gu_w, h->ff, nullptr, Rl, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE, &L.lgu, L.down_w, D);      // ff is down's operand
+        gemm(h, st, h->h, L.gu_w, h->ff, nullptr, Rl, 2 * I, D, D, D, I, EPI_SWIGLU_OP, ACT_NONE, &L.lgu, L.down_w, D, h->site_form(l, lr_engine::SITE_DOWN));      // ff is down's operand
+        { const void* enc = h->pre_enc; const unsigned char* esc = h->pre_enc_sc; const bool e8 = h->pre_enc_hi8;
+          site(lr_engine::SITE_DOWN); h->pre_enc = enc; h->pre_enc_sc = esc; h->pre_enc_hi8 = e8; }
         gemm(h, st, h->ff, L.down_w, h->x, nullptr, Rl, D, I, I, I, D, EPI_RESADD_F32, ACT_NONE, &L.ldown);
     }
     h->set_form(-1);
@@ -542,6 +555,26 @@ int lr_set_precision_map(lr_handle h, int clip_form, int decoder_mid_form, int d
             throw std::invalid_argument("lr_set_precision_map: a stage can take form 0, or a split form the handle was created with "
                                         "(precise >= 1 for form 1, precise == 2 for form 2)");
         h->pm_clip = clip_form; h->pm_mid = decoder_mid_form; h->pm_first = decoder_first; h->pm_last = decoder_last;
+    });
+}
+int lr_set_precision_sites(lr_handle h, int qkv_form, int attention_form, int o_proj_form, int gate_up_form, int down_form) {
+    if (!h) return LR_EINVAL;
+    return guarded(h, [&] {
+        const int f[lr_engine::N_SITES] = {qkv_form, attention_form, o_proj_form, gate_up_form, down_form};
+        for (int v : f)
+            if (v != -1 && !(v == 1 && h->prec0) && !(v == 2 && h->lo8_0))
+                throw std::invalid_argument("lr_set_precision_sites: a site takes -1 (the layer's form), 1 (16-bit residual passes; handle created with "
+                                            "precise >= 1) or 2 (e4m3 residual passes; precise == 2)");
+        for (int i = 0; i < lr_engine::N_SITES; ++i) h->pm_site[i] = f[i];
+    });
+}
+int lr_set_attention_lazy_threshold(lr_handle h, float default_stages, float strict_stages) {
+    if (!h) return LR_EINVAL;
+    return guarded(h, [&] {
+        if (!(default_stages >= 0.f && default_stages <= 15.f && strict_stages >= 0.f && strict_stages <= 15.f))
+            throw std::invalid_argument("lr_set_attention_lazy_threshold: 0 (exact maximum) .. 15 log2 units");
+        h->att_lazy_t = default_stages;
+        h->att_lazy_t_strict = strict_stages;
     });
 }
 uint64_t lr_weights_epoch(lr_handle h) { return h ? h->weights_epoch : 0; }

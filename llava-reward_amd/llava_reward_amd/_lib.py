@@ -76,6 +76,8 @@ _SIGS = {
     "lr_read_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "lr_set_layer_limits": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "lr_set_precision_map": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "lr_set_precision_sites": (C.c_int, [C.c_void_p] + [C.c_int] * 5),
+    "lr_set_attention_lazy_threshold": (C.c_int, [C.c_void_p, C.c_float, C.c_float]),
     "lr_weights_epoch": (C.c_uint64, [C.c_void_p]),
     "lr_set_gemm_tile": (C.c_int, [C.c_void_p, C.c_int]),
     "lr_op_gemm_bt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]),

@@ -121,6 +121,7 @@ class RewardEngine:
         L.check(self.lib, self.lib.lr_create(C.byref(self._desc), self.device, C.byref(h)), None, "lr_create")
         self.h = h
         self.finalized = False
+        self.gemm_tile = -1          # lr_set_gemm_tile: -1 = the heuristic
 
     # ------------------------------------------------------------------ weights
     def weight_names(self):
@@ -260,12 +261,23 @@ class RewardEngine:
         L.check(self.lib, self.lib.lr_set_precision_map(self.h, clip_form, decoder_mid_form, decoder_first, decoder_last), self.h,
                 "lr_set_precision_map")
 
+    def set_precision_sites(self, qkv: int = -1, attention: int = -1, o_proj: int = -1, gate_up: int = -1, down: int = -1) -> None:
+        """Operand form per site of the decoder layers the precision map covers (lr_set_precision_sites): -1 the layer's, 1 strict, 2 default."""
+        L.check(self.lib, self.lib.lr_set_precision_sites(self.h, qkv, attention, o_proj, gate_up, down), self.h, "lr_set_precision_sites")
+
+    def set_attention_lazy_threshold(self, default_stages: float = 8.0, strict_stages: float = 0.0) -> None:
+        """Lazy softmax reference maximum of the attention launches (lr_set_attention_lazy_threshold; log2 units, 0 = exact): in stages
+        that run the default operand form / in stages that run the strict form."""
+        L.check(self.lib, self.lib.lr_set_attention_lazy_threshold(self.h, float(default_stages), float(strict_stages)), self.h,
+                "lr_set_attention_lazy_threshold")
+
     def weights_epoch(self) -> int:
         """Counts the calls that changed this handle's weights (lr_weights_epoch): what was derived from them is stale once it moves."""
         return int(self.lib.lr_weights_epoch(self.h))
 
     def set_gemm_tile(self, tile: int) -> None:
         L.check(self.lib, self.lib.lr_set_gemm_tile(self.h, tile), self.h, "lr_set_gemm_tile")
+        self.gemm_tile = int(tile)
 
     def workspace_bytes(self) -> int:
         return int(self.lib.lr_workspace_bytes(self.h))

@@ -254,6 +254,24 @@ class RewardModel:
             t_start = _now(self.device)
             cands = self._form_candidates()
             strict = score(cands[-1][1])
+            # The yardstick's own fp32 noise on these weights: the strict form once more with the attention launches' lazy reference
+            # maximum (threshold 8: the same softmax, other fp32 roundings of the exponents' arguments -- a numerically equivalent
+            # re-statement of the strict form).  On benign weights the two sit ~1e-6 apart; a weight set that amplifies rounding shows
+            # 1e-4 and more -- the reference's own fp32 arithmetic sits 2.1e-4 from the fp64 value on such a row
+            # (tests/golden/fp64_full_rows.json) -- and no cheaper form can be asked to sit closer to the strict one than the strict one
+            # sits to itself: the budget becomes max(budget, 1.5 x floor), capped at 4/3 of the budget (2e-4 at the default: the locked
+            # form's error against the reference then stays inside the 3e-4 the golden tests hold it to).
+            floor = 0.0
+            if source == "probe":
+                eng.set_attention_lazy_threshold(8.0, 8.0)
+                try:
+                    for a, st in zip(score(cands[-1][1]), strict):
+                        x = float((a - st).abs().max()) if a.numel() else 0.0
+                        floor = float("inf") if x != x else max(floor, x)
+                finally:
+                    eng.set_attention_lazy_threshold(8.0, 0.0)
+                if floor == floor and floor != float("inf"):
+                    budget = min(max(budget, 1.5 * floor), budget * 4.0 / 3.0)
             import torch.distributed as dist
             # Collective ONLY in the explicit calibrate() on user batches (documented as collective).  The probe of .to('cuda') / of
             # a forward after a weight upload must not be one: the reference's .to() and forward have no collectives (rank-0-only
@@ -278,7 +296,8 @@ class RewardModel:
                     break
             self.operand_form = chosen
             self.form_info = {"form": chosen, "default_vs_strict": tried.get("default"), "distance_to_strict": tried, "source": source,
-                              "rows": int(sum(a.shape[0] for a in strict)), "budget": budget, "seconds": _now(self.device) - t_start}
+                              "rows": int(sum(a.shape[0] for a in strict)), "budget": budget, "strict_noise_floor": floor if source == "probe" else None,
+                              "seconds": _now(self.device) - t_start}
             return dict(self.form_info)
         finally:
             self._in_probe = False
@@ -434,6 +453,12 @@ class RewardModel:
         pix = inputs_batch["pixel_values"]
         grid = torch.as_tensor(inputs_batch["image_grid_thw"]).cpu().long()
         unit = self.config.vision.merge_unit
+        if bool((grid[:, 0] != 1).any()):
+            # rw_model:356 hands image_grid_thw to the ViT as it is; the HF processor gives every IMAGE t = 1 (a still is its own temporal
+            # patch pair) and multi-frame grids travel under other keys (pixel_values_videos / video_grid_thw) that custom_forward never
+            # reads -- so t > 1 under image_grid_thw is a malformed batch, refused here by name instead of deep inside the engine
+            raise ValueError(f"image_grid_thw[:, 0] must be 1 (still images; got t = {grid[:, 0].tolist()}): video grids are not served by the "
+                             "qwen branch of custom_forward (rw_model_general_preference.py:354-357 reads image inputs only)")
         # (always checked, check_inputs="deferred" included: lr_forward_qwen has no slot check of its own -- a mismatch would neither
         #  raise nor come back NaN -- and one scalar per forward is all this costs)
         n_slots = int((ids == self.config.image_token_id).sum())

@@ -32,7 +32,7 @@ def record_locked_form(golden_name, dtype, model, err):
         fi = dict(model.form_info or {})
         with open(os.path.join(d, "locked_forms.jsonl"), "a") as f:
             f.write(json.dumps({"golden": golden_name, "mode": dtype, "backbone": model.model_type, "form": model.operand_form,
-                                "distance_to_strict": fi.get("distance_to_strict"), "probe_rows": fi.get("rows"), "budget": fi.get("budget"),
+                                "distance_to_strict": fi.get("distance_to_strict"), "probe_rows": fi.get("rows"), "budget": fi.get("budget"), "strict_noise_floor": fi.get("strict_noise_floor"),
                                 "probe_seconds": fi.get("seconds"), "max_batch": model._opts["max_batch"], "max_seq": model._opts["max_seq"],
                                 "max_crops": model._opts["max_crops"], "abs_err_vs_reference": err}) + "\n")
     except OSError:

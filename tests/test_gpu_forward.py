@@ -174,6 +174,54 @@ def test_operand_form_is_locked_on_the_weights_by_to_cuda():
     assert off.form_info is None and off.operand_form == "default"
 
 
+def test_precision_sites_are_independent_and_consistent():
+    """lr_set_precision_sites (round 6): the operand form of each SITE of the decoder layers the precision map covers -- qkv (input norm +
+    projection), attention (exact / lazy softmax maximum), o_proj, gate_up (post-attention norm + projection), down -- on top of the
+    per-layer form.  All sites strict IS the strict form, all sites default IS strict-vision (bit for bit: a site's form does not leak
+    into its neighbours' operands); every single-site mix is a valid model (on the oracle) and really changes the arithmetic of that
+    site; with un-merged adapters too; the gathered last layer and the kept-hidden-states pass agree; bad values are refused."""
+    from llava_reward_amd._lib import HipError
+    cfg = synth.tiny_config(hidden=1024, intermediate=2048, heads=16, layers=4)
+    seed = 31
+    batch = synth.synth_batch(cfg, seed, [7, 3, 5], [(1, 1), (1, 2), (1, 1)], max_crops=3)
+    W = orc.weights_to_torch(synth.make_weights(cfg, seed, synth.PROFILE_OUTLIER))
+    ref = orc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"])
+    m = _model(cfg, seed, "f16x2f8", upload=False, profile=synth.PROFILE_OUTLIER, calibrate=False)
+    eng = m.engine
+
+    def fwd(cmap, sites=()):
+        eng.set_precision_map(*cmap)
+        eng.set_precision_sites(*sites)
+        return _fwd(m, batch)
+    strict, sv = fwd((1, 1, 0, 0)), fwd((1, -1, 0, 0))
+    assert torch.equal(strict, _fwd(_model(cfg, seed, "f16x2", upload=False, profile=synth.PROFILE_OUTLIER), batch))
+    assert torch.equal(fwd((1, 1, 0, 0), (1, 1, 1, 1, 1)), strict)
+    assert torch.equal(fwd((1, 1, 0, 0), (2, 2, 2, 2, 2)), sv)                 # every decoder site back in the default form: strict-vision
+    assert torch.equal(fwd((1, -1, 0, 0), (1, 1, 1, 1, 1)), sv)                # no strict layer range: the sites have nothing to refine
+    seen = {tuple(strict.flatten().tolist()), tuple(sv.flatten().tolist())}
+    for i, name in enumerate(("qkv", "attention", "o_proj", "gate_up", "down")):
+        one = fwd((1, 1, 0, 0), tuple(2 if j == i else 1 for j in range(5)))
+        err = (one - ref).abs().max().item()
+        print(f"[sites] {name} default, the others strict: |reward - oracle| = {err:.2e}  |. - strict| = {(one - strict).abs().max().item():.2e}")
+        assert torch.isfinite(one).all() and err < TOL_X8
+        if name != "attention":                                                # (S < 64 keys here: the lazy maximum never differs from the exact one)
+            assert tuple(one.flatten().tolist()) not in seen                   # that site's arithmetic really changed, and differently from every other mix
+        seen.add(tuple(one.flatten().tolist()))
+        m.keep_hidden_states = True                                            # the gathered last layer and the full one walk the same sites
+        assert torch.equal(_fwd(m, batch), one)
+        m.keep_hidden_states = False
+    # a layer range: sites apply inside it only
+    part = fwd((1, 1, 0, 2), (1, 2, 2, 1, 2))
+    assert torch.isfinite(part).all() and (part - ref).abs().max().item() < TOL_X8 and not torch.equal(part, fwd((1, 1, 0, 2)))
+    for bad in ((0, -1, -1, -1, -1), (3, 1, 1, 1, 1), (-2, 1, 1, 1, 1)):
+        with pytest.raises(HipError):
+            eng.set_precision_sites(*bad)
+    with pytest.raises(HipError):                                              # a strict-only handle has no e4m3 form to give a site
+        _model(cfg, seed, "f16x2", upload=False).engine.set_precision_sites(2, 1, 1, 1, 1)
+    eng.set_precision_sites()
+    assert torch.equal(fwd((1, 1, 0, 0)), strict)
+
+
 def test_probe_rows_do_not_depend_on_the_engine_capacity():
     """Round 6: the probe rows are fixed tiers (probe.py) -- an engine scores the largest tier that fits it whole and reshapes nothing --
     so two engines of different capacity (batch 1 / 6, other max_seq and max_crops, hence other chunkings of the same fixed batch) on ONE

@@ -167,8 +167,12 @@ def test_qwen_training_flag_and_errors():
     vid = dict(batch)
     vid["image_grid_thw"] = batch["image_grid_thw"].copy()
     vid["image_grid_thw"][0] = [2, 4, 8]             # a video grid with the same patch count
-    with pytest.raises(RuntimeError, match="video"):
+    with pytest.raises(ValueError, match="video grids are not served"):      # (the wrapper refuses it by name; the engine would too: LR_EINVAL)
         _fwd(m, vid)
+    tv = {k: torch.from_numpy(v).cuda() for k, v in vid.items()}
+    from llava_reward_amd._lib import HipError
+    with pytest.raises(HipError, match="video"):
+        m.engine.forward_qwen(tv["input_ids"], tv["attention_mask"], tv["pixel_values"], vid["image_grid_thw"])
 
 
 CASES = sorted(glob.glob(os.path.join(GOLD, "ref_qwen_tiny_*.json")) + glob.glob(os.path.join(GOLD, "ref_qwen_quirk_*.json")))

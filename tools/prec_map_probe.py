@@ -11,7 +11,7 @@ from llava_reward_amd.model import RewardModel
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 profile = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-cfg = synth.full_config()
+cfg = synth.full_config(**({"lora_rank": int(os.environ["PROBE_LORA"])} if os.environ.get("PROBE_LORA") else {}))      # PROBE_LORA=128: un-merged rank-128 adapters
 b = synth.synth_batch(cfg, 77, [128, 64, 200, 17, 96, 128, 33, 150][:rows] + [128] * max(0, rows - 8), (4, 4), with_pixels=False)
 ids, mask = torch.from_numpy(b["input_ids"]).cuda(), torch.from_numpy(b["attention_mask"]).cuda()
 pix = torch.randn(rows, 17, 3, 336, 336, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
@@ -50,6 +50,32 @@ if len(sys.argv) > 3 and sys.argv[3] == "ladder":       # round 5: the finer can
             ("strict-vision", (1, -1, 0, 0))] + \
            [(f"strict-vision+decoder 0..{k - 1} strict", (1, 1, 0, L - k)) for k in (2, 4, 6, 8, 10, 12, 16)] + \
            [(f"default, decoder last {k} single pass", (-1, 0, L - k, 0)) for k in (1, 2, 4, 8)]
+if len(sys.argv) > 3 and sys.argv[3] == "sites":        # round 6: which SITES of the strict decoder layers need their 16-bit residuals (lr_set_precision_sites)
+    k = int(sys.argv[4]) if len(sys.argv) > 4 else L          # strict decoder layers 0..k-1 (vision tower strict), the rest default
+    names = ("qkv", "attention", "o_proj", "gate_up", "down")
+    SITES = [("all five sites strict", (1, 1, 1, 1, 1))] + [(f"{n} default, the others strict", tuple(2 if j == i else 1 for j in range(5))) for i, n in enumerate(names)] + \
+            [("qkv + gate_up strict (the normed-stream GEMMs)", (1, 2, 2, 1, 2)), ("qkv + gate_up + attention strict", (1, 1, 2, 1, 2)),
+             ("qkv + gate_up + down strict", (1, 2, 2, 1, 1)), ("qkv + gate_up + o_proj strict", (1, 2, 1, 1, 2)),
+             ("o_proj + down strict (the residual-add GEMMs)", (2, 2, 1, 2, 1)), ("gate_up + down strict (the MLP)", (2, 2, 2, 1, 1)),
+             ("qkv + attention + o_proj strict (the attention block)", (1, 1, 1, 2, 2)), ("all five sites default (= strict-vision)", (2, 2, 2, 2, 2))]
+    print("the attention launches of DEFAULT-form stages with the lazy maximum (threshold 8) / with the exact one (lr_set_attention_lazy_threshold):")
+    for nm, args in [("default everywhere", (-1, -1, 0, 0)), ("strict-vision", (1, -1, 0, 0))] + [(f"strict-vision+decoder 0..{kk - 1} strict", (1, 1, 0, L - kk)) for kk in (4, 8, 12, 16)]:
+        out = []
+        for thr in (8.0, 0.0):
+            m.engine.set_attention_lazy_threshold(thr, 0.0)
+            r, ms = run(*args)
+            out.append(f"{(r - ref).abs().max().item():9.2e} {ms:8.1f} ms")
+        print(f"{nm:56s} lazy {out[0]}   exact {out[1]}", flush=True)
+    m.engine.set_attention_lazy_threshold(0.0, 0.0)
+    print(f"strict-vision + decoder layers 0..{k - 1} strict, by site (exact maximum in every attention launch):")
+    for name, st in SITES:
+        m.engine.set_precision_sites(*st)
+        r, ms = run(1, 1, 0, L - k)
+        d = (r - ref).abs()
+        print(f"{name:56s} {d.pow(2).mean().sqrt().item():9.2e} {d.max().item():9.2e} {ms:8.1f}", flush=True)
+    m.engine.set_precision_sites()
+    m.engine.set_attention_lazy_threshold(8.0, 0.0)
+    sys.exit(0)
 for name, args in MAPS:
     r, ms = run(*args)
     d = (r - ref).abs()
