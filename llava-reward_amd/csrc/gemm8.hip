@@ -78,6 +78,9 @@ __device__ __forceinline__ f32x4 mfma_f8(const frag_t a0, const frag_t a1, const
 // SEL: which byte of `ea` holds the E8M0 scale of the A rows (four row tiles share one register)
 template <int SEL>
 __device__ __forceinline__ f32x4 mfma_f8s(const frag_t a0, const frag_t a1, const frag_t b0, const frag_t b1, const f32x4 c, const int ea, const int eb) {
+#if defined(LR_GEMM_DIAG_NOSCALE)      // diagnostic (results invalid): the un-scaled encoding of the same matrix instruction -- what do the scale operands cost?
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(join32(a0, a1), join32(b0, b1), c, 0, 0, 0, 0, 0, 0);
+#endif
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(join32(a0, a1), join32(b0, b1), c, 0, 0, SEL, ea, 0, eb);   // x 2^(ea.byte[SEL] - 127) x 2^(eb - 127)
 }
 // FP6 (OCP MX e2m3, cbsz = blgp = 2): 24 bytes per lane and operand -- the 16-byte and the 8-byte part of the lane's 32 elements --
@@ -1058,7 +1061,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 const int col = n0 + c8 * 8;
                 float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
                 if (p.bias && col < p.N) { b0 = *(const float4*)(p.bias + col); b1 = *(const float4*)(p.bias + col + 4); }
-#pragma unroll 2
+#pragma unroll 2        // (4 and 8 measured level on every shape, round 6: the loop is not bound by its own latency chain)
                 for (int it = 0; it < 128 / (8 * RPW); ++it) {
                     const int rl = it * 8 * RPW + wave * RPW + lane / LPR;
                     const int row = rowq + rl;
