@@ -39,6 +39,9 @@
 #ifndef LR_GEMM_SADDR
 #define LR_GEMM_SADDR 1
 #endif
+#ifndef LR_GEMM_COMP_WAIT
+#define LR_GEMM_COMP_WAIT 1
+#endif
 
 namespace lr {
 
@@ -403,6 +406,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         const unsigned char* sc_tile = p.aexp + (size_t)(NW == 1 ? mi >> 1 : mi) * 1024;
         const size_t sc_plane = (size_t)((p.M + 255) >> 8) * 1024;
         const int nsl = nk_lo - nk_hi, nsg = (nsl + 3) >> 2;
+        const bool late_sc = nsg > SC_GROUPS;          // more scale groups than LDS slots: later groups follow the ones they replace
         auto issue_scales = [&](int g) {
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + NS * HT + (g & (SC_GROUPS - 1)) * 1024);
             int l16 = lane * 16;
@@ -563,8 +567,10 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                         typedef __attribute__((address_space(3))) const volatile v2i_t lds_scale_t;       // an LDS read, never a flat one
                         const v2i_t e2 = *(lds_scale_t*)(lds_base + NS * HT + (((j >> 2) & (SC_GROUPS - 1)) << 10) + ((j & 3) << 8) + sc_voff);
                         ea[0] = (NW == 1 && (mi & 1)) ? e2.y : e2.x; ea[1] = e2.y;
-                        const int g = (j >> 2) - 1 + SC_GROUPS;        // its slot was last read in the K-tile before this one
-                        if ((j & 3) == 0 && j >= 4 && g < nsg && wave == (g & 7)) { issue_scales(g); scl = true; }
+                        if (late_sc) {                                 // (K > 16384 only: one uniform test per K-tile for every other shape)
+                            const int g = (j >> 2) - 1 + SC_GROUPS;    // its slot was last read in the K-tile before this one
+                            if ((j & 3) == 0 && j >= 4 && g < nsg && wave == (g & 7)) { issue_scales(g); scl = true; }
+                        }
                     }
                 }
                 if (more) {
@@ -599,6 +605,12 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 if constexpr (DBG == 3) t2 = stamp();
                 // ---------------- COMPUTE ----------------
                 __builtin_amdgcn_s_setprio(1);
+                // The A fragments were requested in LOAD, a counted wait and a barrier ago: they have landed.  Retiring them HERE (a
+                // real s_waitcnt lgkmcnt(0): vmcnt / expcnt untouched) clears the compiler's in-order scoreboard before the B reads
+                // of this segment are issued; without it the waits it counts for the A fragments (lgkmcnt(3), (1), (0) in the middle
+                // of the first block) also cover whatever B reads it has interleaved in front of them -- freshly issued, so their
+                // LDS latency was exposed inside the block (round 6; -DLR_GEMM_COMP_WAIT=0: the old schedule).
+                if constexpr (LR_GEMM_COMP_WAIT) __builtin_amdgcn_s_waitcnt(0xC07F);
                 if constexpr (DBG != 4) {
                     if constexpr (LO == 3) {
                         if (sp == 0) {
@@ -612,6 +624,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 #pragma unroll
                         for (int f = 0; f < 4; ++f) bg[f] = *(const frag_t*)(sB1 + boff[f]);
                     }
+                    if constexpr (LR_GEMM_COMP_WAIT) { if (sp == 0) __builtin_amdgcn_sched_barrier(0); }      // (the B1 requests stay in front of the first block)
                     constexpr int q0 = 0, q1 = 1, q3 = 3, q2 = 2;
                     const int qa = sp == 0 ? q0 : q3, qb = sp == 0 ? q1 : q2;      // first block uses bf (B0), second bg (B1)
                     const bool do_a = NW != 1 || sp == 0, do_b = do_a && NW != 2;        // (compile-time constants after unrolling)
@@ -638,13 +651,24 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 #pragma unroll
                             for (int j = 0; j < 2; ++j) acc[qa][i][j] = Op<OT>::mfma16(af[i * 2 + ks], bf[j * 2 + ks], acc[qa][i][j]);
                     }
-                    if (F8 == 3 && ISS == 1 && sp == 1 && kt + 1 < nk) {      // the next K-tile is an FP6 one
+                    // bf <- B0 of the next K-tile, BEHIND the first block's MFMAs and unconditionally (round 6).  It used to sit under
+                    // `kt + 1 < nk`; in the residual K-tiles the compiler hoisted the four reads to the top of the segment, and because
+                    // they sat in a branch its counted waits for the A fragments (requested in LOAD, long landed) had to hold on the
+                    // path WITHOUT them too: lgkmcnt(3) in front of the first MFMA = one of the reads just issued: their LDS latency
+                    // exposed in every residual super-phase 1 (stamps: COMPUTE 788 cycles against 650 in super-phase 0).  After the last
+                    // K-tile the reads fetch bytes nobody uses (the slot is inside the ring; LDS reads cannot fault).
+                    // (a scheduling barrier between the two blocks in BOTH super-phases: in super-phase 0 the scheduler otherwise pulls
+                    //  second-block MFMAs -- which need the B1 fragments requested at the top of this segment -- into the first block,
+                    //  with a counted wait in front of them ~100 cycles after the request)
+                    if constexpr (LR_GEMM_COMP_WAIT) __builtin_amdgcn_sched_barrier(0);
+                    else if (sp == 1) __builtin_amdgcn_sched_barrier(0);
+                    if (F8 == 3 && ISS == 1 && sp == 1) {      // the next K-tile is an FP6 one
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             bf[j] = *(const frag_t*)(sB0n + b6H + j * 1024);
                             bfl[j] = *(const frag2_t*)(sB0n + b6L + j * 512);
                         }
-                    } else if (sp == 1 && kt + 1 < nk) {
+                    } else if (sp == 1) {
 #pragma unroll
                         for (int f = 0; f < 4; ++f) bf[f] = *(const frag_t*)(sB0n + boff[f]);
                     }
