@@ -1085,30 +1085,42 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 const int col = n0 + c8 * 8;
                 float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
                 if (p.bias && col < p.N) { b0 = *(const float4*)(p.bias + col); b1 = *(const float4*)(p.bias + col + 4); }
+                // The activation and the residual format are uniform over the launch: the loop is instantiated per (activation, format)
+                // and picked ONCE (round 6).  Tested inside the loop -- as until then -- the two `p.act` comparisons were three scalar
+                // branches per ELEMENT (64 per wave-iteration: the optimiser did not unswitch the partially unrolled loop) and `p.oexp`
+                // one more per row.
+                auto out_loop = [&](auto act_tag, auto oexp_tag) {
+                    constexpr int ACT = decltype(act_tag)::value;
+                    constexpr bool OEXP = decltype(oexp_tag)::value != 0;
 #pragma unroll 2        // (4 and 8 measured level on every shape, round 6: the loop is not bound by its own latency chain)
-                for (int it = 0; it < 128 / (8 * RPW); ++it) {
-                    const int rl = it * 8 * RPW + wave * RPW + lane / LPR;
-                    const int row = rowq + rl;
-                    const float* sp = stg + rl * SLD + c8 * 8;
-                    float4 v0 = *(const float4*)sp, v1 = *(const float4*)(sp + 4);
-                    if (row < p.M && col < p.N) {
-                        float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
+                    for (int it = 0; it < 128 / (8 * RPW); ++it) {
+                        const int rl = it * 8 * RPW + wave * RPW + lane / LPR;
+                        const int row = rowq + rl;
+                        const float* sp = stg + rl * SLD + c8 * 8;
+                        float4 v0 = *(const float4*)sp, v1 = *(const float4*)(sp + 4);
+                        if (row < p.M && col < p.N) {
+                            float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            if (p.act == ACT_QUICK_GELU) v[e] = x_sigmoid_fast(v[e], 1.702f);
-                            else if (p.act == ACT_GELU_ERF) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752440f));
-                        }
-                        if (p.oexp) {        // each half-wave row holds two 128-column blocks: lanes 0-15 and 16-31 of it
-                            store_hi_lo8(v, (unsigned short*)p.C + (size_t)row * p.ldc, p.split, col, p.oexp + lo8_scale_at(row, col >> 7, p.M), (lane & 15) == 0);
-                        } else {
-                            uint4 w, wl;
-                            split2p<OT>(v[0], v[1], w.x, wl.x); split2p<OT>(v[2], v[3], w.y, wl.y);
-                            split2p<OT>(v[4], v[5], w.z, wl.z); split2p<OT>(v[6], v[7], w.w, wl.w);
-                            *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + col) = w;
-                            if (p.split > 0) *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + p.split + col) = wl;
+                            for (int e = 0; e < 8; ++e) {
+                                if constexpr (ACT == ACT_QUICK_GELU) v[e] = x_sigmoid_fast(v[e], 1.702f);
+                                else if constexpr (ACT == ACT_GELU_ERF) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752440f));
+                            }
+                            if constexpr (OEXP) {        // each half-wave row holds two 128-column blocks: lanes 0-15 and 16-31 of it
+                                store_hi_lo8(v, (unsigned short*)p.C + (size_t)row * p.ldc, p.split, col, p.oexp + lo8_scale_at(row, col >> 7, p.M), (lane & 15) == 0);
+                            } else {
+                                uint4 w, wl;
+                                split2p<OT>(v[0], v[1], w.x, wl.x); split2p<OT>(v[2], v[3], w.y, wl.y);
+                                split2p<OT>(v[4], v[5], w.z, wl.z); split2p<OT>(v[6], v[7], w.w, wl.w);
+                                *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + col) = w;
+                                if (p.split > 0) *(uint4*)((unsigned short*)p.C + (size_t)row * p.ldc + p.split + col) = wl;
+                            }
                         }
                     }
-                }
+                };
+                const bool oe = p.oexp != nullptr;
+                if (p.act == ACT_QUICK_GELU) { if (oe) out_loop(IC<ACT_QUICK_GELU>{}, IC<1>{}); else out_loop(IC<ACT_QUICK_GELU>{}, IC<0>{}); }
+                else if (p.act == ACT_GELU_ERF) { if (oe) out_loop(IC<ACT_GELU_ERF>{}, IC<1>{}); else out_loop(IC<ACT_GELU_ERF>{}, IC<0>{}); }
+                else { if (oe) out_loop(IC<ACT_NONE>{}, IC<1>{}); else out_loop(IC<ACT_NONE>{}, IC<0>{}); }
             } else {
                 // fp32 out / residual add: 64 float4 per row, one row per wave-iteration (1 KB contiguous)
                 float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
