@@ -11,7 +11,15 @@ sys.path.insert(0, os.path.join(ROOT, "llava-reward_amd"))
 import torch
 from llava_reward_amd import _lib as L
 
-libs = [(os.path.basename(p), L.load(os.path.abspath(p))) for p in sys.argv[1:3]]
+def _load(path):          # only the two entry points this script calls: older builds lack later ABI symbols
+    lib = C.CDLL(os.path.abspath(path))
+    for name in ("lr_op_gemm_bt_mixed", "lr_op_lo8_scratch_bytes"):
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = L._SIGS[name]
+    return lib
+
+
+libs = [(os.path.basename(p), _load(p)) for p in sys.argv[1:3]]
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 st = torch.cuda.current_stream()
 P = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
