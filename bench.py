@@ -106,7 +106,7 @@ def qwen_flop_per_row(cfg, grid, S):
     return float(lin + att + patch + merger + dec + datt)
 
 
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r5_pmc_gemm_gate_up.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r6_pmc_gemm_gate_up.json")
 KERNEL_SOURCES = ("llava-reward_amd/csrc/gemm8.hip", "llava-reward_amd/csrc/common.h")
 
 
@@ -120,7 +120,7 @@ def kernel_source_sha16():
 
 def pmc_for(form):
     """PMC figures of the dominant kernel (HBM-side bytes per launch, MFMA-pipe busy fraction, effective clock) from the committed
-    rocprofv3 summary profiles/r5_pmc_gemm_gate_up.json (tools/pmc_summary.py writes it from separate --pmc passes of
+    rocprofv3 summary profiles/r6_pmc_gemm_gate_up.json (tools/pmc_summary.py writes it from separate --pmc passes of
     tools/gemm_one.py).  They describe THIS build only if the kernel sources are the ones that were profiled: the file records
     their hash and the kernel's template signature; on any mismatch the fields are null (stale profile) instead of a stale number."""
     none = {"traffic": None, "mfma_busy": None, "clock_ghz": None, "pmc_source": None}

@@ -174,6 +174,24 @@ def test_operand_form_is_locked_on_the_weights_by_to_cuda():
     assert off.form_info is None and off.operand_form == "default"
 
 
+def test_reward_dtype_does_not_reach_the_operand_form_probe():
+    """Advisor (round 5): with reward_dtype=torch.bfloat16 the probe compared bf16-rounded rewards -- an ulp of 4e-3 .. 1.6e-2 against a
+    budget of 1.5e-4, so a form 5e-4 from strict read as 0 and was locked.  The rounding is applied to the caller's rewards only: both
+    models measure the same distances and lock the same form, on benign and on outlier-bearing weights."""
+    cfg = synth.tiny_config(hidden=1024, intermediate=2048, heads=16, layers=3)
+    seed = 37
+    batch = synth.synth_batch(cfg, seed, [7, 3, 5], (1, 1))
+    for profile in (0, synth.PROFILE_OUTLIER):
+        a = _model(cfg, seed, "f16x2f8", upload=False, profile=profile)
+        b = _model(cfg, seed, "f16x2f8", upload=False, profile=profile, reward_dtype=torch.bfloat16)
+        assert a.form_info["distance_to_strict"] == b.form_info["distance_to_strict"] and a.operand_form == b.operand_form
+        assert a.form_info["strict_noise_floor"] == b.form_info["strict_noise_floor"]
+        ra, rb = _fwd(a, batch), _fwd(b, batch)
+        assert rb.dtype == torch.bfloat16 and torch.equal(rb, ra.to(torch.bfloat16))
+        info = b.calibrate({k: torch.from_numpy(v).cuda() for k, v in batch.items()})          # the explicit check on caller batches: fp32 inside as well
+        assert all(d == d and (d == 0.0 or d > 1e-9) for d in info["distance_to_strict"].values())
+
+
 def test_precision_sites_are_independent_and_consistent():
     """lr_set_precision_sites (round 6): the operand form of each SITE of the decoder layers the precision map covers -- qkv (input norm +
     projection), attention (exact / lazy softmax maximum), o_proj, gate_up (post-attention norm + projection), down -- on top of the
