@@ -42,6 +42,9 @@
 #ifndef LR_GEMM_COMP_WAIT
 #define LR_GEMM_COMP_WAIT 1
 #endif
+#ifndef LR_GEMM_PRE
+#define LR_GEMM_PRE 0
+#endif
 
 namespace lr {
 
@@ -203,6 +206,24 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
     const int my_xcd = (int)blockIdx.x & 7, per_xcd = (int)gridDim.x >> 3;
     const bool dyn = PB == 2 && p.sched != nullptr;
     int Ldyn = -1;
+    // PRE (round 6): the first PF2 half-tiles of the NEXT tile are fetched into registers under the second half of this tile's epilogue
+    // -- the accumulators are dead behind its staging writes -- and written to the ring at the top of the next tile, where the LDS-DMA
+    // prologue used to expose its whole latency (2-3 us of a 48 us CLIP tile); the next tile's scale groups go out by LDS-DMA at the
+    // same point.  Same bytes at the same LDS addresses: the K loop cannot tell.
+    constexpr bool PRE = LR_GEMM_PRE && PB == 2 && LR_GEMM_SADDR && F8 != 3 && (DBG == 0 || DBG == 3 || DBG == 9 || (DBG >= 6 && DBG <= 8));
+    constexpr int SC_OFF = PRE ? 2 : 0;          // scale group g lives in slot (g + SC_OFF) & 31: slots 0, 1 lie under the staging area's last 2 KB
+    frag_t pre[6][2];
+#pragma unroll
+    for (int g = 0; g < 6; ++g) { asm volatile("" : "=v"(pre[g][0])); asm volatile("" : "=v"(pre[g][1])); }      // (defined, costs nothing)
+    bool pre_ok = false;
+    int Lnext = -1;
+    auto tile_of = [&](int L, int& mi_, int& ni_) {
+        const int band = L / (p.gm * Nt);
+        const int within = L - band * (p.gm * Nt);
+        const int rows_in_band = min(p.gm, Mt - band * p.gm);
+        mi_ = band * p.gm + within % rows_in_band;
+        ni_ = within / rows_in_band;
+    };
     for (int vb = blockIdx.x; vb < nwg;) {
         tstamp(0);
         int L;
@@ -407,15 +428,16 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         const size_t sc_plane = (size_t)((p.M + 255) >> 8) * 1024;
         const int nsl = nk_lo - nk_hi, nsg = (nsl + 3) >> 2;
         const bool late_sc = nsg > SC_GROUPS;          // more scale groups than LDS slots: later groups follow the ones they replace
-        auto issue_scales = [&](int g) {
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + NS * HT + (g & (SC_GROUPS - 1)) * 1024);
+        auto issue_scales_of = [&](const unsigned char* tile_base, int g) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + NS * HT + ((g + SC_OFF) & (SC_GROUPS - 1)) * 1024);
             int l16 = lane * 16;
             asm volatile("" : "+v"(l16));          // rebuilt at each call: hoisted, the address is one more 64-bit value spilled across the K loop
-            const unsigned char* src = sc_tile + (size_t)g * sc_plane + l16;
+            const unsigned char* src = tile_base + (size_t)g * sc_plane + l16;
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
         };
+        auto issue_scales = [&](int g) { issue_scales_of(sc_tile, g); };
 
         // F8 == 3: the FP6 K-tiles' scales, one byte per (row, 32 elements) for both operands: per residual K-tile j one KB of A scales
         // (lane (row, q) of wave group wr: 8 bytes = its 4 row tiles of A half 0, then of A half 1, block q) and one KB of W scales
@@ -456,8 +478,10 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         static_assert(F8 != 2 || (NS + 2) * HT <= 160 * 1024, "the scale slices live behind the ring");
         static_assert(NS - PF2 >= 2, "ring hazard distances (super-phase schedule)");
         int islot = 0;
+        const bool pre_now = PRE && pre_ok;          // this tile's first half-tiles are in registers, its scale groups 0 .. 29 on their way
         if constexpr (F8 == 2) {         // this tile's scale groups first: the oldest entries of the queue, retired by the prologue's wait
-            for (int g = wave; g < min(nsg, SC_GROUPS); g += 8) issue_scales(g);
+            for (int g = wave; g < min(nsg, SC_GROUPS); g += 8)
+                if (!pre_now || g >= SC_GROUPS - SC_OFF) issue_scales(g);
         }
         if constexpr (F8 == 3) {
             for (int x = wave; x < min(2 * nsl, 32); x += 8) issue_scales6(x);
@@ -477,6 +501,18 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                              : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
             }
         };
+        if (pre_now) {
+            // (the previous tile's closing barrier is behind us: its staging reads are done; the bookkeeping is the DMA path's)
+#pragma unroll
+            for (int g = 0; g < PF2; ++g) {
+                if ((g & 3) == 0) ktile_begin();
+                *(frag_t*)(smem + islot * HT + tid * 16) = pre[g][0];
+                *(frag_t*)(smem + islot * HT + 8192 + tid * 16) = pre[g][1];
+                if ((g & 3) == 3) ktile_end();
+                islot = (islot + 1 == NS) ? 0 : islot + 1;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
 #pragma unroll
         for (int g = 0; g < PF2; ++g) {
             if (g < Gtot) {
@@ -488,6 +524,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         }
         if (Gtot > PF2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT2) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         LR_BARRIER();
         if (wr == 1) LR_BARRIER();                      // stagger the second wave group by one barrier
         tstamp(1);
@@ -565,7 +602,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                     if (sp == 0) {
                         typedef int v2i_t __attribute__((ext_vector_type(2)));
                         typedef __attribute__((address_space(3))) const volatile v2i_t lds_scale_t;       // an LDS read, never a flat one
-                        const v2i_t e2 = *(lds_scale_t*)(lds_base + NS * HT + (((j >> 2) & (SC_GROUPS - 1)) << 10) + ((j & 3) << 8) + sc_voff);
+                        const v2i_t e2 = *(lds_scale_t*)(lds_base + NS * HT + ((((j >> 2) + SC_OFF) & (SC_GROUPS - 1)) << 10) + ((j & 3) << 8) + sc_voff);
                         ea[0] = (NW == 1 && (mi & 1)) ? e2.y : e2.x; ea[1] = e2.y;
                         if (late_sc) {                                 // (K > 16384 only: one uniform test per K-tile for every other shape)
                             const int g = (j >> 2) - 1 + SC_GROUPS;    // its slot was last read in the K-tile before this one
@@ -882,6 +919,88 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         // use, inside the residual K-tile loop -- drained the DMA ring every K-tile of the RoPE kernel.
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
+        typedef __attribute__((address_space(3))) volatile int lds_int_t;                    // LDS accesses, not flat ones
+        // the word the claimed tile travels through: behind the staging area -- or, with the early fetch (whose scale groups land there
+        // while the epilogue runs), in the padding of staging row 0
+        lds_int_t* next_l = (lds_int_t*)(lds_base + (PRE ? 256 * 4 : 9 * HT));
+        auto resolve_claim = [&]() {          // thread 0: claim -> tile index (or -1), left in *next_l
+            int Ln = -1;
+            const int i = per_xcd + claim;
+            if (i < chunk_n(my_xcd)) Ln = chunk0(my_xcd) + i;
+            else {
+                for (int tries = 0; tries < 16 && Ln < 0; ++tries) {      // own chunk exhausted: help the XCD with the most tiles left
+                    int v = -1, best = 0;
+                    for (int y = 0; y < 8; ++y) {
+                        const int rem = chunk_n(y) - per_xcd - __hip_atomic_load(&p.sched[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (rem > best) { best = rem; v = y; }
+                    }
+                    if (v < 0) break;
+                    const int j = per_xcd + __hip_atomic_fetch_add(&p.sched[v], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (j < chunk_n(v)) Ln = chunk0(v) + j;
+                }
+            }
+            if (Ln < 0) {          // this workgroup is done; the last one to get here leaves the words zero for the next launch
+                if (__hip_atomic_fetch_add(&p.sched[8], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+                    for (int y = 0; y < 9; ++y) __hip_atomic_store(&p.sched[y], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            *next_l = Ln;
+        };
+        // Early fetch of tile L's operands and scale groups (PRE, above): called between the staging writes and the second barrier of
+        // the epilogue's LAST half.  Offsets as load_seg builds them for segment 0; the lane id is laundered for the same reason.
+        auto early_fetch = [&](int L) {
+            int mi_n, ni_n;
+            tile_of(L, mi_n, ni_n);
+            const int m0n = mi_n * BM, n0n = ni_n * BN;
+            if constexpr (F8 == 2) {
+                const unsigned char* sc_next = p.aexp + (size_t)(NW == 1 ? mi_n >> 1 : mi_n) * 1024;
+                const int nsl_ = ((PB == 2 && MIX) ? p.nk_e1 : nk) - nk_hi, nsg_ = (nsl_ + 3) >> 2;
+                for (int g = wave; g < min(nsg_, 32 - SC_OFF); g += 8) {
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + NS * HT + ((g + SC_OFF) & 31) * 1024);
+                    const unsigned char* src = sc_next + (size_t)g * ((size_t)((p.M + 255) >> 8) * 1024) + lane_e * 16;
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+                }
+            }
+            const GemmParams::KSeg sg = p.seg[0];
+            const bool a2 = (sg.src & GemmParams::SRC_A2) != 0, w2 = (sg.src & GemmParams::SRC_W2) != 0;
+            const bool lo = (sg.src & GemmParams::SRC_LO) != 0;
+            const unsigned short* Ab = (const unsigned short*)(a2 ? p.A2 : p.A);
+            const unsigned short* Wb = (const unsigned short*)(w2 ? (lo ? p.W2lo : p.W2) : (sg.src & GemmParams::SRC_LO16) ? p.Wlo16 : lo ? p.Wlo : p.W);
+            const int la = a2 ? p.lda2 : p.lda, lw = w2 ? p.ldw2 : p.ldw;
+            int t = threadIdx.x;
+            asm volatile("" : "+v"(t));
+            const char* nA = (const char*)(Ab + (size_t)m0n * la + sg.a_col);
+            const char* nB = (const char*)(Wb + (size_t)n0n * lw + sg.w_col);
+            unsigned fA[2][2], fB[2][2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int q = it * 512 + t;
+                const int R = q >> 4, Cp = q & 15;
+                const int C = Cp ^ (R & 15);
+                const int row = 2 * R + (C >> 3), c = C & 7;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int ga = min(m0n + (NW == 1 ? 0 : h * 128) + row, p.M - 1);
+                    const int wrow = NW == 2 ? row : (row >> 5) * 64 + h * 32 + (row & 31);
+                    const int gb = min(n0n + wrow, p.N - 1);
+                    fA[h][it] = (unsigned)((ga - m0n) * la + c * 8) * 2u;
+                    fB[h][it] = (unsigned)((gb - n0n) * lw + c * 8) * 2u;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                const int j = g & 3, kb = (g >> 2) * BK * 2;
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const char* base = (j == 0 || j == 3) ? nA : nB;
+                    const unsigned off = (j == 0) ? fA[0][it] : (j == 1) ? fB[0][it] : (j == 2) ? fB[1][it] : fA[1][it];
+                    pre[g][it] = *(const frag_t*)(base + off + kb);
+                }
+            }
+        };
+        const bool pre_able = PRE && Gtot > 6 && p.seg[0].kt_end >= 2;          // (uniform: a property of the launch)
         {
         const int lane = lane_e, l15 = lane_e & 15, l4 = lane_e >> 4;
         if constexpr (F8 == 1) {    // dequantise: C[m][n] *= ascale[m] * wscale[n]
@@ -961,14 +1080,24 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
             // before it, 8 right after the staging writes (when 64 accumulator registers have been freed)
             float4 ca[8], cb[8];
             const int fcol = n0 + lane * 4;
+            // A tile that lies inside the matrix takes straight-line code (round 6): no bounds test around the residual-row loads and
+            // the stores, so the wait counts the compiler places are exact counts -- not the vmcnt(0) a conditional block forces at
+            // every join (see the store loop below) -- and the LDS reads of the loop can be issued ahead of the arithmetic.
+            const bool interior = m0 + BM <= p.M && n0 + BN <= p.N;
             auto cload = [&](int it) {
                 const int row = rowq + it * 8 + wave;
                 return (row < p.M && fcol < p.N) ? *(const float4*)((const float*)p.C + (size_t)row * p.ldc + fcol)
                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
             };
+            auto cload_in = [&](int it) { return *(const float4*)((const float*)p.C + (size_t)(rowq + it * 8 + wave) * p.ldc + fcol); };
             if constexpr (E_ == EPI_RESADD_F32) {
+                if (interior) {
 #pragma unroll
-                for (int it = 0; it < 8; ++it) ca[it] = (DBG == 6 || DBG == 8) ? make_float4(0.f, 0.f, 0.f, 0.f) : cload(it);
+                    for (int it = 0; it < 8; ++it) ca[it] = (DBG == 6 || DBG == 8) ? make_float4(0.f, 0.f, 0.f, 0.f) : cload_in(it);
+                } else {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) ca[it] = (DBG == 6 || DBG == 8) ? make_float4(0.f, 0.f, 0.f, 0.f) : cload(it);
+                }
             }
             // RoPE epilogue: the (cos, sin) rows of iterations 0-3 are prefetched the same way (2 float4 each)
             const bool rot = E_ == EPI_ROPE_OP && n0 < p.rope_cols;         // rope_cols is a multiple of the tile width
@@ -977,11 +1106,15 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 const int col = n0 + (lane & 31) * 8;
                 return ((const float4*)(p.rope_cs + ((size_t)row * (p.rope_hd >> 1) + ((col % p.rope_hd) >> 1)) * 2))[k];
             };
+            // (round 6: fetched for every column tile, rotated or not -- the table is small and the addresses are always valid.  Under
+            //  `if (rot)` every fetched register was a merge of two paths, the compiler put the copies right behind the loads, and a
+            //  counted wait in front of each copy exposed the loads' latency twice per half)
             if constexpr (E_ == EPI_ROPE_OP) {
-                if (rot) {
 #pragma unroll
-                    for (int it = 0; it < 4; ++it) { ca[2 * it] = rload(it, 0); ca[2 * it + 1] = rload(it, 1); }
-                }
+                for (int it = 0; it < 4; ++it) { ca[2 * it] = rload(it, 0); ca[2 * it + 1] = rload(it, 1); }
+            }
+            if constexpr (PRE) {
+                if (qa == (NW == 1 ? 0 : 1) && dyn && tid == 0) resolve_claim();          // (the claim was requested one epilogue half ago)
             }
             __syncthreads();
             tstamp(4 + 3 * qa);
@@ -997,8 +1130,27 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                             stg[(wr * 64 + i * 16 + 4 * l4 + r) * SLD + (NW == 2 ? wc * 32 : wc * 64 + qb * 32) + j * 16 + l15] = acc[q][i][j][r];
             }
             if constexpr (E_ == EPI_RESADD_F32) {
+                if (interior) {
 #pragma unroll
-                for (int it = 0; it < 8; ++it) cb[it] = (DBG == 6 || DBG == 8) ? make_float4(0.f, 0.f, 0.f, 0.f) : cload(8 + it);
+                    for (int it = 0; it < 8; ++it) cb[it] = (DBG == 6 || DBG == 8) ? make_float4(0.f, 0.f, 0.f, 0.f) : cload_in(8 + it);
+                } else {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) cb[it] = (DBG == 6 || DBG == 8) ? make_float4(0.f, 0.f, 0.f, 0.f) : cload(8 + it);
+                }
+            }
+            if constexpr (PRE) {
+                if (qa == (NW == 1 ? 0 : 1)) {
+                    __builtin_amdgcn_sched_barrier(0);          // the fetch stays behind the staging writes: until there the accumulators own the registers
+                    const int vn = vb + (int)gridDim.x;
+                    Lnext = dyn ? __builtin_amdgcn_readfirstlane(*next_l) : vn < nwg ? chunk0(vn & 7) + (vn >> 3) : -1;
+                    pre_ok = false;
+                    if (pre_able && Lnext >= 0) { early_fetch(Lnext); pre_ok = true; }
+                    else {          // defined on every path through the epilogue: the registers are NOT live across the K loop
+#pragma unroll
+                        for (int g = 0; g < 6; ++g) { asm volatile("" : "=v"(pre[g][0])); asm volatile("" : "=v"(pre[g][1])); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             __syncthreads();
             tstamp(5 + 3 * qa);
@@ -1014,6 +1166,9 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                         bu0 = *(const float4*)(p.bias + bc + 32); bu1 = *(const float4*)(p.bias + bc + 36);
                     }
                 }
+                __builtin_amdgcn_s_waitcnt(0x0F70);          // the bias is retired in straight-line code (see the operand-out loop below)
+                auto glu_rows = [&](auto in_tag) {
+                constexpr bool IN = decltype(in_tag)::value != 0;
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int rl = it * 32 + wave * 4 + (lane >> 4);
@@ -1025,7 +1180,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                         g0.x += bg0.x; g0.y += bg0.y; g0.z += bg0.z; g0.w += bg0.w; g1.x += bg1.x; g1.y += bg1.y; g1.z += bg1.z; g1.w += bg1.w;
                         u0.x += bu0.x; u0.y += bu0.y; u0.z += bu0.z; u0.w += bu0.w; u1.x += bu1.x; u1.y += bu1.y; u1.z += bu1.z; u1.w += bu1.w;
                     }
-                    if (row < p.M && n0 + wcc * 64 + 64 <= p.N) {
+                    if (IN || (row < p.M && n0 + wcc * 64 + 64 <= p.N)) {
                         auto sw = [](float gg, float uu) { return uu * x_sigmoid_fast(gg, 1.f); };
                         const float v[8] = {sw(g0.x, u0.x), sw(g0.y, u0.y), sw(g0.z, u0.z), sw(g0.w, u0.w), sw(g1.x, u1.x), sw(g1.y, u1.y), sw(g1.z, u1.z), sw(g1.w, u1.w)};
                         if (p.oexp) {        // the 16 lanes of this row hold one 128-column block of the output
@@ -1039,6 +1194,8 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                         }
                     }
                 }
+                };
+                if (interior) glu_rows(IC<1>{}); else glu_rows(IC<0>{});
             } else if constexpr (E_ == EPI_ROPE_OP) {
                 // as OUT_OP, no bias; the 8 columns of a lane are 4 (x[i], x[i+hd/2]) pairs of one head
                 const int c8 = lane & 31;
@@ -1047,7 +1204,8 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 if constexpr (BIAS_) {
                     if (col < p.N) { rb0 = *(const float4*)(p.bias + col); rb1 = *(const float4*)(p.bias + col + 4); }
                 }
-                auto body = [&](int it, const float4 a, const float4 bq) {      // a = (c0,s0,c1,s1), bq = (c2,s2,c3,s3)
+                auto body = [&](auto in_tag, int it, const float4 a, const float4 bq) {      // a = (c0,s0,c1,s1), bq = (c2,s2,c3,s3)
+                    constexpr bool IN = decltype(in_tag)::value != 0;
                     const int rl = it * 16 + wave * 2 + (lane >> 5);
                     const int row = rowq + rl;
                     const float* sp = stg + rl * SLD + c8 * 8;
@@ -1055,12 +1213,14 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                     if constexpr (BIAS_) {
                         v0.x += rb0.x; v0.y += rb0.y; v0.z += rb0.z; v0.w += rb0.w; v1.x += rb1.x; v1.y += rb1.y; v1.z += rb1.z; v1.w += rb1.w;
                     }
-                    if (rot) {
+                    {          // (selected, not branched around: the loop stays straight-line code)
                         const float4 x0 = v0, x1 = v1;
-                        v0 = make_float4(x0.x * a.x - x0.y * a.y, x0.y * a.x + x0.x * a.y, x0.z * a.z - x0.w * a.w, x0.w * a.z + x0.z * a.w);
-                        v1 = make_float4(x1.x * bq.x - x1.y * bq.y, x1.y * bq.x + x1.x * bq.y, x1.z * bq.z - x1.w * bq.w, x1.w * bq.z + x1.z * bq.w);
+                        const float4 r0 = make_float4(x0.x * a.x - x0.y * a.y, x0.y * a.x + x0.x * a.y, x0.z * a.z - x0.w * a.w, x0.w * a.z + x0.z * a.w);
+                        const float4 r1 = make_float4(x1.x * bq.x - x1.y * bq.y, x1.y * bq.x + x1.x * bq.y, x1.z * bq.z - x1.w * bq.w, x1.w * bq.z + x1.z * bq.w);
+                        v0 = rot ? r0 : x0;
+                        v1 = rot ? r1 : x1;
                     }
-                    if (row < p.M && col < p.N) {
+                    if (IN || (row < p.M && col < p.N)) {
                         uint4 w, wl;
                         split2p<OT>(v0.x, v0.y, w.x, wl.x); split2p<OT>(v0.z, v0.w, w.y, wl.y);
                         split2p<OT>(v1.x, v1.y, w.z, wl.z); split2p<OT>(v1.z, v1.w, w.w, wl.w);
@@ -1070,14 +1230,17 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 };
                 // the (cos, sin) rows of iterations 4-7 are requested as iterations 0-3 release their registers (one set of 8 float4
                 // instead of two: with both prefetched the epilogue spilled ~100 registers per lane around the staging pass)
+                auto rope_rows = [&](auto in_tag) {
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    body(it, ca[2 * it], ca[2 * it + 1]);
-                    if (rot) { ca[2 * it] = rload(4 + it, 0); ca[2 * it + 1] = rload(4 + it, 1); }
-                }
-                __builtin_amdgcn_sched_barrier(0);          // keep the second half's LDS reads out of the first half's live range
+                    for (int it = 0; it < 4; ++it) {
+                        body(in_tag, it, ca[2 * it], ca[2 * it + 1]);
+                        ca[2 * it] = rload(4 + it, 0); ca[2 * it + 1] = rload(4 + it, 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);          // keep the second half's LDS reads out of the first half's live range
 #pragma unroll
-                for (int it = 0; it < 4; ++it) body(4 + it, ca[2 * it], ca[2 * it + 1]);
+                    for (int it = 0; it < 4; ++it) body(in_tag, 4 + it, ca[2 * it], ca[2 * it + 1]);
+                };
+                if (interior) rope_rows(IC<1>{}); else rope_rows(IC<0>{});
             } else if constexpr (E_ == EPI_OUT_OP) {
                 // 256 columns = 32 chunks of 8: 32 lanes per row, 2 rows per wave-iteration (256 x 128 tiles: 16 lanes, 4 rows)
                 constexpr int LPR = NW == 2 ? 16 : 32, RPW = 64 / LPR;
@@ -1089,16 +1252,22 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 // and picked ONCE (round 6).  Tested inside the loop -- as until then -- the two `p.act` comparisons were three scalar
                 // branches per ELEMENT (64 per wave-iteration: the optimiser did not unswitch the partially unrolled loop) and `p.oexp`
                 // one more per row.
-                auto out_loop = [&](auto act_tag, auto oexp_tag) {
+                // The bias is retired HERE, in straight-line code (round 6): its first use sits in the loop's conditional block, and the
+                // compiler's wait-count pass -- which cannot carry "already waited" across that join and the back edge -- had placed
+                // `s_waitcnt vmcnt(0)` at the head of EVERY iteration: each pair of rows waited for the acknowledgement of the stores
+                // of the pair before it.  A tile inside the matrix (IN) takes a body without the bounds test.
+                __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0); lgkmcnt / expcnt untouched
+                auto out_loop = [&](auto act_tag, auto oexp_tag, auto in_tag) {
                     constexpr int ACT = decltype(act_tag)::value;
                     constexpr bool OEXP = decltype(oexp_tag)::value != 0;
+                    constexpr bool IN = decltype(in_tag)::value != 0;
 #pragma unroll 2        // (4 and 8 measured level on every shape, round 6: the loop is not bound by its own latency chain)
                     for (int it = 0; it < 128 / (8 * RPW); ++it) {
                         const int rl = it * 8 * RPW + wave * RPW + lane / LPR;
                         const int row = rowq + rl;
                         const float* sp = stg + rl * SLD + c8 * 8;
                         float4 v0 = *(const float4*)sp, v1 = *(const float4*)(sp + 4);
-                        if (row < p.M && col < p.N) {
+                        if (IN || (row < p.M && col < p.N)) {
                             float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
@@ -1118,57 +1287,57 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                     }
                 };
                 const bool oe = p.oexp != nullptr;
-                if (p.act == ACT_QUICK_GELU) { if (oe) out_loop(IC<ACT_QUICK_GELU>{}, IC<1>{}); else out_loop(IC<ACT_QUICK_GELU>{}, IC<0>{}); }
-                else if (p.act == ACT_GELU_ERF) { if (oe) out_loop(IC<ACT_GELU_ERF>{}, IC<1>{}); else out_loop(IC<ACT_GELU_ERF>{}, IC<0>{}); }
-                else { if (oe) out_loop(IC<ACT_NONE>{}, IC<1>{}); else out_loop(IC<ACT_NONE>{}, IC<0>{}); }
+                auto pick = [&](auto in_tag) {
+                    if (p.act == ACT_QUICK_GELU) { if (oe) out_loop(IC<ACT_QUICK_GELU>{}, IC<1>{}, in_tag); else out_loop(IC<ACT_QUICK_GELU>{}, IC<0>{}, in_tag); }
+                    else if (p.act == ACT_GELU_ERF) { if (oe) out_loop(IC<ACT_GELU_ERF>{}, IC<1>{}, in_tag); else out_loop(IC<ACT_GELU_ERF>{}, IC<0>{}, in_tag); }
+                    else { if (oe) out_loop(IC<ACT_NONE>{}, IC<1>{}, in_tag); else out_loop(IC<ACT_NONE>{}, IC<0>{}, in_tag); }
+                };
+                if (interior) pick(IC<1>{}); else pick(IC<0>{});
             } else {
                 // fp32 out / residual add: 64 float4 per row, one row per wave-iteration (1 KB contiguous)
                 float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (p.bias && fcol < p.N) bv = *(const float4*)(p.bias + fcol);
+                // Every load this loop consumes (the residual rows, the bias) is retired HERE, in straight-line code, and the arithmetic
+                // stays outside the bounds test (round 6).  With the additions inside `if (row < M ...)` the first use of the loaded
+                // registers sat in a conditional block per iteration; the compiler's wait-count pass cannot carry "already waited" across
+                // such a join, so it placed `s_waitcnt vmcnt(0)` in EVERY iteration -- behind the previous iteration's store, i.e. each
+                // row waited for the acknowledgement of the row before it (4.4 us per 128-row half for 16 stores per wave).
+                auto rows_out = [&](auto in_tag) {
+                    constexpr bool IN = decltype(in_tag)::value != 0;
+                    if constexpr (!IN) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0); lgkmcnt / expcnt untouched
 #pragma unroll
-                for (int it = 0; it < 16; ++it) {
-                    const int rl = it * 8 + wave;
-                    const int row = rowq + rl;
-                    float4 v = *(const float4*)(stg + rl * SLD + lane * 4);
-                    if (row < p.M && fcol < p.N) {
-                        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                        if constexpr (E_ == EPI_RESADD_F32) { const float4 c = it < 8 ? ca[it & 7] : cb[it & 7]; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
-                        if constexpr (DBG == 7 || DBG == 8) { if (v.x == 1.2345e30f) *(float4*)((float*)p.C + (size_t)row * p.ldc + fcol) = v; }
-                        else *(float4*)((float*)p.C + (size_t)row * p.ldc + fcol) = v;
+                    for (int ib = 0; ib < 16; ib += 8) {          // 8 rows' LDS reads in flight, then their additions and stores
+                        float4 r[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) r[i] = *(const float4*)(stg + ((ib + i) * 8 + wave) * SLD + lane * 4);
+                        if constexpr (IN) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int it = ib + i;
+                            const int row = rowq + it * 8 + wave;
+                            float4 v = r[i];
+                            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                            if constexpr (E_ == EPI_RESADD_F32) { const float4 c = it < 8 ? ca[it & 7] : cb[it & 7]; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+                            if (IN || (row < p.M && fcol < p.N)) {
+                                if constexpr (DBG == 7 || DBG == 8) { if (v.x == 1.2345e30f) *(float4*)((float*)p.C + (size_t)row * p.ldc + fcol) = v; }
+                                else *(float4*)((float*)p.C + (size_t)row * p.ldc + fcol) = v;
+                            }
+                        }
                     }
-                }
+                };
+                if (interior) rows_out(IC<1>{}); else rows_out(IC<0>{});
             }
             tstamp(6 + 3 * qa);
         }
         }       // (epilogue scope: laundered lane id)
         tstamp(3);
         ++tile_it;
-        if (dyn) {
-            typedef __attribute__((address_space(3))) volatile int lds_int_t;                    // LDS accesses, not flat ones
-            lds_int_t* next_l = (lds_int_t*)(lds_base + 9 * HT);                                 // behind the staging area
-            if (tid == 0) {
-                int Ln = -1;
-                const int i = per_xcd + claim;
-                if (i < chunk_n(my_xcd)) Ln = chunk0(my_xcd) + i;
-                else {
-                    for (int tries = 0; tries < 16 && Ln < 0; ++tries) {      // own chunk exhausted: help the XCD with the most tiles left
-                        int v = -1, best = 0;
-                        for (int y = 0; y < 8; ++y) {
-                            const int rem = chunk_n(y) - per_xcd - __hip_atomic_load(&p.sched[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (rem > best) { best = rem; v = y; }
-                        }
-                        if (v < 0) break;
-                        const int j = per_xcd + __hip_atomic_fetch_add(&p.sched[v], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (j < chunk_n(v)) Ln = chunk0(v) + j;
-                    }
-                }
-                if (Ln < 0) {          // this workgroup is done; the last one to get here leaves the words zero for the next launch
-                    if (__hip_atomic_fetch_add(&p.sched[8], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
-                        for (int y = 0; y < 9; ++y) __hip_atomic_store(&p.sched[y], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                *next_l = Ln;
-            }
+        if (dyn && PRE) {
+            __syncthreads();      // staging reads done before the next tile's operands reuse the ring (the claim was resolved in the last half)
+            Ldyn = Lnext;
+            if (Ldyn < 0) break;
+        } else if (dyn) {
+            if (tid == 0) resolve_claim();
             __syncthreads();      // staging reads done, the claim visible
             Ldyn = __builtin_amdgcn_readfirstlane(*next_l);        // uniform again: the tile coordinates stay in scalar registers
             __syncthreads();      // ... and read by every wave before the next tile's DMA reuses the ring

@@ -28,7 +28,10 @@ CASES = [("dec.gate_up", 84544, 16384, 3072, L.EPI_SWIGLU_OP, 0, 32, 32), ("dec.
          ("dec.o", 84544, 3072, 3072, L.EPI_RESADD_F32, 0, 0, 32), ("dec.down", 84544, 3072, 8192, L.EPI_RESADD_F32, 0, 0, 32),
          ("clip.qkv", 313888, 3072, 1024, L.EPI_OUT_OP, 0, 0, 23), ("clip.out", 313888, 1024, 1024, L.EPI_RESADD_F32, 0, 0, 23),
          ("clip.fc1", 313888, 4096, 1024, L.EPI_OUT_OP, L.ACT_QUICK_GELU, 32, 23), ("clip.fc2", 313888, 1024, 4096, L.EPI_RESADD_F32, 0, 0, 23),
-         ("llava.gate_up", 64 * 2200, 28672, 4096, L.EPI_SWIGLU_OP, 0, 32, 0), ("llava.down", 64 * 2200, 4096, 14336, L.EPI_RESADD_F32, 0, 0, 0)]
+         ("llava.gate_up", 64 * 2200, 28672, 4096, L.EPI_SWIGLU_OP, 0, 32, 0), ("llava.down", 64 * 2200, 4096, 14336, L.EPI_RESADD_F32, 0, 0, 0),
+         # the CLIP linears as the step runs them: with a bias vector, M not a multiple of the tile height (counted above: weight 0)
+         ("clip.out+bias", 313888 - 100, 1024, 1024, L.EPI_RESADD_F32, 0, 0, 0, True), ("clip.fc2+bias", 313888 - 100, 1024, 4096, L.EPI_RESADD_F32, 0, 0, 0, True),
+         ("clip.fc1+bias", 313888 - 100, 4096, 1024, L.EPI_OUT_OP, L.ACT_QUICK_GELU, 32, 0, True)]
 
 
 def timed(fn):
@@ -45,8 +48,9 @@ def timed(fn):
 
 tot = [0.0, 0.0]
 print(f"{'GEMM':18s} {libs[0][0]:>24s} {libs[1][0]:>24s}   delta   same bits")
-for name, M, N, K, epi, act, oflag, cnt in CASES:
+for name, M, N, K, epi, act, oflag, cnt, *rest in CASES:
     torch.manual_seed(M + N + K)
+    bias = torch.randn(N, device="cuda") if rest and rest[0] else None
     A = torch.randn(M, 2 * K, device="cuda").to(torch.float16)
     A[:, K:] *= 2.0 ** -11
     W = (torch.randn(N, K, device="cuda") * 0.02).to(torch.float16)
@@ -56,8 +60,8 @@ for name, M, N, K, epi, act, oflag, cnt in CASES:
     outs = [torch.zeros(M, 2 * nout if op_out else nout, device="cuda", dtype=torch.float16 if op_out else torch.float32) for _ in libs]
     ae = torch.full((libs[0][1].lr_op_lo8_scratch_bytes(M, K) + libs[0][1].lr_op_lo8_scratch_bytes(M, nout),), 127, dtype=torch.uint8, device="cuda")
     we = C.c_int(0)
-    assert libs[0][1].lr_op_gemm_bt_mixed(P(A), P(W), P(W8), P(ae), P(outs[0]), None, M, N, K, epi, act, L.LR_DT_F16, 7, C.byref(we), S) == 0
-    fns = [(lambda lib=lib, o=o: lib.lr_op_gemm_bt_mixed(P(A), P(W), P(W8), P(ae), P(o), None, M, N, K, epi, act, L.LR_DT_F16, oflag, C.byref(we), S)) for (_, lib), o in zip(libs, outs)]
+    assert libs[0][1].lr_op_gemm_bt_mixed(P(A), P(W), P(W8), P(ae), P(outs[0]), P(bias), M, N, K, epi, act, L.LR_DT_F16, 7, C.byref(we), S) == 0
+    fns = [(lambda lib=lib, o=o: lib.lr_op_gemm_bt_mixed(P(A), P(W), P(W8), P(ae), P(o), P(bias), M, N, K, epi, act, L.LR_DT_F16, oflag, C.byref(we), S)) for (_, lib), o in zip(libs, outs)]
     for o, f in zip(outs, fns):            # one launch each from zeroed outputs: the bits
         o.zero_()
         assert f() == 0
