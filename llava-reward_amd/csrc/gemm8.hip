@@ -42,9 +42,6 @@
 #ifndef LR_GEMM_COMP_WAIT
 #define LR_GEMM_COMP_WAIT 1
 #endif
-#ifndef LR_GEMM_PRE
-#define LR_GEMM_PRE 0
-#endif
 
 namespace lr {
 
@@ -206,24 +203,6 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
     const int my_xcd = (int)blockIdx.x & 7, per_xcd = (int)gridDim.x >> 3;
     const bool dyn = PB == 2 && p.sched != nullptr;
     int Ldyn = -1;
-    // PRE (round 6): the first PF2 half-tiles of the NEXT tile are fetched into registers under the second half of this tile's epilogue
-    // -- the accumulators are dead behind its staging writes -- and written to the ring at the top of the next tile, where the LDS-DMA
-    // prologue used to expose its whole latency (2-3 us of a 48 us CLIP tile); the next tile's scale groups go out by LDS-DMA at the
-    // same point.  Same bytes at the same LDS addresses: the K loop cannot tell.
-    constexpr bool PRE = LR_GEMM_PRE && PB == 2 && LR_GEMM_SADDR && F8 != 3 && (DBG == 0 || DBG == 3 || DBG == 9 || (DBG >= 6 && DBG <= 8));
-    constexpr int SC_OFF = PRE ? 2 : 0;          // scale group g lives in slot (g + SC_OFF) & 31: slots 0, 1 lie under the staging area's last 2 KB
-    frag_t pre[6][2];
-#pragma unroll
-    for (int g = 0; g < 6; ++g) { asm volatile("" : "=v"(pre[g][0])); asm volatile("" : "=v"(pre[g][1])); }      // (defined, costs nothing)
-    bool pre_ok = false;
-    int Lnext = -1;
-    auto tile_of = [&](int L, int& mi_, int& ni_) {
-        const int band = L / (p.gm * Nt);
-        const int within = L - band * (p.gm * Nt);
-        const int rows_in_band = min(p.gm, Mt - band * p.gm);
-        mi_ = band * p.gm + within % rows_in_band;
-        ni_ = within / rows_in_band;
-    };
     for (int vb = blockIdx.x; vb < nwg;) {
         tstamp(0);
         int L;
@@ -428,16 +407,15 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         const size_t sc_plane = (size_t)((p.M + 255) >> 8) * 1024;
         const int nsl = nk_lo - nk_hi, nsg = (nsl + 3) >> 2;
         const bool late_sc = nsg > SC_GROUPS;          // more scale groups than LDS slots: later groups follow the ones they replace
-        auto issue_scales_of = [&](const unsigned char* tile_base, int g) {
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + NS * HT + ((g + SC_OFF) & (SC_GROUPS - 1)) * 1024);
+        auto issue_scales = [&](int g) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + NS * HT + (g & (SC_GROUPS - 1)) * 1024);
             int l16 = lane * 16;
             asm volatile("" : "+v"(l16));          // rebuilt at each call: hoisted, the address is one more 64-bit value spilled across the K loop
-            const unsigned char* src = tile_base + (size_t)g * sc_plane + l16;
+            const unsigned char* src = sc_tile + (size_t)g * sc_plane + l16;
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
         };
-        auto issue_scales = [&](int g) { issue_scales_of(sc_tile, g); };
 
         // F8 == 3: the FP6 K-tiles' scales, one byte per (row, 32 elements) for both operands: per residual K-tile j one KB of A scales
         // (lane (row, q) of wave group wr: 8 bytes = its 4 row tiles of A half 0, then of A half 1, block q) and one KB of W scales
@@ -478,10 +456,8 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         static_assert(F8 != 2 || (NS + 2) * HT <= 160 * 1024, "the scale slices live behind the ring");
         static_assert(NS - PF2 >= 2, "ring hazard distances (super-phase schedule)");
         int islot = 0;
-        const bool pre_now = PRE && pre_ok;          // this tile's first half-tiles are in registers, its scale groups 0 .. 29 on their way
         if constexpr (F8 == 2) {         // this tile's scale groups first: the oldest entries of the queue, retired by the prologue's wait
-            for (int g = wave; g < min(nsg, SC_GROUPS); g += 8)
-                if (!pre_now || g >= SC_GROUPS - SC_OFF) issue_scales(g);
+            for (int g = wave; g < min(nsg, SC_GROUPS); g += 8) issue_scales(g);
         }
         if constexpr (F8 == 3) {
             for (int x = wave; x < min(2 * nsl, 32); x += 8) issue_scales6(x);
@@ -501,18 +477,6 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                              : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
             }
         };
-        if (pre_now) {
-            // (the previous tile's closing barrier is behind us: its staging reads are done; the bookkeeping is the DMA path's)
-#pragma unroll
-            for (int g = 0; g < PF2; ++g) {
-                if ((g & 3) == 0) ktile_begin();
-                *(frag_t*)(smem + islot * HT + tid * 16) = pre[g][0];
-                *(frag_t*)(smem + islot * HT + 8192 + tid * 16) = pre[g][1];
-                if ((g & 3) == 3) ktile_end();
-                islot = (islot + 1 == NS) ? 0 : islot + 1;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        } else {
 #pragma unroll
         for (int g = 0; g < PF2; ++g) {
             if (g < Gtot) {
@@ -524,7 +488,6 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         }
         if (Gtot > PF2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT2) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
         LR_BARRIER();
         if (wr == 1) LR_BARRIER();                      // stagger the second wave group by one barrier
         tstamp(1);
@@ -602,7 +565,7 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                     if (sp == 0) {
                         typedef int v2i_t __attribute__((ext_vector_type(2)));
                         typedef __attribute__((address_space(3))) const volatile v2i_t lds_scale_t;       // an LDS read, never a flat one
-                        const v2i_t e2 = *(lds_scale_t*)(lds_base + NS * HT + ((((j >> 2) + SC_OFF) & (SC_GROUPS - 1)) << 10) + ((j & 3) << 8) + sc_voff);
+                        const v2i_t e2 = *(lds_scale_t*)(lds_base + NS * HT + (((j >> 2) & (SC_GROUPS - 1)) << 10) + ((j & 3) << 8) + sc_voff);
                         ea[0] = (NW == 1 && (mi & 1)) ? e2.y : e2.x; ea[1] = e2.y;
                         if (late_sc) {                                 // (K > 16384 only: one uniform test per K-tile for every other shape)
                             const int g = (j >> 2) - 1 + SC_GROUPS;    // its slot was last read in the K-tile before this one
@@ -919,88 +882,6 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         // use, inside the residual K-tile loop -- drained the DMA ring every K-tile of the RoPE kernel.
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
-        typedef __attribute__((address_space(3))) volatile int lds_int_t;                    // LDS accesses, not flat ones
-        // the word the claimed tile travels through: behind the staging area -- or, with the early fetch (whose scale groups land there
-        // while the epilogue runs), in the padding of staging row 0
-        lds_int_t* next_l = (lds_int_t*)(lds_base + (PRE ? 256 * 4 : 9 * HT));
-        auto resolve_claim = [&]() {          // thread 0: claim -> tile index (or -1), left in *next_l
-            int Ln = -1;
-            const int i = per_xcd + claim;
-            if (i < chunk_n(my_xcd)) Ln = chunk0(my_xcd) + i;
-            else {
-                for (int tries = 0; tries < 16 && Ln < 0; ++tries) {      // own chunk exhausted: help the XCD with the most tiles left
-                    int v = -1, best = 0;
-                    for (int y = 0; y < 8; ++y) {
-                        const int rem = chunk_n(y) - per_xcd - __hip_atomic_load(&p.sched[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (rem > best) { best = rem; v = y; }
-                    }
-                    if (v < 0) break;
-                    const int j = per_xcd + __hip_atomic_fetch_add(&p.sched[v], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (j < chunk_n(v)) Ln = chunk0(v) + j;
-                }
-            }
-            if (Ln < 0) {          // this workgroup is done; the last one to get here leaves the words zero for the next launch
-                if (__hip_atomic_fetch_add(&p.sched[8], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
-                    for (int y = 0; y < 9; ++y) __hip_atomic_store(&p.sched[y], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            *next_l = Ln;
-        };
-        // Early fetch of tile L's operands and scale groups (PRE, above): called between the staging writes and the second barrier of
-        // the epilogue's LAST half.  Offsets as load_seg builds them for segment 0; the lane id is laundered for the same reason.
-        auto early_fetch = [&](int L) {
-            int mi_n, ni_n;
-            tile_of(L, mi_n, ni_n);
-            const int m0n = mi_n * BM, n0n = ni_n * BN;
-            if constexpr (F8 == 2) {
-                const unsigned char* sc_next = p.aexp + (size_t)(NW == 1 ? mi_n >> 1 : mi_n) * 1024;
-                const int nsl_ = ((PB == 2 && MIX) ? p.nk_e1 : nk) - nk_hi, nsg_ = (nsl_ + 3) >> 2;
-                for (int g = wave; g < min(nsg_, 32 - SC_OFF); g += 8) {
-                    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + NS * HT + ((g + SC_OFF) & 31) * 1024);
-                    const unsigned char* src = sc_next + (size_t)g * ((size_t)((p.M + 255) >> 8) * 1024) + lane_e * 16;
-                    unsigned keep;
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-                }
-            }
-            const GemmParams::KSeg sg = p.seg[0];
-            const bool a2 = (sg.src & GemmParams::SRC_A2) != 0, w2 = (sg.src & GemmParams::SRC_W2) != 0;
-            const bool lo = (sg.src & GemmParams::SRC_LO) != 0;
-            const unsigned short* Ab = (const unsigned short*)(a2 ? p.A2 : p.A);
-            const unsigned short* Wb = (const unsigned short*)(w2 ? (lo ? p.W2lo : p.W2) : (sg.src & GemmParams::SRC_LO16) ? p.Wlo16 : lo ? p.Wlo : p.W);
-            const int la = a2 ? p.lda2 : p.lda, lw = w2 ? p.ldw2 : p.ldw;
-            int t = threadIdx.x;
-            asm volatile("" : "+v"(t));
-            const char* nA = (const char*)(Ab + (size_t)m0n * la + sg.a_col);
-            const char* nB = (const char*)(Wb + (size_t)n0n * lw + sg.w_col);
-            unsigned fA[2][2], fB[2][2];
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int q = it * 512 + t;
-                const int R = q >> 4, Cp = q & 15;
-                const int C = Cp ^ (R & 15);
-                const int row = 2 * R + (C >> 3), c = C & 7;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int ga = min(m0n + (NW == 1 ? 0 : h * 128) + row, p.M - 1);
-                    const int wrow = NW == 2 ? row : (row >> 5) * 64 + h * 32 + (row & 31);
-                    const int gb = min(n0n + wrow, p.N - 1);
-                    fA[h][it] = (unsigned)((ga - m0n) * la + c * 8) * 2u;
-                    fB[h][it] = (unsigned)((gb - n0n) * lw + c * 8) * 2u;
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < 6; ++g) {
-                const int j = g & 3, kb = (g >> 2) * BK * 2;
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const char* base = (j == 0 || j == 3) ? nA : nB;
-                    const unsigned off = (j == 0) ? fA[0][it] : (j == 1) ? fB[0][it] : (j == 2) ? fB[1][it] : fA[1][it];
-                    pre[g][it] = *(const frag_t*)(base + off + kb);
-                }
-            }
-        };
-        const bool pre_able = PRE && Gtot > 6 && p.seg[0].kt_end >= 2;          // (uniform: a property of the launch)
         {
         const int lane = lane_e, l15 = lane_e & 15, l4 = lane_e >> 4;
         if constexpr (F8 == 1) {    // dequantise: C[m][n] *= ascale[m] * wscale[n]
@@ -1113,9 +994,6 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) { ca[2 * it] = rload(it, 0); ca[2 * it + 1] = rload(it, 1); }
             }
-            if constexpr (PRE) {
-                if (qa == (NW == 1 ? 0 : 1) && dyn && tid == 0) resolve_claim();          // (the claim was requested one epilogue half ago)
-            }
             __syncthreads();
             tstamp(4 + 3 * qa);
 #pragma unroll
@@ -1136,20 +1014,6 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                 } else {
 #pragma unroll
                     for (int it = 0; it < 8; ++it) cb[it] = (DBG == 6 || DBG == 8) ? make_float4(0.f, 0.f, 0.f, 0.f) : cload(8 + it);
-                }
-            }
-            if constexpr (PRE) {
-                if (qa == (NW == 1 ? 0 : 1)) {
-                    __builtin_amdgcn_sched_barrier(0);          // the fetch stays behind the staging writes: until there the accumulators own the registers
-                    const int vn = vb + (int)gridDim.x;
-                    Lnext = dyn ? __builtin_amdgcn_readfirstlane(*next_l) : vn < nwg ? chunk0(vn & 7) + (vn >> 3) : -1;
-                    pre_ok = false;
-                    if (pre_able && Lnext >= 0) { early_fetch(Lnext); pre_ok = true; }
-                    else {          // defined on every path through the epilogue: the registers are NOT live across the K loop
-#pragma unroll
-                        for (int g = 0; g < 6; ++g) { asm volatile("" : "=v"(pre[g][0])); asm volatile("" : "=v"(pre[g][1])); }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __syncthreads();
@@ -1332,12 +1196,32 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
         }       // (epilogue scope: laundered lane id)
         tstamp(3);
         ++tile_it;
-        if (dyn && PRE) {
-            __syncthreads();      // staging reads done before the next tile's operands reuse the ring (the claim was resolved in the last half)
-            Ldyn = Lnext;
-            if (Ldyn < 0) break;
-        } else if (dyn) {
-            if (tid == 0) resolve_claim();
+        if (dyn) {
+            typedef __attribute__((address_space(3))) volatile int lds_int_t;                    // LDS accesses, not flat ones
+            lds_int_t* next_l = (lds_int_t*)(lds_base + 9 * HT);                                 // behind the staging area
+            if (tid == 0) {
+                int Ln = -1;
+                const int i = per_xcd + claim;
+                if (i < chunk_n(my_xcd)) Ln = chunk0(my_xcd) + i;
+                else {
+                    for (int tries = 0; tries < 16 && Ln < 0; ++tries) {      // own chunk exhausted: help the XCD with the most tiles left
+                        int v = -1, best = 0;
+                        for (int y = 0; y < 8; ++y) {
+                            const int rem = chunk_n(y) - per_xcd - __hip_atomic_load(&p.sched[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (rem > best) { best = rem; v = y; }
+                        }
+                        if (v < 0) break;
+                        const int j = per_xcd + __hip_atomic_fetch_add(&p.sched[v], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (j < chunk_n(v)) Ln = chunk0(v) + j;
+                    }
+                }
+                if (Ln < 0) {          // this workgroup is done; the last one to get here leaves the words zero for the next launch
+                    if (__hip_atomic_fetch_add(&p.sched[8], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+                        for (int y = 0; y < 9; ++y) __hip_atomic_store(&p.sched[y], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                *next_l = Ln;
+            }
             __syncthreads();      // staging reads done, the claim visible
             Ldyn = __builtin_amdgcn_readfirstlane(*next_l);        // uniform again: the tile coordinates stay in scalar registers
             __syncthreads();      // ... and read by every wave before the next tile's DMA reuses the ring
