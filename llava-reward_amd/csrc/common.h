@@ -153,6 +153,18 @@ __device__ __forceinline__ float x_sigmoid_fast(float x, float a) {
     return x * __builtin_amdgcn_rcpf(1.f + e);
 }
 
+// One RoPE pair, (x, y) = (q[i], q[i + hd/2]) -> (x cos - y sin, y cos + x sin), in the REFERENCE's arithmetic
+// (modeling_phi3_v.py:521-553, q * cos + rotate_half(q) * sin in fp32): two rounded products and one rounded sum per output, no fused
+// multiply-add.  Contraction is switched off for these four lines on purpose (round 6): left as a * b - c * d, which of the two products the
+// compiler fuses depends on the code around the expression -- it differed between instantiations of one GEMM kernel -- and the
+// rewards move with it (1 ulp of the operand type on a few elements per launch).
+// (the pragma, not __fmul_rn / __fadd_rn: HIP defines those as the plain operators, which contract like any others)
+__device__ __forceinline__ void rope_pair(float x, float y, float c, float sn, float& ox, float& oy) {
+#pragma clang fp contract(off)
+    ox = x * c - y * sn;
+    oy = y * c + x * sn;
+}
+
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short u) {
     return __builtin_bit_cast(float, ((unsigned)u) << 16);
 }

@@ -1079,8 +1079,9 @@ __global__ __launch_bounds__(512) void gemm_bt8_kernel(GemmParams p) {
                     }
                     {          // (selected, not branched around: the loop stays straight-line code)
                         const float4 x0 = v0, x1 = v1;
-                        const float4 r0 = make_float4(x0.x * a.x - x0.y * a.y, x0.y * a.x + x0.x * a.y, x0.z * a.z - x0.w * a.w, x0.w * a.z + x0.z * a.w);
-                        const float4 r1 = make_float4(x1.x * bq.x - x1.y * bq.y, x1.y * bq.x + x1.x * bq.y, x1.z * bq.z - x1.w * bq.w, x1.w * bq.z + x1.z * bq.w);
+                        float4 r0, r1;          // (common.h rope_pair: the reference's own arithmetic, no contraction left to the compiler)
+                        rope_pair(x0.x, x0.y, a.x, a.y, r0.x, r0.y); rope_pair(x0.z, x0.w, a.z, a.w, r0.z, r0.w);
+                        rope_pair(x1.x, x1.y, bq.x, bq.y, r1.x, r1.y); rope_pair(x1.z, x1.w, bq.z, bq.w, r1.z, r1.w);
                         v0 = rot ? r0 : x0;
                         v1 = rot ? r1 : x1;
                     }

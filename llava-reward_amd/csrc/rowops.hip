@@ -462,8 +462,10 @@ __global__ __launch_bounds__(256) void rope_split_kernel(const float* __restrict
         const int i0 = (col % hd) >> 1;
         const float4 x = *(const float4*)(src + col);
         const float4 c = t[i0 >> 1];
-        store4s<OT>(out, row, ld, prec, col, x.x * c.x - x.y * c.y, x.y * c.x + x.x * c.y,
-                    x.z * c.z - x.w * c.w, x.w * c.z + x.z * c.w);
+        float4 r;
+        rope_pair(x.x, x.y, c.x, c.y, r.x, r.y);
+        rope_pair(x.z, x.w, c.z, c.w, r.z, r.w);
+        store4s<OT>(out, row, ld, prec, col, r.x, r.y, r.z, r.w);
     }
     for (int c = threadIdx.x; c < (v_cols >> 2); c += 256) {
         const float4 v = *(const float4*)(src + rope_cols + 4 * c);

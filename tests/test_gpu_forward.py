@@ -87,7 +87,11 @@ def test_tiny_vs_oracle(dtype, tol, variant):
     if dtype != "f16x2":
         emu = orc.custom_forward(W, cfg, batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["image_sizes"],
                                  opr=orc.f16_round if dtype == "f16" else orc.bf16_round)
-        assert (got - emu).abs().max().item() < (5e-4 if dtype == "f16" else 4e-3)      # (bf16: rounding noise, measured 2.0e-3 .. 3.3e-3 across builds)
+        # (rounding noise of the single-pass modes, not a parity bar -- that is the line above.  bf16: measured 2.0e-3 .. 3.3e-3 across
+        #  builds; f16: < 5e-4 until round 6, 5.4e-4 .. 5.9e-4 across the round-6 builds that moved the fused RoPE's rounding points --
+        #  the last of them to the reference's own arithmetic, common.h rope_pair, with which the distance to the fp32 oracle above
+        #  FELL from 3.4e-4 to 2.9e-4)
+        assert (got - emu).abs().max().item() < (7e-4 if dtype == "f16" else 4e-3)
     # device-side synthetic weights == uploaded numpy weights, bit for bit
     m2 = _model(cfg, seed, dtype, upload=False)
     assert torch.equal(_fwd(m2, batch), got)
