@@ -221,19 +221,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
         }
     };
 
-    // ---- prologue: first two tiles in flight, then the key bitmask and the Q fragments ----
-    if (ntiles > 0) issue(0, true);
-    if (PD > 1 && ntiles > 1) issue(1, true);
-    {
-        const int w0 = kbeg / KT, w1 = (kend + KT - 1) / KT;
-        for (int w = w0 + wave; w < w1; w += NW) {
-            const int kk = w * KT + lane;
-            bool ok = kk < S;
-            if (ok && p.mask) ok = p.mask[(size_t)b * S + kk] != 0;
-            const unsigned long long bits = __ballot(ok);
-            if (lane == 0) { sBits[2 * w] = (unsigned)bits; sBits[2 * w + 1] = (unsigned)(bits >> 32); }
-        }
-    }
+    // ---- prologue: the Q fragments requested FIRST, then the first two tiles by LDS-DMA, then the key bitmask ----
+    // (round 6: the order used to be tiles, bitmask, Q.  The bitmask's mask load -- or, without a mask, the join behind its branch --
+    //  carries a `vmcnt(0)`, which retires in order: the tiles had to LAND before the Q loads were even issued, and their latency
+    //  followed: two exposed round trips per workgroup instead of one.  The 577-token CLIP workgroups and the ragged Qwen windows live
+    //  for ten key tiles or fewer.)
     uint4 qf[KSTEPS];       // lane (c,h) holds Q[q0+c][16*ks + 8h .. +7]
     {
         const int qrow = max(min(q0 + lc, S - 1), 0);
@@ -247,6 +239,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
         const unsigned short* src = Qp + (rowbase + qrow) * p.ldq + p.lo_off + 8 * lh;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) qfl[ks] = *(const uint4*)(src + 16 * ks);
+    }
+    __builtin_amdgcn_sched_barrier(0);          // (the requests stay in front of the DMA issue)
+    if (ntiles > 0) issue(0, true);
+    if (PD > 1 && ntiles > 1) issue(1, true);
+    {
+        const int w0 = kbeg / KT, w1 = (kend + KT - 1) / KT;
+        for (int w = w0 + wave; w < w1; w += NW) {
+            const int kk = w * KT + lane;
+            bool ok = kk < S;
+            if (ok && p.mask) ok = p.mask[(size_t)b * S + kk] != 0;
+            const unsigned long long bits = __ballot(ok);
+            if (lane == 0) { sBits[2 * w] = (unsigned)bits; sBits[2 * w + 1] = (unsigned)(bits >> 32); }
+        }
     }
     // Retire the ordinary loads HERE (vmcnt(0), expcnt/lgkmcnt untouched).  Otherwise hipcc puts its waits
     // for the Q loads at their first use inside the loop, where a vmcnt(0) would drain the DMA ring on
