@@ -245,12 +245,28 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_kernel(AttnPara
     if (PD > 1 && ntiles > 1) issue(1, true);
     {
         const int w0 = kbeg / KT, w1 = (kend + KT - 1) / KT;
-        for (int w = w0 + wave; w < w1; w += NW) {
-            const int kk = w * KT + lane;
-            bool ok = kk < S;
-            if (ok && p.mask) ok = p.mask[(size_t)b * S + kk] != 0;
-            const unsigned long long bits = __ballot(ok);
-            if (lane == 0) { sBits[2 * w] = (unsigned)bits; sBits[2 * w + 1] = (unsigned)(bits >> 32); }
+        if (p.mask) {
+            // A wave's mask words, eight key tiles at a time: all loads first (unconditional, addresses clamped), then the ballots.
+            // One tile per iteration -- load, wait, ballot -- exposed a round trip per key tile: five or six per wave and workgroup at
+            // S = 2642, ~4 us of a ~90 us workgroup (round 6).
+            constexpr int J = 8;
+            const int64_t* mrow = p.mask + (size_t)b * S;
+            for (int w = w0 + wave; w < w1; w += NW * J) {
+                int64_t mv[J];
+#pragma unroll
+                for (int j = 0; j < J; ++j) mv[j] = mrow[min(min(w + j * NW, w1 - 1) * KT + lane, S - 1)];
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const int ww = w + j * NW;
+                    const unsigned long long bits = __ballot(ww * KT + lane < S && mv[j] != 0);
+                    if (ww < w1 && lane == 0) { sBits[2 * ww] = (unsigned)bits; sBits[2 * ww + 1] = (unsigned)(bits >> 32); }
+                }
+            }
+        } else {
+            for (int w = w0 + wave; w < w1; w += NW) {
+                const unsigned long long bits = __ballot(w * KT + lane < S);
+                if (lane == 0) { sBits[2 * w] = (unsigned)bits; sBits[2 * w + 1] = (unsigned)(bits >> 32); }
+            }
         }
     }
     // Retire the ordinary loads HERE (vmcnt(0), expcnt/lgkmcnt untouched).  Otherwise hipcc puts its waits
