@@ -147,6 +147,33 @@ def test_gemm_fused_rope_epilogue(lib, dt):
     assert (err <= ulp * refb.abs() + 2e-4).all(), err.max().item()
 
 
+def test_fused_rope_is_the_reference_arithmetic_bit_for_bit(lib):
+    """The rotation of the fused epilogue is q * cos + rotate_half(q) * sin as the reference evaluates it in fp32
+    (modeling_phi3_v.py:521-553): two ROUNDED products and one rounded sum per output, no fused multiply-add (common.h rope_pair; left
+    to the compiler, which product is fused differed between instantiations of one kernel -- round 6).  Inputs whose GEMM sums are exact
+    in fp32 (small integers) make the check bit for bit: the kernel's f16 output must equal the f16 rounding of torch's own mul / mul /
+    add on the same fp32 values, on inside tiles, edge tiles and the narrow-tile instantiation alike."""
+    for M, tile in ((700, 5), (1500, -1), (2100, 6), (256, -1)):          # (-1 / 6: the product kernel, narrow tiles chosen by M)
+        D, hd, K = 384, 96, 128
+        N, half = 3 * D, hd // 2
+        g = torch.Generator().manual_seed(M)
+        A = torch.randint(-4, 5, (M, K), generator=g).float().cuda().half()
+        W = torch.randint(-1, 2, (N, K), generator=g).float().cuda().half()
+        ang = rnd((M, half), 35, 3.0)
+        cs = torch.stack([torch.cos(ang) * 1.19, torch.sin(ang) * 1.19], dim=-1).contiguous()
+        y = A.float() @ W.float().t()                      # |sums| <= 512: exact in fp32 in any order
+        assert (y == y.round()).all()
+        qk = y[:, :2 * D].view(M, 2 * D // hd, half, 2)
+        c, s_ = cs[:, None, :, 0], cs[:, None, :, 1]
+        ref = y.clone()
+        x0, x1 = qk[..., 0], qk[..., 1]
+        ref[:, :2 * D] = torch.stack([torch.sub(torch.mul(x0, c), torch.mul(x1, s_)), torch.add(torch.mul(x1, c), torch.mul(x0, s_))], dim=-1).reshape(M, 2 * D)
+        out = torch.zeros(M, N, device="cuda", dtype=torch.float16)
+        assert lib.lr_op_gemm_rope(P(A), P(W), P(out), P(None), P(cs), M, N, K, 2 * D, hd, L.LR_DT_F16, tile, stream()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref.half()), (M, tile, (out.float() - ref.half().float()).abs().max().item())
+
+
 def _attn_ref(q, k, v, mask, causal, scale):
     # q,k,v [B,H,S,hd] fp32; mask [B,S] or None
     B, H, S, _ = q.shape
