@@ -34,8 +34,8 @@ TOL_BF16 = 8e-3
 # Outlier-bearing full-size rows (synth.PROFILE_OUTLIER: |reward| up to 3.8, every rounding amplified 15-25x).  Round 6 settled whose
 # error the distance to the reference is there: tests/golden/fp64_full_rows.json holds the oracle's DOUBLE-precision reward of these rows
 # (make_fp64_fixture.py), and on the GPM row the REFERENCE's own fp32 arithmetic sits 2.1e-4 from it (|reference_fp32 - fp64|; the fp32
-# oracle, another draw of the same noise: 3.1e-5), while the HIP strict form sits 1.5e-5 .. 1.0e-4 from the fp64 value (two GEMM tile shapes,
-# profiles/r6_outlier_fp64.log).  So |hip - reference| <= 3e-4 on these rows is mostly the reference's noise (2.1e-4) plus ours (<= 1.1e-4),
+# oracle, another draw of the same noise: 3.1e-5), while the HIP strict form sits 1.5e-5 .. 2.3e-5 from the fp64 value (two GEMM tile shapes; 1.0e-4 before the fused RoPE took the reference's rounding points,
+# profiles/r6_outlier_fp64.log).  So |hip - reference| <= 3e-4 on these rows is mostly the reference's noise (2.1e-4) plus ours (<= 2.3e-5),
 # and the sharper statement is the one against fp64: the strict form within TOL_FP64 of it.  (Round 5 had widened the bound to 8e-4
 # after the attention kernels' lazy softmax maximum moved the strict form to 5.2e-4 from the reference / 3.1e-4 from fp64: the strict
 # stages run the exact maximum again -- AttnParams::lazy_t = 0 -- and the 3e-4 bound is back.)
@@ -602,7 +602,7 @@ def test_reference_golden_full_size(path, dtype):
     if dtype == "f16x2":
         # strict parity form: measured 2.6e-6 / 5.5e-6 on benign rows.  On the outlier-bearing rows (|reward| up to 3.8, every rounding
         # amplified 15-25x) the fp32 summation order itself shows: 5e-6 (BT row), 1.07e-4 (GPM row, where the reference itself is
-        # 2.1e-4 from the fp64 value and this form 1.0e-4) -- held to 3e-4 there
+        # 2.1e-4 from the fp64 value and this form 2.3e-5) -- held to 3e-4 there
         assert err < (TOL_OUTLIER if outlier else TOL_X2)
     elif dtype == "f16x2f8" and outlier:
         # The outlier-bearing weight set amplifies ANY operand rounding 15-25x (single-pass f16 lands 1.3e-2 from the strict form there
